@@ -1,0 +1,191 @@
+/*
+ * neolssvm_hip.h - C ABI of the MI355X (gfx950) implementation of the neo-ls-svm fit/predict hot path.
+ *
+ * The reference (lsorber/neo-ls-svm, pure Python) has no FFI; its only seams for this path are two
+ * private solver methods and three public inference methods.  Each entry point below names the
+ * reference interface it replaces (file:line into the reference tree, src/neo_ls_svm/...):
+ *
+ *   nls_featuremap          RandomFourierFeatures.transform              _feature_maps.py:153-203
+ *                           (AffineFeatureMap.transform inside it)       _affine_feature_map.py:72-92
+ *   nls_gram_only           first product of _optimize_beta_gamma        _neo_ls_svm.py:110-114,127
+ *   nls_primal_fit          NeoLSSVM._optimize_beta_gamma(phi, y, s, C)  _neo_ls_svm.py:77-189
+ *                           fused with the transform that feeds it       _neo_ls_svm.py:386,401-402
+ *   nls_primal_predict      decision_function / predict_std (primal)     _neo_ls_svm.py:661-665, 464-469,477
+ *   nls_dual_fit            NeoLSSVM._optimize_alpha_gamma(X, y, s)      _neo_ls_svm.py:191-325
+ *   nls_dual_predict        decision_function / predict_std (dual)       _neo_ls_svm.py:666-671, 470-477
+ *
+ * Conventions
+ *   - Every call returns 0 on success, non-zero on failure; nls_last_error() gives the message.
+ *     NLS_ERR_ARG    bad argument               (the Python mirror raises ValueError)
+ *     NLS_ERR_HIP    HIP / rocBLAS failure      (RuntimeError)
+ *     NLS_ERR_LINALG rocSOLVER info != 0        (numpy.linalg.LinAlgError, like scipy's cho_factor)
+ *     NLS_ERR_COMM   the all-reduce hook failed (RuntimeError)
+ *   - All matrices are dense, C-contiguous (row-major) float64 unless stated; complex values are
+ *     interleaved (re, im) pairs, i.e. numpy complex128.
+ *   - Bulk inputs (X, y, s, Xt, Xq) may be HOST or DEVICE pointers; the library asks the HIP runtime
+ *     which (hipPointerGetAttributes).  Device-resident inputs are used in place, host inputs are
+ *     staged with one H2D copy.  Small parameter arrays (shift, scale, B, gammas, beta, L, alpha) and
+ *     all outputs are host pointers.  Nothing is retained after a call returns.
+ *   - Calls are blocking; one host thread per context.  The library never uses a CPU fallback.
+ *   - Multi-GPU: one process and one context per GPU, rows sharded by the caller.  The library calls
+ *     the registered all-reduce hook (sum over ranks, in place, on a DEVICE buffer of doubles) at the
+ *     three points where the path exchanges data: {sum s, sum s*y, n}, the Hermitian block A||b, and
+ *     the per-gamma error vectors.  Without a hook the context is single-rank.
+ */
+#ifndef NEOLSSVM_HIP_H
+#define NEOLSSVM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NLS_OK 0
+#define NLS_ERR_ARG 1
+#define NLS_ERR_HIP 2
+#define NLS_ERR_LINALG 3
+#define NLS_ERR_COMM 4
+
+#define NLS_ABI_VERSION 1
+#define NLS_NUM_TIMINGS 24
+
+typedef struct nls_ctx nls_ctx;
+
+/* Sum-all-reduce of `count` doubles at device address `buf`, in place, over all ranks; return 0 on
+ * success.  The library has synchronised its stream before the call and expects the result to be
+ * complete (visible to any stream) on return. */
+typedef int (*nls_allreduce_fn)(void* buf, size_t count, void* user);
+
+/* ---- context ---------------------------------------------------------------------------------- */
+int nls_abi_version(void);
+int nls_ctx_create(int device, nls_ctx** ctx);
+void nls_ctx_destroy(nls_ctx* ctx);
+/* Message of the last failure on this context (ctx == NULL: last failure of nls_ctx_create). */
+const char* nls_last_error(const nls_ctx* ctx);
+/* Register the collective hook; world == 1 or fn == NULL resets to single-rank. */
+int nls_set_allreduce(nls_ctx* ctx, nls_allreduce_fn fn, void* user, int rank, int world);
+/* Upper bound, in bytes, on the device workspace the context may hold (0 = default: 60% of HBM). */
+int nls_set_workspace_limit(nls_ctx* ctx, size_t bytes);
+
+/* ---- device memory plumbing (so a host without a GPU array library can keep inputs resident) -- */
+int nls_device_malloc(nls_ctx* ctx, size_t bytes, void** dptr);
+int nls_device_free(nls_ctx* ctx, void* dptr);
+int nls_memcpy_h2d(nls_ctx* ctx, void* dst, const void* src, size_t bytes);
+int nls_memcpy_d2h(nls_ctx* ctx, void* dst, const void* src, size_t bytes);
+int nls_synchronize(nls_ctx* ctx);
+/* Device description: name (<=255 chars), CU count, HBM bytes. */
+int nls_device_info(nls_ctx* ctx, char* name, int name_len, int* compute_units, size_t* hbm_bytes);
+
+/* ---- K1: feature map --------------------------------------------------------------------------
+ * phi[i, j<D] = exp(-i * t_ij) / sqrt(D),  t = ((X - shift) / scale) @ B;  phi[i, D] = 1.
+ * X: n x d.  shift, scale: d.  B: d x D (the separator matrix with Z already folded in,
+ * _feature_maps.py:150).  phi: n x (D+1) complex128, host or device pointer. */
+int nls_featuremap(nls_ctx* ctx, const double* X, int64_t n, int d, const double* shift,
+                   const double* scale, const double* B, int D, double* phi);
+
+/* ---- K2: weighted Hermitian normal equations (test / bench hook) ------------------------------
+ * s is normalised by its (global) sum inside, as _neo_ls_svm.py:110.  A: (D+1) x (D+1) complex128
+ * row-major, full Hermitian; b: (D+1) complex128.  With a collective hook the result is the
+ * all-reduced block on every rank. */
+int nls_gram_only(nls_ctx* ctx, const double* X, const double* y, const double* s, int64_t n, int d,
+                  const double* shift, const double* scale, const double* B, int D, double* A,
+                  double* b);
+
+/* ---- primal fit ------------------------------------------------------------------------------- */
+typedef struct nls_primal_fit_args {
+  /* inputs */
+  const double* X;      /* n x d (local rows)                                  host | device */
+  const double* y;      /* n     targets: float for regression, +-1 for classification       */
+  const double* s;      /* n     sample weights, un-normalised (>= 0)                        */
+  const double* shift;  /* d                                                   host          */
+  const double* scale;  /* d     (non-zero)                                    host          */
+  const double* B;      /* d x D folded projection                             host          */
+  const double* gammas; /* G     regularisation grid (reference: logspace(1e-6, 20, 1024))   */
+  int64_t n;
+  int32_t d, D, G;
+  int32_t is_classifier;  /* 0 regressor, 1 classifier (residual clipping + hinge selection)  */
+  int32_t gamma_index_in; /* >= 0 forces the selected grid index, -1 = argmin as the reference */
+  /* outputs (host; any may be NULL) */
+  double* beta;          /* 2 (D+1)   fitted weights, complex128                              */
+  double* L;             /* 2 (D+1)^2 cho_factor(gamma* C + A) as scipy returns it: upper     */
+                         /*           triangular factor U (A = U^H U), row-major, lower=False */
+  double* lam;           /* D+1       eigenvalues of A / c (ascending)                        */
+  double* loo_errors;    /* G         s @ |e_loo(gamma)|                  (loo_errors_gammas_) */
+  double* objective;     /* G         the vector whose argmin selects gamma                   */
+  double* loo_residuals; /* n         column of the selected gamma                            */
+  double* loo_leverage;  /* n                                                                 */
+  double* loo_std;       /* n                                                                 */
+  double* residuals;     /* n         Re(phi beta) - y after the Cholesky re-solve            */
+  double* loo_score;     /* 1         weighted accuracy / R^2 of the LOO predictions          */
+  int32_t* gamma_index;  /* 1         selected grid index                                     */
+  double* timings;       /* NLS_NUM_TIMINGS seconds per stage, see NLS_T_* (HIP events)       */
+} nls_primal_fit_args;
+
+/* indices into timings[] */
+#define NLS_T_TOTAL 0
+#define NLS_T_UPLOAD 1
+#define NLS_T_FEATUREMAP 2   /* all K1 launches                                  */
+#define NLS_T_GRAM 3         /* K2 launches incl. slab reduction                 */
+#define NLS_T_ALLREDUCE 4
+#define NLS_T_EVD 5          /* rocsolver_zheevd + assembly                      */
+#define NLS_T_ROTATE 6       /* K4: P = phi Q with fused |P|^2, Re(P v) epilogue  */
+#define NLS_T_SWEEP 7        /* K5: the two gamma-sweep GEMMs                     */
+#define NLS_T_LOO 8          /* LOO residual epilogue + weighted reductions       */
+#define NLS_T_CHOLESKY 9     /* zpotrf + zpotrs                                   */
+#define NLS_T_RESIDUALS 10   /* Re(phi beta) - y                                  */
+#define NLS_T_DOWNLOAD 11
+#define NLS_T_ROTATE_LAUNCHES 12 /* number of K4 launches (for the per-launch roofline)       */
+#define NLS_T_GRAM_LAUNCHES 13
+#define NLS_T_SWEEP_LAUNCHES 14
+#define NLS_T_FEATUREMAP_LAUNCHES 15
+#define NLS_T_ROTATE_FLOPS 16    /* algorithmic flops of all K4 launches: 8 n (D+1)^2          */
+#define NLS_T_GRAM_FLOPS 17      /* 4 n (D+1)^2                                               */
+#define NLS_T_SWEEP_FLOPS 18     /* 4 n (D+1) G                                               */
+#define NLS_T_FEATUREMAP_FLOPS 19 /* 2 n d D per pass                                         */
+#define NLS_T_ROW_CHUNK 20       /* rows per chunk used                                       */
+
+int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* args);
+
+/* ---- primal inference -------------------------------------------------------------------------
+ * yhat[i] = Re(phi(x_i) . beta); sigma[i] = sqrt(Re phi_i (U^H U)^-1 phi_i^H).  Either output may be
+ * NULL; L (format as nls_primal_fit's output) is only read when sigma != NULL. */
+int nls_primal_predict(nls_ctx* ctx, const double* X, int64_t m, int d, const double* shift,
+                       const double* scale, const double* B, int D, const double* beta,
+                       const double* L, double* yhat, double* sigma);
+
+/* ---- dual fit --------------------------------------------------------------------------------- */
+typedef struct nls_dual_fit_args {
+  const double* Xt;     /* n x r  affine-transformed training rows (X_)        host | device */
+  const double* y;      /* n */
+  const double* s;      /* n      strictly positive weights (zero-weight rows dropped by caller,
+                                  _neo_ls_svm.py:388-389) */
+  const double* gammas; /* G      (reference: logspace(1e-6, 20, 128)) */
+  int64_t n;
+  int32_t r, G;
+  int32_t is_classifier;
+  int32_t gamma_index_in;
+  double* alpha;         /* n */
+  double* L;             /* n x n  cho_factor(gamma* diag(sn^-2) + K), upper, row-major */
+  double* lam;           /* n */
+  double* loo_errors;    /* G */
+  double* objective;     /* G */
+  double* loo_residuals; /* n */
+  double* loo_std;       /* n */
+  double* residuals;     /* n */
+  double* loo_score;     /* 1 */
+  int32_t* gamma_index;  /* 1 */
+  double* timings;       /* NLS_NUM_TIMINGS */
+} nls_dual_fit_args;
+
+int nls_dual_fit(nls_ctx* ctx, const nls_dual_fit_args* args);
+
+/* yhat = k(Xq, Xt) alpha + sum(alpha); sigma = sqrt(1 - sum K o cho_solve(L, K^T)^T). */
+int nls_dual_predict(nls_ctx* ctx, const double* Xq, int64_t m, const double* Xt, int64_t n, int r,
+                     const double* alpha, const double* L, double* yhat, double* sigma);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEOLSSVM_HIP_H */

@@ -1,0 +1,33 @@
+"""MI355X-native implementation of the neo-ls-svm fit/predict hot path.
+
+Host code is Python + NumPy marshalling over a ctypes C ABI (``include/neolssvm_hip.h``) into
+hand-written HIP kernels for gfx950 plus rocSOLVER for the dense EVD / Cholesky.  No CPU fallback.
+"""
+
+from ._lib import Context, DeviceArray, NlsError, default_context, load_library  # noqa: F401
+from .hotpath import (  # noqa: F401
+    dual_fit,
+    dual_predict,
+    featuremap,
+    gamma_grid,
+    gram,
+    orf_frequencies,
+    primal_fit,
+    primal_predict,
+)
+
+__all__ = [
+    "Context",
+    "DeviceArray",
+    "NlsError",
+    "default_context",
+    "load_library",
+    "featuremap",
+    "gram",
+    "primal_fit",
+    "primal_predict",
+    "dual_fit",
+    "dual_predict",
+    "gamma_grid",
+    "orf_frequencies",
+]

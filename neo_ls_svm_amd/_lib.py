@@ -1,0 +1,305 @@
+"""ctypes binding of ``libneolssvm_hip.so`` (C ABI: ``include/neolssvm_hip.h``).
+
+There is no CPU fallback: importing this module without the built library, or creating a context
+without an MI355X, raises.  Build with ``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C neo_ls_svm_amd/csrc``.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = Path(os.environ.get("NEOLSSVM_HIP_LIB", _HERE / "libneolssvm_hip.so"))
+
+NLS_OK, NLS_ERR_ARG, NLS_ERR_HIP, NLS_ERR_LINALG, NLS_ERR_COMM = 0, 1, 2, 3, 4
+NUM_TIMINGS = 24
+TIMING_NAMES = {
+    "total": 0,
+    "upload": 1,
+    "featuremap": 2,
+    "gram": 3,
+    "allreduce": 4,
+    "evd": 5,
+    "rotate": 6,
+    "sweep": 7,
+    "loo": 8,
+    "cholesky": 9,
+    "residuals": 10,
+    "download": 11,
+    "rotate_launches": 12,
+    "gram_launches": 13,
+    "sweep_launches": 14,
+    "featuremap_launches": 15,
+    "rotate_flops": 16,
+    "gram_flops": 17,
+    "sweep_flops": 18,
+    "featuremap_flops": 19,
+    "row_chunk": 20,
+}
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_void_p)
+
+_dp = C.POINTER(C.c_double)
+
+
+class PrimalFitArgs(C.Structure):
+    """Mirror of ``nls_primal_fit_args`` (field order is the ABI)."""
+
+    _fields_ = [
+        ("X", C.c_void_p),
+        ("y", C.c_void_p),
+        ("s", C.c_void_p),
+        ("shift", C.c_void_p),
+        ("scale", C.c_void_p),
+        ("B", C.c_void_p),
+        ("gammas", C.c_void_p),
+        ("n", C.c_int64),
+        ("d", C.c_int32),
+        ("D", C.c_int32),
+        ("G", C.c_int32),
+        ("is_classifier", C.c_int32),
+        ("gamma_index_in", C.c_int32),
+        ("beta", C.c_void_p),
+        ("L", C.c_void_p),
+        ("lam", C.c_void_p),
+        ("loo_errors", C.c_void_p),
+        ("objective", C.c_void_p),
+        ("loo_residuals", C.c_void_p),
+        ("loo_leverage", C.c_void_p),
+        ("loo_std", C.c_void_p),
+        ("residuals", C.c_void_p),
+        ("loo_score", C.c_void_p),
+        ("gamma_index", C.c_void_p),
+        ("timings", C.c_void_p),
+    ]
+
+
+class DualFitArgs(C.Structure):
+    """Mirror of ``nls_dual_fit_args``."""
+
+    _fields_ = [
+        ("Xt", C.c_void_p),
+        ("y", C.c_void_p),
+        ("s", C.c_void_p),
+        ("gammas", C.c_void_p),
+        ("n", C.c_int64),
+        ("r", C.c_int32),
+        ("G", C.c_int32),
+        ("is_classifier", C.c_int32),
+        ("gamma_index_in", C.c_int32),
+        ("alpha", C.c_void_p),
+        ("L", C.c_void_p),
+        ("lam", C.c_void_p),
+        ("loo_errors", C.c_void_p),
+        ("objective", C.c_void_p),
+        ("loo_residuals", C.c_void_p),
+        ("loo_std", C.c_void_p),
+        ("residuals", C.c_void_p),
+        ("loo_score", C.c_void_p),
+        ("gamma_index", C.c_void_p),
+        ("timings", C.c_void_p),
+    ]
+
+
+# name -> (restype, argtypes); must list every symbol include/neolssvm_hip.h declares.
+SIGNATURES = {
+    "nls_abi_version": (C.c_int, []),
+    "nls_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "nls_ctx_destroy": (None, [C.c_void_p]),
+    "nls_last_error": (C.c_char_p, [C.c_void_p]),
+    "nls_set_allreduce": (C.c_int, [C.c_void_p, ALLREDUCE_FN, C.c_void_p, C.c_int, C.c_int]),
+    "nls_set_workspace_limit": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "nls_device_malloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "nls_device_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "nls_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "nls_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "nls_synchronize": (C.c_int, [C.c_void_p]),
+    "nls_device_info": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_size_t)]),
+    "nls_featuremap": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p],
+    ),
+    "nls_gram_only": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        + [C.c_void_p, C.c_void_p],
+    ),
+    "nls_primal_fit": (C.c_int, [C.c_void_p, C.POINTER(PrimalFitArgs)]),
+    "nls_primal_predict": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        + [C.c_void_p, C.c_void_p],
+    ),
+    "nls_dual_fit": (C.c_int, [C.c_void_p, C.POINTER(DualFitArgs)]),
+    "nls_dual_predict": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
+    ),
+}
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """Load the HIP library once; raise loudly when it is missing (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise ImportError(
+            f"{LIB_PATH} not found: the MI355X HIP library is not built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C neo_ls_svm_amd/csrc`). "
+            "neo_ls_svm_amd has no CPU fallback."
+        )
+    lib = C.CDLL(str(LIB_PATH), mode=C.RTLD_GLOBAL)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the export is missing
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+class NlsError(RuntimeError):
+    pass
+
+
+def raise_for(code: int, message: str):
+    """Map C error codes to the exceptions the reference raises."""
+    if code == NLS_OK:
+        return
+    if code == NLS_ERR_ARG:
+        raise ValueError(message)
+    if code == NLS_ERR_LINALG:
+        raise np.linalg.LinAlgError(message)
+    raise NlsError(message)
+
+
+class DeviceArray:
+    """A float64 array resident in HBM, owned by a Context (plain pointer + shape, no torch)."""
+
+    def __init__(self, ctx: "Context", shape):
+        self.ctx = ctx
+        self.shape = tuple(int(x) for x in np.atleast_1d(shape))
+        self.nbytes = int(np.prod(self.shape)) * 8
+        p = C.c_void_p()
+        ctx._check(ctx.lib.nls_device_malloc(ctx.handle, max(self.nbytes, 8), C.byref(p)))
+        self.ptr = p.value
+
+    # Lets torch / cupy wrap the buffer without a copy (used for the RCCL all-reduce of A||b).
+    @property
+    def __cuda_array_interface__(self):
+        return {"shape": self.shape, "typestr": "<f8", "data": (self.ptr, False), "version": 2, "strides": None}
+
+    def copy_from_host(self, a: np.ndarray) -> "DeviceArray":
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        assert a.nbytes == self.nbytes
+        self.ctx._check(self.ctx.lib.nls_memcpy_h2d(self.ctx.handle, self.ptr, a.ctypes.data, a.nbytes))
+        return self
+
+    def to_host(self) -> np.ndarray:
+        out = np.empty(self.shape, dtype=np.float64)
+        self.ctx._check(self.ctx.lib.nls_memcpy_d2h(self.ctx.handle, out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.ctx.lib.nls_device_free(self.ctx.handle, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _ptr(a):
+    """void* of a numpy array / DeviceArray / None."""
+    if a is None:
+        return None
+    if isinstance(a, DeviceArray):
+        return a.ptr
+    return a.ctypes.data
+
+
+class Context:
+    """One context per process and GPU: stream, rocBLAS/rocSOLVER handles, grow-only workspace."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.nls_ctx_create(int(device), C.byref(h))
+        if rc != NLS_OK:
+            msg = self.lib.nls_last_error(None)
+            raise NlsError(f"nls_ctx_create failed: {msg.decode() if msg else rc}")
+        self.handle = h
+        self.device = int(device)
+        self._hook = None  # keep the ctypes callback alive
+
+    def _check(self, rc: int):
+        if rc != NLS_OK:
+            msg = self.lib.nls_last_error(self.handle)
+            raise_for(rc, msg.decode() if msg else f"error {rc}")
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.nls_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        self._check(self.lib.nls_synchronize(self.handle))
+
+    def device_info(self) -> dict:
+        name = C.create_string_buffer(256)
+        cus, hbm = C.c_int(), C.c_size_t()
+        self._check(self.lib.nls_device_info(self.handle, name, 256, C.byref(cus), C.byref(hbm)))
+        return {"name": name.value.decode(), "compute_units": cus.value, "hbm_bytes": hbm.value}
+
+    def to_device(self, a: np.ndarray) -> DeviceArray:
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        return DeviceArray(self, a.shape).copy_from_host(a)
+
+    def empty(self, shape) -> DeviceArray:
+        return DeviceArray(self, shape)
+
+    def set_allreduce(self, fn, rank: int, world: int):
+        """fn(device_ptr: int, count: int) -> None sums `count` doubles at `device_ptr` over all ranks."""
+        if fn is None or world <= 1:
+            self._hook = None
+            self._check(self.lib.nls_set_allreduce(self.handle, ALLREDUCE_FN(0), None, 0, 1))
+            return
+
+        def _thunk(buf, count, _user):
+            try:
+                fn(int(buf), int(count))
+                return 0
+            except Exception as exc:  # surfaced as NLS_ERR_COMM
+                import traceback
+
+                traceback.print_exc()
+                self._hook_error = exc
+                return 1
+
+        self._hook = ALLREDUCE_FN(_thunk)
+        self._check(self.lib.nls_set_allreduce(self.handle, self._hook, None, int(rank), int(world)))
+
+
+_default_ctx: dict[int, Context] = {}
+
+
+def default_context(device: int = 0) -> Context:
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]

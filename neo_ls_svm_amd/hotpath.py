@@ -1,0 +1,291 @@
+"""Host-side mirror of the reference's solver seam, calling the HIP library through the C ABI.
+
+Functions here have the argument meaning of the reference's private solver methods
+(``NeoLSSVM._optimize_beta_gamma`` ``_neo_ls_svm.py:77-189``, ``_optimize_alpha_gamma`` ``:191-325``) and
+of ``RandomFourierFeatures.transform`` (``_feature_maps.py:153-203``); results come back as a dict
+keyed like the fitted attributes the reference sets as side effects (``:146-187``).
+
+All arithmetic happens on the GPU.  NumPy is used for argument marshalling only.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import Context, DeviceArray, DualFitArgs, PrimalFitArgs, default_context
+
+__all__ = [
+    "gamma_grid",
+    "orf_frequencies",
+    "featuremap",
+    "gram",
+    "primal_fit",
+    "primal_predict",
+    "dual_fit",
+    "dual_predict",
+    "timings_dict",
+]
+
+
+def gamma_grid(num: int) -> np.ndarray:
+    """``np.logspace(log10(1e-6), log10(20), num)``: ``_neo_ls_svm.py:146`` (1024) / ``:270`` (128)."""
+    return np.logspace(np.log10(1e-6), np.log10(20), num, dtype=np.float64)
+
+
+def orf_frequencies(d: int, D: int, random_state=42) -> np.ndarray:
+    """Orthogonal random frequencies Z (d x D), host side (P0): ``_feature_maps.py:209-223``.
+
+    O(d^2 D) on a d x D matrix, negligible next to the fit; it stays on the host so that the legacy
+    ``RandomState`` stream (and therefore Z) is bit-identical to the reference's.
+    """
+    gen = random_state if isinstance(random_state, np.random.RandomState) else np.random.RandomState(random_state)
+    Z = gen.randn(d, D)
+    for j in range(0, D, d):
+        block = Z[:, j : j + d]
+        q, _ = np.linalg.qr(block)
+        Z[:, j : j + block.shape[1]] = q[:, : block.shape[1]]
+    Z *= np.sqrt(gen.chisquare(d, size=(1, D)))
+    return Z
+
+
+def _f64(a, name, shape=None):
+    if isinstance(a, DeviceArray):
+        if shape is not None and tuple(a.shape) != tuple(shape):
+            raise ValueError(f"{name} has shape {a.shape}, expected {shape}")
+        return a
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and a.shape != tuple(shape):
+        raise ValueError(f"{name} has shape {a.shape}, expected {shape}")
+    return a
+
+
+def _map_params(shift, scale, B, d):
+    B = _f64(B, "B")
+    if B.ndim != 2 or B.shape[0] != d:
+        raise ValueError(f"B must be (d={d}, D), got {B.shape}")
+    shift = _f64(np.ravel(np.broadcast_to(np.asarray(shift, dtype=np.float64).ravel(), (d,))), "shift", (d,))
+    scale = _f64(np.ravel(np.broadcast_to(np.asarray(scale, dtype=np.float64).ravel(), (d,))), "scale", (d,))
+    return shift, scale, B
+
+
+def timings_dict(t: np.ndarray) -> dict:
+    return {k: float(t[i]) for k, i in _lib.TIMING_NAMES.items()}
+
+
+def featuremap(X, shift, scale, B, ctx: Context | None = None, out: DeviceArray | None = None):
+    """phi(X) = [exp(-i ((X - shift)/scale) B)/sqrt(D), 1] as complex128 (n x (D+1)), or into ``out`` (device)."""
+    ctx = ctx or default_context()
+    X = _f64(X, "X")
+    n, d = X.shape
+    shift, scale, B = _map_params(shift, scale, B, d)
+    D = B.shape[1]
+    if out is None:
+        phi = np.empty((n, D + 1), dtype=np.complex128)
+        target = phi.ctypes.data
+    else:
+        phi, target = out, out.ptr
+    ctx._check(
+        ctx.lib.nls_featuremap(ctx.handle, _lib._ptr(X), n, d, shift.ctypes.data, scale.ctypes.data, B.ctypes.data, D, target)
+    )
+    return phi
+
+
+def gram(X, y, s, shift, scale, B, ctx: Context | None = None):
+    """(A, b) of ``_neo_ls_svm.py:110-114,127`` with phi generated on the fly (never materialised)."""
+    ctx = ctx or default_context()
+    X = _f64(X, "X")
+    n, d = X.shape
+    y, s = _f64(y, "y", (n,)), _f64(s, "s", (n,))
+    shift, scale, B = _map_params(shift, scale, B, d)
+    D1 = B.shape[1] + 1
+    A = np.empty((D1, D1), dtype=np.complex128)
+    b = np.empty(D1, dtype=np.complex128)
+    ctx._check(
+        ctx.lib.nls_gram_only(
+            ctx.handle, _lib._ptr(X), _lib._ptr(y), _lib._ptr(s), n, d, shift.ctypes.data, scale.ctypes.data,
+            B.ctypes.data, B.shape[1], A.ctypes.data, b.ctypes.data,
+        )
+    )  # fmt: skip
+    return A, b
+
+
+def primal_fit(
+    X,
+    y,
+    s,
+    shift,
+    scale,
+    B,
+    is_classifier: bool,
+    gammas=None,
+    gamma_index: int | None = None,
+    ctx: Context | None = None,
+    want_L: bool = True,
+    want_rows: bool = True,
+) -> dict:
+    """Primal LS-SVM fit with the full gamma sweep (P1-P9).
+
+    X (n x d), y (n), s (n) may be NumPy arrays or ``DeviceArray`` s already resident in HBM.  Returns
+    a dict with the reference's attribute names (ASCII): beta, gamma, gammas, opt, loo_errors_gammas,
+    loo_residuals, loo_yhat (host input y only), loo_leverage, loo_error, loo_score, L (scipy ``cho_factor``
+    format, lower=False), residuals, loo_std, lam, timings.
+    """
+    ctx = ctx or default_context()
+    X = _f64(X, "X")
+    if len(X.shape) != 2:
+        raise ValueError("X must be 2-D")
+    n, d = X.shape
+    y, s = _f64(y, "y", (n,)), _f64(s, "s", (n,))
+    shift, scale, B = _map_params(shift, scale, B, d)
+    D = B.shape[1]
+    D1 = D + 1
+    gammas = gamma_grid(1024) if gammas is None else np.ascontiguousarray(gammas, dtype=np.float64)
+    G = gammas.size
+    out = {
+        "beta": np.empty(D1, dtype=np.complex128),
+        "lam": np.empty(D1),
+        "loo_errors_gammas": np.empty(G),
+        "objective": np.empty(G),
+    }
+    if want_L:
+        out["L"] = np.empty((D1, D1), dtype=np.complex128)
+    if want_rows:
+        for k in ("loo_residuals", "loo_leverage", "loo_std", "residuals"):
+            out[k] = np.empty(n)
+    score = C.c_double()
+    opt = C.c_int32()
+    tm = np.zeros(_lib.NUM_TIMINGS)
+    a = PrimalFitArgs()
+    a.X, a.y, a.s = _lib._ptr(X), _lib._ptr(y), _lib._ptr(s)
+    a.shift, a.scale, a.B, a.gammas = shift.ctypes.data, scale.ctypes.data, B.ctypes.data, gammas.ctypes.data
+    a.n, a.d, a.D, a.G = n, d, D, G
+    a.is_classifier = 1 if is_classifier else 0
+    a.gamma_index_in = -1 if gamma_index is None else int(gamma_index)
+    a.beta, a.lam = out["beta"].ctypes.data, out["lam"].ctypes.data
+    a.L = out["L"].ctypes.data if want_L else None
+    a.loo_errors, a.objective = out["loo_errors_gammas"].ctypes.data, out["objective"].ctypes.data
+    if want_rows:
+        a.loo_residuals, a.loo_leverage = out["loo_residuals"].ctypes.data, out["loo_leverage"].ctypes.data
+        a.loo_std, a.residuals = out["loo_std"].ctypes.data, out["residuals"].ctypes.data
+    a.loo_score = C.addressof(score)
+    a.gamma_index = C.addressof(opt)
+    a.timings = tm.ctypes.data
+    ctx._check(ctx.lib.nls_primal_fit(ctx.handle, C.byref(a)))
+    out["gammas"] = gammas
+    out["opt"] = int(opt.value)
+    out["gamma"] = float(gammas[opt.value])
+    out["loo_error"] = float(out["loo_errors_gammas"][opt.value])
+    out["loo_score"] = float(score.value)
+    out["L_lower"] = False
+    if want_rows and not isinstance(y, DeviceArray):
+        out["loo_yhat"] = y + out["loo_residuals"]
+    out["timings"] = timings_dict(tm)
+    return out
+
+
+def primal_predict(X, shift, scale, B, beta=None, L=None, ctx: Context | None = None):
+    """(yhat, sigma): ``decision_function`` ``_neo_ls_svm.py:661-665`` and ``predict_std`` ``:464-469,477``.
+
+    Pass ``beta`` for yhat and/or ``L`` (upper factor as returned by ``primal_fit``) for sigma.
+    """
+    ctx = ctx or default_context()
+    X = _f64(X, "X")
+    m, d = X.shape
+    shift, scale, B = _map_params(shift, scale, B, d)
+    D = B.shape[1]
+    yhat = sigma = None
+    if beta is not None:
+        beta = np.ascontiguousarray(beta, dtype=np.complex128)
+        if beta.shape != (D + 1,):
+            raise ValueError(f"beta must have shape ({D + 1},)")
+        yhat = np.empty(m)
+    if L is not None:
+        L = np.ascontiguousarray(L, dtype=np.complex128)
+        if L.shape != (D + 1, D + 1):
+            raise ValueError(f"L must have shape ({D + 1}, {D + 1})")
+        sigma = np.empty(m)
+    ctx._check(
+        ctx.lib.nls_primal_predict(
+            ctx.handle, _lib._ptr(X), m, d, shift.ctypes.data, scale.ctypes.data, B.ctypes.data, D,
+            _lib._ptr(beta), _lib._ptr(L), _lib._ptr(yhat), _lib._ptr(sigma),
+        )
+    )  # fmt: skip
+    return yhat, sigma
+
+
+def dual_fit(
+    Xt, y, s, is_classifier: bool, gammas=None, gamma_index: int | None = None, ctx: Context | None = None,
+    want_L: bool = True,
+) -> dict:  # fmt: skip
+    """Dual LS-SVM fit (D1-D5) on affine-transformed rows ``Xt``; weights must be strictly positive."""
+    ctx = ctx or default_context()
+    Xt = _f64(Xt, "Xt")
+    n, r = Xt.shape
+    y, s = _f64(y, "y", (n,)), _f64(s, "s", (n,))
+    gammas = gamma_grid(128) if gammas is None else np.ascontiguousarray(gammas, dtype=np.float64)
+    G = gammas.size
+    out = {
+        "alpha": np.empty(n),
+        "lam": np.empty(n),
+        "loo_errors_gammas": np.empty(G),
+        "objective": np.empty(G),
+        "loo_residuals": np.empty(n),
+        "loo_std": np.empty(n),
+        "residuals": np.empty(n),
+    }
+    if want_L:
+        out["L"] = np.empty((n, n))
+    score, opt = C.c_double(), C.c_int32()
+    tm = np.zeros(_lib.NUM_TIMINGS)
+    a = DualFitArgs()
+    a.Xt, a.y, a.s, a.gammas = _lib._ptr(Xt), _lib._ptr(y), _lib._ptr(s), gammas.ctypes.data
+    a.n, a.r, a.G = n, r, G
+    a.is_classifier = 1 if is_classifier else 0
+    a.gamma_index_in = -1 if gamma_index is None else int(gamma_index)
+    a.alpha, a.lam = out["alpha"].ctypes.data, out["lam"].ctypes.data
+    a.L = out["L"].ctypes.data if want_L else None
+    a.loo_errors, a.objective = out["loo_errors_gammas"].ctypes.data, out["objective"].ctypes.data
+    a.loo_residuals, a.loo_std, a.residuals = (
+        out["loo_residuals"].ctypes.data,
+        out["loo_std"].ctypes.data,
+        out["residuals"].ctypes.data,
+    )
+    a.loo_score, a.gamma_index, a.timings = C.addressof(score), C.addressof(opt), tm.ctypes.data
+    ctx._check(ctx.lib.nls_dual_fit(ctx.handle, C.byref(a)))
+    out["gammas"] = gammas
+    out["opt"] = int(opt.value)
+    out["gamma"] = float(gammas[opt.value])
+    out["loo_error"] = float(out["loo_errors_gammas"][opt.value])
+    out["loo_score"] = float(score.value)
+    out["L_lower"] = False
+    if not isinstance(y, DeviceArray):
+        out["loo_yhat"] = y + out["loo_residuals"]
+    out["timings"] = timings_dict(tm)
+    return out
+
+
+def dual_predict(Xq, Xt, alpha=None, L=None, ctx: Context | None = None):
+    """(yhat, sigma) of the dual model: ``_neo_ls_svm.py:666-671`` and ``:470-477``."""
+    ctx = ctx or default_context()
+    Xq, Xt = _f64(Xq, "Xq"), _f64(Xt, "Xt")
+    m, r = Xq.shape
+    n = Xt.shape[0]
+    if Xt.shape[1] != r:
+        raise ValueError("Xq and Xt must have the same number of columns")
+    yhat = sigma = None
+    if alpha is not None:
+        alpha = _f64(alpha, "alpha", (n,))
+        yhat = np.empty(m)
+    if L is not None:
+        L = _f64(L, "L", (n, n))
+        sigma = np.empty(m)
+    ctx._check(
+        ctx.lib.nls_dual_predict(
+            ctx.handle, _lib._ptr(Xq), m, _lib._ptr(Xt), n, r, _lib._ptr(alpha), _lib._ptr(L), _lib._ptr(yhat),
+            _lib._ptr(sigma),
+        )
+    )  # fmt: skip
+    return yhat, sigma

@@ -256,7 +256,7 @@ static int launch_featuremap_planes(nls_ctx* ctx, const MapParams& mp, const dou
 // Rows per chunk so that the per-chunk buffers (feature planes + rotation outputs) stay within budget.
 static long pick_row_chunk(nls_ctx* ctx, long n, const MapParams& mp, size_t fixed_bytes) {
   const size_t limit = ctx->ws_limit ? ctx->ws_limit : (size_t)(0.6 * (double)ctx->hbm_bytes);
-  size_t avail = limit > fixed_bytes ? limit - fixed_bytes : (size_t)1 << 30;
+  size_t avail = limit > 2 * fixed_bytes ? limit - fixed_bytes : limit / 2;
   avail = std::min(avail, (size_t)48 << 30);  // larger chunks buy nothing once launches are >~100 ms
   const size_t per_row = 16ull * ((size_t)mp.Kp + (size_t)mp.Np);
   long rc_max = (long)(avail / per_row) / BM * BM;

@@ -1,13 +1,339 @@
-// Dual path (D1-D6): placeholder translation unit, replaced by the real kernels in the next milestone.
-#include "../../include/neolssvm_hip.h"
+// Dual path of the hot path: n x n RBF kernel, real symmetric EVD, reduced LOO
+// gamma sweep (2 n^3 + O(n^2 G) instead of the reference's n x G x n tensor), Cholesky re-solve, sigma.
+// Reference: NeoLSSVM._optimize_alpha_gamma, _neo_ls_svm.py:191-325; inference :470-477, :666-671.
+#include "nls_dual_kernels.h"
+#include "nls_host.h"
+#include "nls_kernels.h"
 
-extern "C" int nls_dual_fit(nls_ctx* ctx, const nls_dual_fit_args* args) {
-  (void)ctx;
-  (void)args;
-  return NLS_ERR_ARG;
+using namespace nls;
+
+namespace {
+
+constexpr size_t SMEM_REAL_D = 2 * TILE_DOUBLES * sizeof(double);
+
+template <int EPI>
+int launch_gemm(nls_ctx* ctx, const GemmParams& p, long M, long N) {
+  dim3 grid((unsigned)(N / BN), (unsigned)(M / BM));
+  hipLaunchKernelGGL(k_gemm<EPI>, grid, dim3(Cfg4::NTHREADS), SMEM_REAL_D, ctx->stream, p);
+  HIPCHK(ctx, hipGetLastError());
+  return NLS_OK;
 }
-extern "C" int nls_dual_predict(nls_ctx* ctx, const double* Xq, int64_t m, const double* Xt, int64_t n, int r,
-                                const double* alpha, const double* L, double* yhat, double* sigma) {
-  (void)ctx; (void)Xq; (void)m; (void)Xt; (void)n; (void)r; (void)alpha; (void)L; (void)yhat; (void)sigma;
-  return NLS_ERR_ARG;
+
+int gemm_store(nls_ctx* ctx, const double* A, long lda, const double* B, long ldb, double* C, long ldc, long M, long N, long K) {
+  GemmParams p{};
+  p.A = A;
+  p.B = B;
+  p.C = C;
+  p.lda = lda;
+  p.ldb = ldb;
+  p.ldc = ldc;
+  p.K = (int)K;
+  return launch_gemm<EPI_STORE>(ctx, p, M, N);
+}
+
+dim3 grid2(long cols, long rows) { return dim3((unsigned)((cols + 255) / 256), (unsigned)rows); }
+
+// K(Xa, Xb) = exp(-||xa - xb||^2 / 2) + add on padded operands; Xb given transposed ([r_pad][nb_pad]).
+int rbf_block(nls_ctx* ctx, const double* Xa_pad, const double* XbT_pad, const double* aa, const double* bb, long ma, long nb,
+              long ma_pad, long nb_pad, long r_pad, int same, double add, double* out) {
+  GemmParams p{};
+  p.A = Xa_pad;
+  p.B = XbT_pad;
+  p.C = out;
+  p.lda = r_pad;
+  p.ldb = nb_pad;
+  p.ldc = nb_pad;
+  p.K = (int)r_pad;
+  p.xx = aa;
+  p.yy = bb;
+  p.m_valid = ma;
+  p.n_valid = nb;
+  p.same = same;
+  p.add = add;
+  return launch_gemm<EPI_RBF>(ctx, p, ma_pad, nb_pad);
+}
+
+}  // namespace
+
+extern "C" int nls_dual_fit(nls_ctx* ctx, const nls_dual_fit_args* a) {
+  if (!ctx) return NLS_ERR_ARG;
+  if (!a) return fail(ctx, NLS_ERR_ARG, "args is NULL");
+  if (!a->Xt || !a->y || !a->s || !a->gammas) return fail(ctx, NLS_ERR_ARG, "Xt, y, s and gammas must not be NULL");
+  if (a->n < 2 || a->r < 1 || a->G < 1) return fail(ctx, NLS_ERR_ARG, "need n >= 2, r >= 1, G >= 1");
+  if (a->gamma_index_in >= a->G) return fail(ctx, NLS_ERR_ARG, "gamma_index_in out of range");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const double t_start = wall();
+  double tm[NLS_NUM_TIMINGS];
+  std::memset(tm, 0, sizeof(tm));
+  ctx->spans.clear();
+  ctx->events_used = 0;
+
+  const long n = a->n, r = a->r;
+  const int G = a->G, is_clf = a->is_classifier ? 1 : 0;
+  const long n_pad = round_up(n, BM), r_pad = round_up(r, BK);
+  const int Gp = (int)round_up(G, BN);
+  const double *dX = nullptr, *dy = nullptr, *ds_in = nullptr;
+  {
+    SpanGuard g(ctx, NLS_T_UPLOAD);
+    NLSCHK(resident(ctx, "in.X", a->Xt, (size_t)n * r, &dX));
+    NLSCHK(resident(ctx, "in.y", a->y, (size_t)n, &dy));
+    NLSCHK(resident(ctx, "in.s", a->s, (size_t)n, &ds_in));
+  }
+  // Weights: s1 = s / sum(s); sn = s1 / median|s1| (_neo_ls_svm.py:252-253).  The median is an O(n) host
+  // selection on n doubles; everything else stays on the device.
+  std::vector<double> hs((size_t)n), hy((size_t)n);
+  HIPCHK(ctx, hipMemcpyAsync(hs.data(), ds_in, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(hy.data(), dy, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  double ssum = 0.0, sysum = 0.0;
+  for (long i = 0; i < n; ++i) {
+    if (!(hs[i] > 0.0) || !std::isfinite(hs[i]))
+      return fail(ctx, NLS_ERR_ARG, "dual path needs strictly positive finite weights (s[%ld] = %g); drop zero-weight rows first", i, hs[i]);
+    ssum += hs[i];
+  }
+  std::vector<double> s1((size_t)n), sn((size_t)n), tmp((size_t)n);
+  for (long i = 0; i < n; ++i) {
+    s1[i] = hs[i] / ssum;
+    tmp[i] = std::fabs(s1[i]);
+    sysum += s1[i] * hy[i];
+  }
+  std::nth_element(tmp.begin(), tmp.begin() + n / 2, tmp.end());
+  double med = tmp[n / 2];
+  if (n % 2 == 0) med = 0.5 * (med + *std::max_element(tmp.begin(), tmp.begin() + n / 2));
+  for (long i = 0; i < n; ++i) sn[i] = s1[i] / med;
+  const double ybar = sysum;  // weights s1 sum to one
+  double *d_s1 = nullptr, *d_sn = nullptr;
+  NLSCHK(ws_get_t(ctx, "dual.s1", (size_t)n_pad, &d_s1));
+  NLSCHK(ws_get_t(ctx, "dual.sn", (size_t)n_pad, &d_sn));
+  HIPCHK(ctx, hipMemcpyAsync(d_s1, s1.data(), sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(d_sn, sn.data(), sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+
+  const size_t NN = (size_t)n_pad * n_pad;
+  double *Xp = nullptr, *XpT = nullptr, *xx = nullptr, *F = nullptr, *F0 = nullptr, *Q = nullptr, *W = nullptr, *M = nullptr,
+         *WW = nullptr, *WQ = nullptr, *lam = nullptr, *evd_e = nullptr, *qy = nullptr, *dgam = nullptr, *R = nullptr;
+  rocblas_int* dinfo = nullptr;
+  NLSCHK(ws_get_t(ctx, "dual.Xp", (size_t)n_pad * r_pad, &Xp));
+  NLSCHK(ws_get_t(ctx, "dual.XpT", (size_t)r_pad * n_pad, &XpT));
+  NLSCHK(ws_get_t(ctx, "dual.xx", (size_t)n_pad, &xx));
+  NLSCHK(ws_get_t(ctx, "dual.F", NN, &F));
+  NLSCHK(ws_get_t(ctx, "dual.F0", NN, &F0));
+  NLSCHK(ws_get_t(ctx, "dual.Q", NN, &Q));
+  NLSCHK(ws_get_t(ctx, "dual.W", NN, &W));
+  NLSCHK(ws_get_t(ctx, "dual.M", NN, &M));
+  NLSCHK(ws_get_t(ctx, "dual.WW", NN, &WW));
+  NLSCHK(ws_get_t(ctx, "dual.WQ", NN, &WQ));
+  NLSCHK(ws_get_t(ctx, "dual.lam", (size_t)n_pad, &lam));
+  NLSCHK(ws_get_t(ctx, "dual.e", (size_t)n_pad, &evd_e));
+  NLSCHK(ws_get_t(ctx, "dual.qy", (size_t)n_pad, &qy));
+  NLSCHK(ws_get_t(ctx, "evd.info", 4, &dinfo));
+  NLSCHK(ws_get_t(ctx, "sweep.gammas", (size_t)G, &dgam));
+  NLSCHK(ws_get_t(ctx, "dual.R", (size_t)n_pad * Gp, &R));
+  HIPCHK(ctx, hipMemcpyAsync(dgam, a->gammas, sizeof(double) * G, hipMemcpyHostToDevice, ctx->stream));
+
+  // ---- D1: F = rbf(Xt, 1/2) + 1 -----------------------------------------------------------------
+  {
+    SpanGuard g(ctx, NLS_T_GRAM);
+    hipLaunchKernelGGL(k_copy_pad, grid2(r_pad, n_pad), dim3(256), 0, ctx->stream, dX, n, r, r, Xp, n_pad, r_pad);
+    hipLaunchKernelGGL(k_transpose_pad, grid2(n_pad, r_pad), dim3(256), 0, ctx->stream, dX, n, r, r, XpT, r_pad, n_pad);
+    hipLaunchKernelGGL(k_row_sqnorm, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, dX, n, r, r, xx);
+    HIPCHK(ctx, hipGetLastError());
+    NLSCHK(rbf_block(ctx, Xp, XpT, xx, xx, n, n, n_pad, n_pad, r_pad, 1, 1.0, F));
+    tm[NLS_T_GRAM_LAUNCHES] += 1;
+    tm[NLS_T_GRAM_FLOPS] += 2.0 * n * n * r;
+  }
+  // ---- D2: EVD of sn K sn ------------------------------------------------------------------------
+  {
+    SpanGuard g(ctx, NLS_T_EVD);
+    hipLaunchKernelGGL(k_dual_scale_sym, grid2(n, n), dim3(256), 0, ctx->stream, F, n_pad, d_sn, n, Q, n);
+    HIPCHK(ctx, hipGetLastError());
+    BLASCHK(ctx, rocsolver_dsyevd(ctx->blas, rocblas_evect_original, rocblas_fill_lower, (rocblas_int)n, Q, (rocblas_int)n, lam, evd_e, dinfo));
+    NLSCHK(check_info(ctx, dinfo, "rocsolver_dsyevd"));
+  }
+  // ---- D3: reduced sweep -------------------------------------------------------------------------
+  double *T = nullptr, *HD = nullptr, *AG = nullptr, *FA = nullptr;
+  NLSCHK(ws_get_t(ctx, "dual.T", (size_t)n_pad * Gp, &T));
+  NLSCHK(ws_get_t(ctx, "dual.HD", (size_t)n_pad * Gp, &HD));
+  NLSCHK(ws_get_t(ctx, "dual.AG", (size_t)n_pad * Gp, &AG));
+  NLSCHK(ws_get_t(ctx, "dual.FA", (size_t)n_pad * Gp, &FA));
+  {
+    SpanGuard g(ctx, NLS_T_ROTATE);
+    hipLaunchKernelGGL(k_dual_build_W, grid2(n_pad, n_pad), dim3(256), 0, ctx->stream, Q, n, d_sn, W, n_pad);
+    hipLaunchKernelGGL(k_dual_qty, dim3((unsigned)n), dim3(256), 0, ctx->stream, Q, n, d_sn, dy, qy);
+    hipLaunchKernelGGL(k_zero_diag_copy, grid2(n_pad, n_pad), dim3(256), 0, ctx->stream, F, n_pad, n_pad, n, F0);
+    HIPCHK(ctx, hipGetLastError());
+    NLSCHK(gemm_store(ctx, F0, n_pad, W, n_pad, M, n_pad, n_pad, n_pad, n_pad));
+    hipLaunchKernelGGL(k_dual_hadamards, grid2(n_pad, n_pad), dim3(256), 0, ctx->stream, W, M, qy, n, n_pad, M, WW, WQ);
+    HIPCHK(ctx, hipGetLastError());
+    tm[NLS_T_ROTATE_LAUNCHES] += 1;
+    tm[NLS_T_ROTATE_FLOPS] += 2.0 * n * n * n;
+  }
+  {
+    SpanGuard g(ctx, NLS_T_SWEEP);
+    const long tot = n_pad * (long)Gp;
+    hipLaunchKernelGGL(k_rgrid, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, lam, dgam, (int)n, G, (int)n_pad, Gp, R);
+    HIPCHK(ctx, hipGetLastError());
+    NLSCHK(gemm_store(ctx, M, n_pad, R, Gp, T, Gp, n_pad, Gp, n_pad));
+    NLSCHK(gemm_store(ctx, WW, n_pad, R, Gp, HD, Gp, n_pad, Gp, n_pad));
+    NLSCHK(gemm_store(ctx, WQ, n_pad, R, Gp, AG, Gp, n_pad, Gp, n_pad));
+    NLSCHK(gemm_store(ctx, F0, n_pad, AG, Gp, FA, Gp, n_pad, Gp, n_pad));
+    hipLaunchKernelGGL(k_dual_yloo, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, T, HD, AG, FA, tot);
+    HIPCHK(ctx, hipGetLastError());
+    tm[NLS_T_SWEEP_LAUNCHES] += 4;
+    tm[NLS_T_SWEEP_FLOPS] += 8.0 * n * n * G;
+  }
+  // ---- D4: selection -----------------------------------------------------------------------------
+  const long nblk = (n + 63) / 64;
+  double *part = nullptr, *errs = nullptr;
+  NLSCHK(ws_get_t(ctx, "loo.part", (size_t)nblk * 3 * Gp, &part));
+  NLSCHK(ws_get_t(ctx, "loo.errs", (size_t)3 * Gp, &errs));
+  {
+    SpanGuard g(ctx, NLS_T_LOO);
+    hipLaunchKernelGGL(k_dual_errors, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, T, dy, d_s1, n, G, Gp, is_clf, part);
+    hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)((3 * Gp + 255) / 256)), dim3(256), 0, ctx->stream, part, nblk, 3L * Gp, errs);
+    HIPCHK(ctx, hipGetLastError());
+  }
+  std::vector<double> herrs((size_t)3 * Gp), hobj((size_t)G);
+  HIPCHK(ctx, hipMemcpyAsync(herrs.data(), errs, sizeof(double) * 3 * Gp, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  for (int g = 0; g < G; ++g) hobj[g] = is_clf ? (herrs[Gp + g] + herrs[2 * Gp + g]) + herrs[g] : herrs[g];  // :296-302
+  int opt = a->gamma_index_in;
+  if (opt < 0) {
+    opt = 0;
+    for (int g = 0; g < G; ++g) {
+      if (std::isnan(hobj[g])) {
+        opt = g;
+        break;
+      }
+      if (hobj[g] < hobj[opt]) opt = g;
+    }
+  }
+  const double gamma_opt = a->gammas[opt];
+  double *loo_res = nullptr, *res = nullptr, *sig = nullptr, *cpart = nullptr, *csum = nullptr, *alpha = nullptr;
+  NLSCHK(ws_get_t(ctx, "out.loo_res", (size_t)n_pad, &loo_res));
+  NLSCHK(ws_get_t(ctx, "out.res", (size_t)n_pad, &res));
+  NLSCHK(ws_get_t(ctx, "out.loo_std", (size_t)n_pad, &sig));
+  NLSCHK(ws_get_t(ctx, "dual.alpha", (size_t)n_pad, &alpha));
+  const long cblk = (n + 255) / 256;
+  NLSCHK(ws_get_t(ctx, "loo.cpart", (size_t)cblk * 2, &cpart));
+  NLSCHK(ws_get_t(ctx, "loo.csum", 4, &csum));
+  {
+    SpanGuard g(ctx, NLS_T_LOO);
+    hipLaunchKernelGGL(k_dual_column, dim3((unsigned)cblk), dim3(256), 0, ctx->stream, T, dy, d_s1, n, Gp, opt, is_clf, ybar, loo_res,
+                       cpart);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(64), 0, ctx->stream, cpart, cblk, 2L, csum);
+    HIPCHK(ctx, hipGetLastError());
+  }
+  double hsum[2];
+  HIPCHK(ctx, hipMemcpyAsync(hsum, csum, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+
+  // ---- D5: Cholesky re-solve, residuals, sigma -----------------------------------------------------
+  double* M2 = Q;   // n x n, Q is dead
+  double* Kp = W;   // n x n, W is dead
+  double* Z = WW;   // n x n
+  {
+    SpanGuard g(ctx, NLS_T_CHOLESKY);
+    hipLaunchKernelGGL(k_dual_chol_inputs, grid2(n, n), dim3(256), 0, ctx->stream, F, n_pad, d_sn, n, gamma_opt, M2, Kp);
+    HIPCHK(ctx, hipGetLastError());
+    BLASCHK(ctx, rocsolver_dpotrf(ctx->blas, rocblas_fill_lower, (rocblas_int)n, M2, (rocblas_int)n, dinfo));
+    NLSCHK(check_info(ctx, dinfo, "rocsolver_dpotrf"));
+    HIPCHK(ctx, hipMemcpyAsync(alpha, dy, sizeof(double) * n, hipMemcpyDeviceToDevice, ctx->stream));
+    BLASCHK(ctx, rocsolver_dpotrs(ctx->blas, rocblas_fill_lower, (rocblas_int)n, 1, M2, (rocblas_int)n, alpha, (rocblas_int)n));
+    HIPCHK(ctx, hipMemcpyAsync(Z, Kp, sizeof(double) * n * n, hipMemcpyDeviceToDevice, ctx->stream));
+    BLASCHK(ctx, rocsolver_dpotrs(ctx->blas, rocblas_fill_lower, (rocblas_int)n, (rocblas_int)n, M2, (rocblas_int)n, Z, (rocblas_int)n));
+  }
+  {
+    SpanGuard g(ctx, NLS_T_RESIDUALS);
+    hipLaunchKernelGGL(k_dual_gemv, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, F, n_pad, n, n, alpha, 0.0, dy, is_clf, res);
+    // sigma2_i = 1 - sum_j Kp[i][j] Z[j][i]; the column-major solve output read row-major is Z^T.
+    hipLaunchKernelGGL(k_dual_sigma, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, Kp, Z, n, n, n, sig);
+    HIPCHK(ctx, hipGetLastError());
+  }
+  {
+    SpanGuard g(ctx, NLS_T_DOWNLOAD);
+    auto d2h = [&](void* dst, const void* src, size_t bytes) -> int {
+      if (dst) HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+      return NLS_OK;
+    };
+    NLSCHK(d2h(a->alpha, alpha, sizeof(double) * n));
+    NLSCHK(d2h(a->lam, lam, sizeof(double) * n));
+    NLSCHK(d2h(a->loo_residuals, loo_res, sizeof(double) * n));
+    NLSCHK(d2h(a->loo_std, sig, sizeof(double) * n));
+    NLSCHK(d2h(a->residuals, res, sizeof(double) * n));
+    // Column-major lower Cholesky factor == row-major upper factor U (M2 = U^T U): scipy's lower=False layout.
+    NLSCHK(d2h(a->L, M2, sizeof(double) * n * n));
+  }
+  NLSCHK(spans_collect(ctx, tm));
+  if (a->loo_errors) std::memcpy(a->loo_errors, herrs.data(), sizeof(double) * G);
+  if (a->objective) std::memcpy(a->objective, hobj.data(), sizeof(double) * G);
+  if (a->gamma_index) *a->gamma_index = opt;
+  if (a->loo_score) *a->loo_score = is_clf ? hsum[0] : 1.0 - hsum[0] / hsum[1];
+  tm[NLS_T_TOTAL] = wall() - t_start;
+  if (a->timings) std::memcpy(a->timings, tm, sizeof(tm));
+  return NLS_OK;
+}
+
+extern "C" int nls_dual_predict(nls_ctx* ctx, const double* Xq, int64_t m, const double* Xt, int64_t n, int r, const double* alpha,
+                                const double* L, double* yhat, double* sigma) {
+  if (!ctx) return NLS_ERR_ARG;
+  if (!Xq || !Xt || m < 0 || n < 1 || r < 1) return fail(ctx, NLS_ERR_ARG, "Xq/Xt NULL or bad sizes");
+  if (yhat && !alpha) return fail(ctx, NLS_ERR_ARG, "alpha is required for yhat");
+  if (sigma && !L) return fail(ctx, NLS_ERR_ARG, "L is required for sigma");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (m == 0 || (!yhat && !sigma)) return NLS_OK;
+  const long n_pad = round_up(n, BM), r_pad = round_up(r, BK);
+  const double *dXt = nullptr, *dXq = nullptr;
+  NLSCHK(resident(ctx, "in.X", Xt, (size_t)n * r, &dXt));
+  NLSCHK(resident(ctx, "in.Xq", Xq, (size_t)m * r, &dXq));
+  // Query rows per chunk: K block of at most ~2 GiB.
+  long mc = std::max<long>(BM, (long)(((size_t)2 << 30) / ((size_t)n_pad * 8)) / BM * BM);
+  mc = std::min<long>(mc, round_up(m, BM));
+  double *XtT = nullptr, *xx = nullptr, *Qp = nullptr, *qq = nullptr, *K = nullptr, *dalpha = nullptr, *dL = nullptr, *dy = nullptr,
+         *dsig = nullptr, *asum = nullptr;
+  NLSCHK(ws_get_t(ctx, "dual.XpT", (size_t)r_pad * n_pad, &XtT));
+  NLSCHK(ws_get_t(ctx, "dual.xx", (size_t)n_pad, &xx));
+  NLSCHK(ws_get_t(ctx, "dual.Qp", (size_t)mc * r_pad, &Qp));
+  NLSCHK(ws_get_t(ctx, "dual.qq", (size_t)mc, &qq));
+  NLSCHK(ws_get_t(ctx, "dual.Kq", (size_t)mc * n_pad, &K));
+  NLSCHK(ws_get_t(ctx, "out.res", (size_t)round_up(m, BM), &dy));
+  NLSCHK(ws_get_t(ctx, "out.loo_std", (size_t)round_up(m, BM), &dsig));
+  NLSCHK(ws_get_t(ctx, "loo.csum", 4, &asum));
+  hipLaunchKernelGGL(k_transpose_pad, grid2(n_pad, r_pad), dim3(256), 0, ctx->stream, dXt, (long)n, (long)r, (long)r, XtT, r_pad, n_pad);
+  hipLaunchKernelGGL(k_row_sqnorm, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, dXt, (long)n, (long)r, (long)r, xx);
+  HIPCHK(ctx, hipGetLastError());
+  double halpha_sum = 0.0;
+  if (yhat) {
+    NLSCHK(ws_get_t(ctx, "dual.alpha", (size_t)n_pad, &dalpha));
+    HIPCHK(ctx, hipMemcpyAsync(dalpha, alpha, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+    for (long i = 0; i < n; ++i) halpha_sum += alpha[i];  // b = sum(alpha), _neo_ls_svm.py:670
+  }
+  if (sigma) {
+    NLSCHK(ws_get_t(ctx, "dual.Q", (size_t)n_pad * n_pad, &dL));
+    HIPCHK(ctx, hipMemcpyAsync(dL, L, sizeof(double) * n * n, hipMemcpyHostToDevice, ctx->stream));
+  }
+  const double one = 1.0;
+  for (long q0 = 0; q0 < m; q0 += mc) {
+    const long rows = std::min<long>(mc, m - q0);
+    const long rows_pad = round_up(rows, BM);
+    hipLaunchKernelGGL(k_copy_pad, grid2(r_pad, rows_pad), dim3(256), 0, ctx->stream, dXq + q0 * r, rows, (long)r, (long)r, Qp, rows_pad, r_pad);
+    hipLaunchKernelGGL(k_row_sqnorm, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, dXq + q0 * r, rows, (long)r, (long)r, qq);
+    HIPCHK(ctx, hipGetLastError());
+    NLSCHK(rbf_block(ctx, Qp, XtT, qq, xx, rows, n, rows_pad, n_pad, r_pad, 0, 0.0, K));
+    if (yhat) {
+      hipLaunchKernelGGL(k_dual_gemv, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, K, n_pad, rows, (long)n, dalpha, halpha_sum,
+                         (const double*)nullptr, 0, dy + q0);
+      HIPCHK(ctx, hipGetLastError());
+    }
+    if (sigma) {
+      // Z = Lc^-1 K^T with Lc the column-major lower factor (== the row-major upper U); K (rows x n_pad row-major) is
+      // K^T column-major with leading dimension n_pad.  sigma2_i = 1 - ||Z[:, i]||^2.
+      BLASCHK(ctx, rocblas_dtrsm(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit,
+                                 (rocblas_int)n, (rocblas_int)rows, &one, dL, (rocblas_int)n, K, (rocblas_int)n_pad));
+      hipLaunchKernelGGL(k_dual_sigma, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, K, K, n_pad, rows, (long)n, dsig + q0);
+      HIPCHK(ctx, hipGetLastError());
+    }
+  }
+  if (yhat) HIPCHK(ctx, hipMemcpyAsync(yhat, dy, sizeof(double) * m, hipMemcpyDeviceToHost, ctx->stream));
+  if (sigma) HIPCHK(ctx, hipMemcpyAsync(sigma, dsig, sizeof(double) * m, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return NLS_OK;
 }

@@ -1,0 +1,76 @@
+"""GPU parity tests of the dual path (D1-D6) against the reference fixtures and the NumPy oracle."""
+
+from __future__ import annotations
+
+import numpy as np
+import pytest
+from conftest import DUAL_CASES, relerr, signed_targets
+
+import neolssvm_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def hp():
+    import neo_ls_svm_amd as pkg
+
+    pkg.default_context()
+    return pkg
+
+
+@pytest.mark.parametrize("name", DUAL_CASES)
+def test_dual_fit_matches_reference_fixture(name, golden_loader, hp):
+    g = golden_loader(name)
+    nz = g["nz"]
+    y, s, is_clf = signed_targets(g)[nz], g["s"][nz], g["task"] == "clf"
+    r = hp.dual_fit(g["Xt"], y, s, is_clf)
+    assert np.array_equal(r["gammas"], g["gammas"])
+    assert relerr(r["loo_errors_gammas"], g["loo_errors_gammas"]) < TOL
+    assert r["opt"] == int(g["opt"])
+    assert relerr(r["alpha"], g["alpha"]) < TOL
+    assert relerr(r["loo_residuals"], g["loo_residuals"]) < TOL
+    assert relerr(r["loo_yhat"], g["loo_yhat"]) < TOL
+    assert relerr(r["residuals"], g["residuals"]) < TOL
+    assert relerr(r["loo_std"], g["loo_std"]) < TOL
+    assert abs(r["loo_score"] - float(g["loo_score"])) < 1e-9
+    yq, sq = hp.dual_predict(g["Xqt"], g["Xt"], alpha=r["alpha"], L=r["L"])
+    assert relerr(yq, g["decision_function"]) < TOL
+    assert relerr(sq, g["predict_std"]) < TOL
+    # the stored factor is scipy's cho_factor(lower=False) layout
+    o = orc.dual_fit_reduced(g["Xt"], y, s, is_clf)
+    iu = np.triu_indices(y.size)
+    assert relerr(r["L"][iu], o["L"][iu]) < TOL
+    assert relerr(r["lam"], o["lam"]) < 1e-8
+
+
+@pytest.mark.parametrize("task", ["reg", "clf"])
+def test_dual_fit_vs_oracle_seeded(task, hp):
+    rng = np.random.default_rng(9)
+    n, r_ = 777, 37  # ragged sizes
+    Xt = rng.standard_normal((n, r_)) * 0.4
+    w = rng.standard_normal(r_)
+    y = np.sin(Xt @ w) + 0.1 * rng.standard_normal(n) if task == "reg" else np.where(Xt @ w + 0.2 * rng.standard_normal(n) > 0, 1.0, -1.0)
+    s = rng.uniform(0.3, 2.0, n)
+    o = orc.dual_fit_reduced(Xt, y, s, task == "clf")
+    r = hp.dual_fit(Xt, y, s, task == "clf", gamma_index=o["opt"])
+    assert relerr(r["loo_errors_gammas"], o["loo_errors_gammas"]) < 1e-6
+    assert relerr(r["alpha"], o["alpha"]) < TOL
+    assert relerr(r["loo_residuals"], o["loo_residuals"]) < 1e-6
+    assert relerr(r["loo_std"], o["loo_std"]) < 1e-6
+    assert abs(r["loo_score"] - o["loo_score"]) < 1e-8
+    Xq = rng.standard_normal((300, r_)) * 0.4
+    yq, sq = hp.dual_predict(Xq, Xt, alpha=o["alpha"], L=o["L"])
+    assert relerr(yq, orc.dual_decision_function(Xq, Xt, o["alpha"])) < 1e-10
+    assert relerr(sq, orc.dual_predict_std(Xq, Xt, o["L"], o["L_lower"])) < 1e-7
+
+
+def test_dual_rejects_zero_weights(hp):
+    rng = np.random.default_rng(0)
+    Xt, y = rng.standard_normal((40, 3)), rng.standard_normal(40)
+    s = np.ones(40)
+    s[3] = 0.0
+    with pytest.raises(ValueError):
+        hp.dual_fit(Xt, y, s, False)

@@ -286,7 +286,7 @@ def primal_fit_streamed(
         tick("feature_map", t0)
         t0 = time.perf_counter()
         P = phi @ Q
-        U = np.real(P * v[None, :])
+        U = np.ascontiguousarray(np.real(P * v[None, :]))  # np.real is a strided view (:141-143)
         Gm = np.real(P) ** 2 + np.imag(P) ** 2
         tick("rotate", t0)
         t0 = time.perf_counter()
@@ -552,7 +552,7 @@ def time_primal_row_stages(X, y, s, shift, scale, B, gammas, row_tile: int = 204
         st["feature_map"] += time.perf_counter() - t0
         t0 = time.perf_counter()
         P = phi @ Q
-        U = np.real(P * v[None, :])
+        U = np.ascontiguousarray(np.real(P * v[None, :]))  # np.real is a strided view (:141-143)
         Gm = np.real(P) ** 2 + np.imag(P) ** 2
         st["rotate"] += time.perf_counter() - t0
         t0 = time.perf_counter()

@@ -1,0 +1,260 @@
+"""Supervised affine pre-step: produces ``shift_``, ``scale_`` and the separator matrix ``A_``.
+
+This is the host-side (NumPy) counterpart of the reference's L2c layer, which runs *before* the hot path and
+feeds it.  It restates, in this package's own code, what these reference functions
+compute so that ``NeoLSSVM.fit`` can stand alone where upstream ``neo_ls_svm`` is not installed:
+
+    sample bins of the target      _quantizer.py:98-171 (hist_quantized_ecdf), :246-253
+    weighted per-bin medians       _weighted_quantile.py:35-77
+    shift / scale                  _affine_normalizer.py:50-117
+    separator matrix A and lambda  _affine_separator.py:107-210
+
+The random draws use ``numpy.random.RandomState`` in the same order as the reference, so for equal inputs the
+outputs agree with it to rounding (pinned by ``tests/test_prestep.py`` against the golden fixtures).
+It is O(n d log n) sort/select work on the CPU - SURVEY.md 8(f) lists it as the next row to move to the GPU.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+__all__ = ["target_bins", "weighted_median_columns", "fit_affine_normalizer", "fit_affine_separator"]
+
+
+# --------------------------------------------------------------------------------------------
+# Target binning (ECDF quantisation)
+# --------------------------------------------------------------------------------------------
+def _scan_right(xs, cum, knot, tol, cap):
+    """Grow a bin [knot, nxt) to the right until its linear ECDF fit breaks ``tol`` or it exceeds ``cap``.
+
+    ``_quantizer.py:18-44``.  xs/cum carry the -inf/0 and +inf/max sentinels at both ends.
+    """
+    lo, hi = 0.0, np.inf
+    nxt, count = knot, 0
+    for nxt in range(knot + 1, len(xs)):
+        count = int(cum[nxt - 1] - cum[knot - 1]) if knot > 0 else int(cum[nxt - 1])
+        if count > cap:
+            break
+        if nxt == knot + 1:
+            continue
+        dx, dy = xs[nxt - 1] - xs[knot], cum[nxt - 1] - cum[knot]
+        hi = min(hi, (dy + tol) / dx)
+        lo = max(lo, (dy - tol) / dx)
+        if not (lo <= dy / dx <= hi):
+            break
+    return nxt, count
+
+
+def _scan_left(xs, cum, knot, tol, cap):
+    """Mirror image of ``_scan_right``: ``_quantizer.py:47-73``."""
+    lo, hi = 0.0, np.inf
+    prv, count = knot, 0
+    for prv in range(knot - 1, -1, -1):
+        count = int(cum[knot - 1] - cum[prv - 1]) if prv > 0 else int(cum[knot - 1])
+        if count > cap:
+            break
+        if knot == prv + 1:
+            continue
+        dx, dy = xs[knot - 1] - xs[prv], cum[knot - 1] - cum[prv]
+        hi = min(hi, (dy + tol) / dx)
+        lo = max(lo, (dy - tol) / dx)
+        if not (lo <= dy / dx <= hi):
+            break
+    return prv, count
+
+
+def _ecdf_bin_edges(values, max_bin_error=0.0125, max_bin_size=0.125, merge_bin_size=0.025):
+    """Variable-width bin edges from both ends of the ECDF towards the middle: ``_quantizer.py:98-171``."""
+    n = len(values)
+    tol, cap, merge = int(max_bin_error * n), int(max_bin_size * n), int(merge_bin_size * n)
+    ux, counts = np.unique(values, return_counts=True)
+    cum = np.cumsum(counts)
+    xs = np.concatenate(([-np.inf], ux, [np.inf]))
+    cs = np.concatenate(([0], cum, [np.iinfo(cum.dtype).max]))
+    left, right = 1, len(xs) - 1
+    edges_l, edges_r = [ux[0]], [ux[-1]]
+    edges = None
+    while left < right:
+        left_prev, right_prev = left, right
+        left, _ = _scan_right(xs, cs, left, tol, cap)
+        right, _ = _scan_left(xs, cs, right, tol, cap)
+        edges_l.append((xs[left] + xs[left - 1]) / 2 if left > 0 else xs[left])
+        edges_r.insert(0, (xs[right] + xs[right - 1]) / 2 if right > 0 else xs[right])
+        if left == right:
+            edges = edges_l + edges_r[1:]
+            break
+        if left > right:
+            edges = edges_l[:-1] + edges_r[1:]
+            break
+        if cs[right - 1] - cs[left - 1] <= merge:
+            mid_l = int(np.floor((left + right) / 2))
+            mid_r = int(np.ceil((left + right) / 2))
+            edges = edges_l[:-1] + [(xs[mid_l] + xs[mid_r]) / 2] + edges_r[1:]
+            break
+        del left_prev, right_prev
+    if edges is None:  # pragma: no cover - the loop always terminates through one of the breaks
+        edges = edges_l + edges_r[1:]
+    return np.asarray(edges, dtype=np.float64)
+
+
+def target_bins(y: np.ndarray) -> np.ndarray:
+    """Integer class-bin label per sample: ``sample_bins_quantized_ecdf``, ``_quantizer.py:246-253``.
+
+    Few distinct targets (<= ceil(sqrt(n))) are their own bins (classification); otherwise the target's
+    ECDF is quantised into dynamically sized bins.
+    """
+    uniq, inv = np.unique(y, return_inverse=True)
+    if len(uniq) <= np.ceil(np.sqrt(len(y))):
+        return inv
+    edges = _ecdf_bin_edges(inv)  # the reference quantises the rank codes, not the raw values
+    return np.clip(np.searchsorted(edges, inv, side="right") - 1, 0, len(edges) - 2).astype(np.intp)
+
+
+# --------------------------------------------------------------------------------------------
+# Weighted medians
+# --------------------------------------------------------------------------------------------
+def weighted_median_columns(Xb: np.ndarray, wb: np.ndarray) -> np.ndarray:
+    """Weighted 0.5-quantile of every column: ``weighted_quantile(a, w, 0.5, axis=0)``, ``_weighted_quantile.py:35-63``.
+
+    The estimate is the average of the two interpolants through (lower cumulative weight, value) and
+    (upper cumulative weight, value).
+    """
+    A = np.ascontiguousarray(Xb.T)  # one row per feature
+    W = np.broadcast_to(np.ravel(wb)[None, :], A.shape)
+    order = np.argsort(A, axis=1)
+    A = np.take_along_axis(A, order, axis=1)
+    W = np.take_along_axis(W, order, axis=1)
+    cum = np.cumsum(W, axis=1)
+    total = cum[:, [-1]].copy()
+    p_lo, p_hi = (cum - W) / total, cum / total
+    out = np.empty(A.shape[0], dtype=A.dtype)
+    for j in range(A.shape[0]):
+        out[j] = (np.interp(0.5, p_lo[j], A[j]) + np.interp(0.5, p_hi[j], A[j])) / 2
+    return out[None, :]
+
+
+# --------------------------------------------------------------------------------------------
+# Shift / scale
+# --------------------------------------------------------------------------------------------
+def _split_bins(X, y, sw):
+    labels = target_bins(y)
+    masks = [labels == i for i in range(np.min(labels), np.max(labels) + 1)]
+    X_bins = [X[m, :] for m in masks]
+    n_bins = [np.sum(sw[m]) for m in masks]
+    s_bins = [sw[np.newaxis, m] / np.sum(sw[m]) for m in masks]
+    return masks, X_bins, n_bins, s_bins
+
+
+def fit_affine_normalizer(X: np.ndarray, y: np.ndarray, sample_weight: np.ndarray | None = None):
+    """(shift, scale), each 1 x d: ``AffineNormalizer.fit``, ``_affine_normalizer.py:50-117``.
+
+    Per-bin weighted medians and mean absolute deviations; every pair of bins votes for a separating
+    threshold (shift) and a spread (scale) with weight sqrt((n_i + n_j) (1/2 + separability)).
+    """
+    X = np.asarray(X)
+    y = np.ravel(np.asarray(y)).astype(X.dtype)
+    sw = (np.ones(y.shape) if sample_weight is None else np.ravel(np.asarray(sample_weight))).astype(y.dtype)
+    d = X.shape[1]
+    _, X_bins, n_bins, s_bins = _split_bins(X, y, sw)
+    if len(X_bins) <= 1:
+        return np.zeros((1, d), dtype=X.dtype), np.ones((1, d), dtype=X.dtype)
+    centers = [weighted_median_columns(Xb, sb) for Xb, sb in zip(X_bins, s_bins)]
+    spreads = [sb @ np.abs(Xb - mu) for Xb, sb, mu in zip(X_bins, s_bins, centers)]
+    eps = np.finfo(X.dtype).eps
+    sign = np.zeros((1, d), dtype=X.dtype)
+    wsum = np.zeros((1, d), dtype=X.dtype)
+    shift = np.zeros((1, d), dtype=X.dtype)
+    scale = np.zeros((1, d), dtype=X.dtype)
+    for i in range(len(centers) - 1):
+        for j in range(i + 1, len(centers)):
+            dmu = centers[j] - centers[i]
+            ssum = np.maximum(spreads[i] + spreads[j], eps)
+            w = np.sqrt((n_bins[i] + n_bins[j]) * (0.5 + np.abs(dmu) / ssum))
+            alpha = np.clip(spreads[i] / ssum, 1e-6, 1.0 - 1e-6)
+            shift = shift + w * (centers[i] + alpha * dmu)
+            scale = scale + w * ssum
+            sign += w * np.sign(dmu)
+            wsum += w
+    sign /= wsum
+    shift, scale = shift / wsum, scale / wsum
+    scale[np.sign(sign) < 0] = -scale[np.sign(sign) < 0]
+    return shift, scale
+
+
+# --------------------------------------------------------------------------------------------
+# Separator matrix
+# --------------------------------------------------------------------------------------------
+def _sq_dists(P, Q):
+    return np.sum(P * P, axis=1, keepdims=True) - 2 * P @ Q.T + np.sum(Q * Q, axis=1, keepdims=True).T
+
+
+def _nearest_rows(P, Q):
+    """Rows of Q nearest to each row of P: ``_affine_separator.py:24-29``."""
+    idx = np.argmin(_sq_dists(P, Q), axis=1, keepdims=True)
+    return np.take_along_axis(Q, idx, axis=0)
+
+
+def _right_singular_vectors(M):
+    """Singular values (descending) and right singular vectors via an eigendecomposition: ``:32-51``."""
+    if M.shape[0] >= M.shape[1]:
+        e, V = np.linalg.eigh(M.conj().T @ M)
+        return np.sqrt(np.abs(e))[::-1], V[:, ::-1]
+    e, U = np.linalg.eigh(M @ M.conj().T)
+    sv = np.sqrt(np.abs(e))[::-1]
+    U = U[:, ::-1]
+    keep = sv > 0
+    sv, U = sv[keep], U[:, keep]
+    return sv, (M.conj().T @ U) / sv[np.newaxis, :]
+
+
+def fit_affine_separator(
+    X: np.ndarray,
+    y: np.ndarray,
+    sample_weight: np.ndarray | None = None,
+    *,
+    rank_threshold: float = 2e-2,
+    edge_sample_size: int = 384,
+    edge_search_multiplier: int = 4,
+    random_state=42,
+):
+    """(shift, scale, A): ``AffineSeparator.fit``, ``_affine_separator.py:107-210``.  A is None for one bin.
+
+    For every class bin: sample edge points of the bin and of its complement (weighted draws), pair each
+    with its nearest neighbour on the other side, and keep the leading right singular vectors of the
+    difference matrix.  The concatenated directions are scaled by lambda = sqrt(2 log(f/g) / (f - g)) with f / g
+    the mean inter- / intra-bin squared distances of the edge samples.
+    """
+    X = np.asarray(X)
+    y = np.ravel(np.asarray(y)).astype(X.dtype)
+    shift, scale = fit_affine_normalizer(X, y, sample_weight)
+    Xn = ((X - shift) / scale).astype(X.dtype)
+    sw = (np.ones(y.shape) if sample_weight is None else np.ravel(np.asarray(sample_weight))).astype(y.dtype)
+    masks, X_bins, n_bins, s_bins = _split_bins(Xn, y, sw)
+    if len(X_bins) <= 1:
+        return shift, scale, None
+    m = int(edge_sample_size * 4 / 3) if len(X_bins) == 2 else edge_sample_size
+    gen = random_state if isinstance(random_state, np.random.RandomState) else np.random.RandomState(random_state)
+    dirs, edge_in, edge_out = [], [], []
+    for i in range(len(X_bins)):
+        p_in = np.ravel(s_bins[i])
+        seeds = X_bins[i][gen.choice(len(X_bins[i]), size=m, p=p_in), :]
+        X_rest = np.vstack([Xb for j, Xb in enumerate(X_bins) if j != i])
+        s_rest = np.hstack([sw[mk] for j, mk in enumerate(masks) if j != i])
+        cand = X_rest[gen.choice(len(X_rest), size=m * edge_search_multiplier, p=np.ravel(s_rest) / np.sum(s_rest)), :]
+        outside = _nearest_rows(seeds, cand)
+        edge_out.append(outside)
+        cand_in = X_bins[i][gen.choice(len(X_bins[i]), size=m * edge_search_multiplier, p=p_in), :]
+        inside = _nearest_rows(outside, cand_in)
+        edge_in.append(inside)
+        sv, V = _right_singular_vectors(inside - outside)
+        dirs.append(V[:, : int(np.sum(sv > rank_threshold * sv[0]))])
+    A = np.hstack(dirs)
+    inter = intra = 0.0
+    n_inter, n_intra = m * (m + 1) / 2, m * (m - 1) / 2
+    for ein, eout, nb in zip(edge_in, edge_out, n_bins):
+        inter += nb * np.sum(np.tril(_sq_dists(ein @ A, eout @ A), k=0)) / n_inter
+        intra += nb * np.sum(np.tril(_sq_dists(ein @ A, ein @ A), k=-1)) / n_intra
+    inter /= sum(n_bins)
+    intra /= sum(n_bins)
+    lam = np.sqrt(2 * np.log(inter / intra) / (inter - intra)) if intra > 0 else 1
+    return shift, scale, A * lam

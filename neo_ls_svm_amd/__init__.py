@@ -16,7 +16,12 @@ from .hotpath import (  # noqa: F401
     primal_predict,
 )
 
+from .estimator import AffineSeparator, NeoLSSVM, OrthogonalRandomFourierFeatures  # noqa: E402,F401
+
 __all__ = [
+    "NeoLSSVM",
+    "OrthogonalRandomFourierFeatures",
+    "AffineSeparator",
     "Context",
     "DeviceArray",
     "NlsError",

@@ -1,0 +1,317 @@
+"""sklearn-compatible ``NeoLSSVM`` whose solver section runs on the MI355X.
+
+Mirrors the reference estimator's public surface (``_neo_ls_svm.py:43-821``): constructor parameters,
+``fit / decision_function / predict / predict_std / predict_proba / score`` and the fitted attributes the
+reference sets (same names, including the Greek ones, so code written against upstream keeps working).
+What differs is *where* the work happens:
+
+    validation, task inference, primal/dual switch        here, as ``_neo_ls_svm.py:335-376``
+    supervised affine pre-step + ORF frequency matrix     host NumPy (``_prestep.py``, ``hotpath.orf_frequencies``)
+    feature map, Gram, EVD, gamma sweep, Cholesky, sigma  GPU, one C-ABI call (``nls_primal_fit`` / ``nls_dual_fit``)
+    inference                                             GPU (``nls_primal_predict`` / ``nls_dual_predict``)
+    isotonic calibration, conformal split                 host sklearn, as ``_neo_ls_svm.py:405-441``
+
+Fitted state lives in NumPy attributes (beta, L, shift/scale/A) so the estimator pickles and predicts
+without the context that fitted it.  The conformal quantile regressors (``predict_quantiles`` /
+``predict_interval``) are outside the hot path and are not provided.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+from sklearn.base import BaseEstimator, clone
+from sklearn.isotonic import IsotonicRegression
+from sklearn.metrics import accuracy_score, r2_score
+from sklearn.model_selection import train_test_split
+from sklearn.utils.validation import check_array, check_consistent_length, check_is_fitted, check_X_y
+
+from . import _prestep, hotpath
+from ._lib import default_context
+
+__all__ = ["NeoLSSVM", "AffineSeparator", "OrthogonalRandomFourierFeatures"]
+
+
+class AffineSeparator(BaseEstimator):
+    """(x - shift) diag(1/scale) A with supervised shift/scale/A: reference ``_affine_separator.py:54-210``."""
+
+    def __init__(self, *, rank_threshold=2e-2, edge_sample_size=384, edge_search_multiplier=4, random_state=42):
+        self.rank_threshold = rank_threshold
+        self.edge_sample_size = edge_sample_size
+        self.edge_search_multiplier = edge_search_multiplier
+        self.random_state = random_state
+
+    def fit(self, X, y, sample_weight=None):
+        X, y = check_X_y(X, y, dtype=np.float64)
+        self.shift_, self.scale_, self.A_ = _prestep.fit_affine_separator(
+            X,
+            y,
+            sample_weight,
+            rank_threshold=self.rank_threshold,
+            edge_sample_size=self.edge_sample_size,
+            edge_search_multiplier=self.edge_search_multiplier,
+            random_state=self.random_state,
+        )
+        self.n_features_in_ = X.shape[1]
+        return self
+
+    def transform(self, X):
+        """Affine map only (used by the dual path: ``_neo_ls_svm.py:394,668``); n x r output, host GEMM."""
+        X = check_array(X, dtype=np.float64)
+        Xs = (X - self.shift_) / self.scale_
+        return Xs if self.A_ is None else Xs @ self.A_
+
+
+class OrthogonalRandomFourierFeatures(BaseEstimator):
+    """phi(x) = [exp(-i Z^T A^T ((x - shift)/scale)) / sqrt(D), 1]: reference ``_feature_maps.py:117-223``.
+
+    ``fit`` learns the separator and folds the ORF matrix Z into its A (``:147-150``); ``transform`` evaluates the
+    map on the GPU (``nls_featuremap``).
+    """
+
+    def __init__(self, affine_feature_map=None, num_features=512, random_state=42):
+        self.affine_feature_map = affine_feature_map
+        self.num_features = num_features
+        self.random_state = random_state
+
+    def fit(self, X, y=None, sample_weight=None):
+        self.affine_feature_map_ = clone(self.affine_feature_map) if self.affine_feature_map is not None else AffineSeparator()
+        self.affine_feature_map_.fit(X, y, sample_weight)
+        A = self.affine_feature_map_.A_
+        d_in = A.shape[1] if A is not None else np.asarray(X).shape[1]
+        self.Z_ = hotpath.orf_frequencies(d_in, self.num_features, self.random_state)
+        self.B_ = A @ self.Z_ if A is not None else self.Z_
+        self.n_features_in_ = np.asarray(X).shape[1]
+        return self
+
+    @property
+    def map_params(self):
+        return np.ravel(self.affine_feature_map_.shift_), np.ravel(self.affine_feature_map_.scale_), self.B_
+
+    @property
+    def complexity_matrix(self):
+        """Identity: the reference's fast diagonal approximation (``_feature_maps.py:129-135``)."""
+        return np.eye(self.num_features + 1)
+
+    def transform(self, X, ctx=None):
+        shift, scale, B = self.map_params
+        return hotpath.featuremap(check_array(X, dtype=np.float64), shift, scale, B, ctx=ctx)
+
+
+def _series_like(values, X_in):
+    if hasattr(X_in, "dtypes") and hasattr(X_in, "index"):
+        try:
+            import pandas as pd
+        except ImportError:
+            return values
+        return pd.Series(values, index=X_in.index)
+    return values
+
+
+class NeoLSSVM(BaseEstimator):
+    """Neo LS-SVM with the fit/predict hot path on an MI355X (drop-in for ``neo_ls_svm.NeoLSSVM``)."""
+
+    def __init__(
+        self,
+        *,
+        primal_feature_map="auto",
+        dual_feature_map="auto",
+        dual="auto",
+        estimator_type="auto",
+        random_state=42,
+        device=0,
+    ):
+        self.primal_feature_map = primal_feature_map
+        self.dual_feature_map = dual_feature_map
+        self.dual = dual
+        self.random_state = random_state
+        self.estimator_type = estimator_type
+        self.device = device
+
+    # ---- sklearn plumbing -------------------------------------------------------------------
+    def __sklearn_tags__(self):
+        tags = super().__sklearn_tags__()
+        tags.target_tags.required = True
+        kind = getattr(self, "_estimator_type", None) or (None if self.estimator_type == "auto" else self.estimator_type)
+        if kind == "classifier":
+            from sklearn.utils import ClassifierTags
+
+            tags.estimator_type = "classifier"
+            tags.classifier_tags = ClassifierTags(multi_class=False)
+        elif kind == "regressor":
+            from sklearn.utils import RegressorTags
+
+            tags.estimator_type = "regressor"
+            tags.regressor_tags = RegressorTags()
+        return tags
+
+    def _ctx(self):
+        return default_context(int(self.device))
+
+    # ---- fit --------------------------------------------------------------------------------
+    def fit(self, X, y, sample_weight=None):
+        """Fit this predictor (reference ``fit``: ``_neo_ls_svm.py:327-442``)."""
+        X, y = check_X_y(X, y, dtype=(np.float64, np.float32), ensure_min_samples=2)
+        X = np.ascontiguousarray(X, dtype=np.float64)  # the GPU path computes in float64 throughout
+        y = np.ravel(np.asarray(y))
+        self.n_features_in_ = X.shape[1]
+        self.y_dtype_ = y.dtype
+        sw = np.ones(y.shape, np.float64) if sample_weight is None else np.ravel(np.asarray(sample_weight)).astype(np.float64)
+        check_consistent_length(y, sw)
+        # Task inference (:351-373).
+        unique_y = np.unique(y)
+        inferred = None
+        if len(unique_y) == 2:  # noqa: PLR2004
+            inferred = "classifier"
+        elif np.issubdtype(y.dtype, np.number) or np.issubdtype(y.dtype, np.datetime64) or np.issubdtype(y.dtype, np.timedelta64):
+            inferred = "regressor"
+        self._estimator_type = inferred if self.estimator_type == "auto" else self.estimator_type
+        if self._estimator_type == "classifier":
+            self.classes_ = unique_y
+            y_ = np.ones(y.shape, dtype=np.float64)
+            y_[y == self.classes_[0]] = -1
+        elif self._estimator_type == "regressor":
+            y_ = y.astype(np.float64)
+        else:
+            raise ValueError("Target type not supported")
+        is_clf = self._estimator_type == "classifier"
+        self.dual_ = bool(X.shape[0] <= 1024 if self.dual == "auto" else self.dual)  # noqa: PLR2004
+        self.primal_ = not self.dual_
+        ctx = self._ctx()
+        if self.primal_:
+            fm = OrthogonalRandomFourierFeatures() if isinstance(self.primal_feature_map, str) else self.primal_feature_map
+            if not isinstance(fm, OrthogonalRandomFourierFeatures):  # e.g. upstream's feature-map object: take its size
+                fm = OrthogonalRandomFourierFeatures(
+                    num_features=int(getattr(fm, "num_features", 512)), random_state=getattr(fm, "random_state", 42)
+                )
+            self.primal_feature_map_ = clone(fm).fit(X, y_, sw)
+            shift, scale, B = self.primal_feature_map_.map_params
+            r = hotpath.primal_fit(X, y_, sw, shift, scale, B, is_clf, ctx=ctx)
+            self.β̂_, self.γ_ = r["beta"], r["gamma"]
+            self.loo_leverage_ = r["loo_leverage"]
+        else:
+            nz = sw > 0
+            X, y_, sw = X[nz], y_[nz], sw[nz]
+            sep = AffineSeparator() if isinstance(self.dual_feature_map, str) else self.dual_feature_map
+            if not isinstance(sep, AffineSeparator):
+                sep = AffineSeparator()
+            self.dual_feature_map_ = clone(sep).fit(X, y_, sw)
+            self.X_ = np.ascontiguousarray(self.dual_feature_map_.transform(X))
+            r = hotpath.dual_fit(self.X_, y_, sw, is_clf, ctx=ctx)
+            self.α̂_, self.γ_ = r["alpha"], r["gamma"]
+        # Attributes the reference's solver sets as side effects (:146-187 / :270-323).
+        self.γs_ = r["gammas"]
+        self.loo_errors_γs_ = r["loo_errors_gammas"]
+        self.loo_residuals_ = r["loo_residuals"]
+        self.loo_ŷ_ = y_ + r["loo_residuals"]
+        self.loo_error_ = r["loo_error"]
+        self.loo_score_ = r["loo_score"]
+        self.L_ = (r["L"], False)
+        self.residuals_ = r["residuals"]
+        self.loo_std_ = r["loo_std"]
+        self.fit_timings_ = r["timings"]
+        # Isotonic probability calibration on the LOO predictions (:406-412).
+        if is_clf:
+            self.predict_proba_calibrator_ = IsotonicRegression(out_of_bounds="clip", y_min=0, y_max=1, increasing=True)
+            target = np.zeros_like(y_)
+            target[y_ == np.max(y_)] = 1.0
+            self.predict_proba_calibrator_.fit(self.loo_ŷ_, target, sw)
+        # Two-level conformal calibration split of the LOO quantities (:414-430).
+        (
+            self.nonconformity_calib_l1_,
+            self.nonconformity_calib_l2_,
+            self.ŷ_calib_l1_,
+            self.ŷ_calib_l2_,
+            self.residuals_calib_l1_,
+            self.residuals_calib_l2_,
+            self.sample_weight_calib_l1_,
+            self.sample_weight_calib_l2_,
+        ) = train_test_split(
+            self.loo_std_,
+            self.loo_ŷ_,
+            self.loo_residuals_,
+            sw,
+            train_size=min(1440, max(1024, (X.shape[0] * 2) // 3), X.shape[0] - 1),
+            random_state=self.random_state,
+        )
+        return self
+
+    # ASCII aliases of the Greek attribute names.
+    @property
+    def beta_(self):
+        return self.β̂_
+
+    @property
+    def alpha_(self):
+        return self.α̂_
+
+    @property
+    def gamma_(self):
+        return self.γ_
+
+    # ---- inference ----------------------------------------------------------------------------
+    def _check_X(self, X):
+        check_is_fitted(self)
+        Xa = check_array(X, dtype=(np.float64, np.float32))
+        if Xa.shape[1] != self.n_features_in_:
+            raise ValueError(f"X has {Xa.shape[1]} features, but NeoLSSVM is expecting {self.n_features_in_} features as input")
+        return np.ascontiguousarray(Xa, dtype=np.float64)
+
+    def decision_function(self, X):
+        """yhat(X): primal Re(phi(X) beta), dual k(X, X_) alpha + 1'alpha (``_neo_ls_svm.py:655-681``)."""
+        Xa = self._check_X(X)
+        if self.primal_:
+            shift, scale, B = self.primal_feature_map_.map_params
+            yhat, _ = hotpath.primal_predict(Xa, shift, scale, B, beta=self.β̂_, ctx=self._ctx())
+        else:
+            Xq = np.ascontiguousarray(self.dual_feature_map_.transform(Xa))
+            yhat, _ = hotpath.dual_predict(Xq, self.X_, alpha=self.α̂_, ctx=self._ctx())
+        return _series_like(yhat, X)
+
+    def predict_std(self, X):
+        """Bayesian predictive standard deviation from the stored Cholesky factor (``:452-487``)."""
+        Xa = self._check_X(X)
+        if self.primal_:
+            shift, scale, B = self.primal_feature_map_.map_params
+            _, sigma = hotpath.primal_predict(Xa, shift, scale, B, L=self.L_[0], ctx=self._ctx())
+        else:
+            Xq = np.ascontiguousarray(self.dual_feature_map_.transform(Xa))
+            _, sigma = hotpath.dual_predict(Xq, self.X_, L=self.L_[0], ctx=self._ctx())
+        return _series_like(sigma, X)
+
+    def predict(self, X, *, coverage=None, quantiles=None):
+        """Point predictions (``:719-762``).  Interval / quantile prediction is outside this package's scope."""
+        if coverage is not None or quantiles is not None:
+            raise NotImplementedError(
+                "conformal predict_quantiles / predict_interval are outside the MI355X hot path (SURVEY.md section 2, rows 6/8)"
+            )
+        yhat = np.asarray(self.decision_function(X))
+        if self._estimator_type == "classifier":
+            sgn = np.sign(yhat)
+            sgn[sgn == 0] = -1
+            out = self.classes_[((sgn + 1) // 2).astype(np.intp)]
+        else:
+            out = yhat
+        if not np.issubdtype(self.y_dtype_, np.integer):
+            out = out.astype(self.y_dtype_)
+        return _series_like(out, X)
+
+    def predict_proba(self, X):
+        """Isotonically calibrated class probabilities (classifier) or the prediction (regressor): ``:772-799``."""
+        yhat = np.asarray(self.decision_function(X))
+        if self._estimator_type == "classifier":
+            pos = self.predict_proba_calibrator_.transform(yhat)
+            proba = np.hstack([1 - pos[:, None], pos[:, None]])
+            if hasattr(X, "dtypes") and hasattr(X, "index"):
+                import pandas as pd
+
+                return pd.DataFrame(proba, index=X.index, columns=self.classes_)
+            return proba
+        out = yhat if np.issubdtype(self.y_dtype_, np.integer) else yhat.astype(self.y_dtype_)
+        return _series_like(out, X)
+
+    def score(self, X, y, sample_weight=None):
+        """Accuracy or R^2 (``:801-817``)."""
+        yhat = np.asarray(self.predict(X))
+        if self._estimator_type == "classifier":
+            return accuracy_score(y, yhat, sample_weight=sample_weight)
+        return r2_score(np.asarray(y).astype(np.float64), yhat.astype(np.float64), sample_weight=sample_weight)

@@ -1,0 +1,104 @@
+"""End-to-end GPU tests of the sklearn surface: NeoLSSVM.fit / predict / predict_std vs the reference fixtures."""
+
+from __future__ import annotations
+
+import pickle
+
+import numpy as np
+import pytest
+from conftest import DUAL_CASES, PRIMAL_CASES, relerr
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+def _fit(g, dual):
+    from neo_ls_svm_amd import NeoLSSVM, OrthogonalRandomFourierFeatures
+
+    sw = g["s"] if bool(g["has_weights"]) else None
+    if dual:
+        return NeoLSSVM(dual=True).fit(g["X"], g["y"], sample_weight=sw)
+    fm = OrthogonalRandomFourierFeatures(num_features=int(g["D"]))
+    return NeoLSSVM(primal_feature_map=fm, dual=False).fit(g["X"], g["y"], sample_weight=sw)
+
+
+@pytest.mark.parametrize("name", PRIMAL_CASES)
+def test_primal_estimator_matches_reference(name, golden_loader):
+    g = golden_loader(name)
+    m = _fit(g, dual=False)
+    assert m.primal_ and not m.dual_
+    assert m._estimator_type == ("classifier" if g["task"] == "clf" else "regressor")
+    assert relerr(m.primal_feature_map_.B_, g["B"]) < 1e-9
+    assert m.γ_ == float(g["gamma"])
+    assert relerr(m.β̂_, g["beta"]) < TOL
+    assert relerr(m.loo_residuals_, g["loo_residuals"]) < TOL
+    assert relerr(m.loo_ŷ_, g["loo_yhat"]) < TOL
+    assert relerr(m.loo_leverage_, g["loo_leverage"]) < TOL
+    assert relerr(m.loo_std_, g["loo_std"]) < TOL
+    assert relerr(m.residuals_, g["residuals"]) < TOL
+    assert relerr(m.loo_errors_γs_, g["loo_errors_gammas"]) < TOL
+    assert abs(m.loo_score_ - float(g["loo_score"])) < 1e-8
+    assert relerr(m.decision_function(g["Xq"]), g["decision_function"]) < TOL
+    assert relerr(m.predict_std(g["Xq"]), g["predict_std"]) < TOL
+    if g["task"] == "clf":
+        assert np.array_equal(m.predict(g["Xq"]), g["predict"])
+        p = m.predict_proba(g["Xq"])
+        assert p.shape == (g["Xq"].shape[0], 2) and np.allclose(p.sum(1), 1)
+    else:
+        assert relerr(m.predict(g["Xq"]), g["predict"]) < TOL
+    m2 = pickle.loads(pickle.dumps(m))
+    assert np.array_equal(np.asarray(m2.decision_function(g["Xq"])), np.asarray(m.decision_function(g["Xq"])))
+    assert m.L_[1] is False and m.L_[0].shape == (int(g["D"]) + 1,) * 2
+
+
+@pytest.mark.parametrize("name", DUAL_CASES)
+def test_dual_estimator_matches_reference(name, golden_loader):
+    g = golden_loader(name)
+    m = _fit(g, dual=True)
+    assert m.dual_
+    assert relerr(m.X_, g["Xt"]) < 1e-9
+    assert m.γ_ == float(g["gamma"])
+    assert relerr(m.α̂_, g["alpha"]) < TOL
+    assert relerr(m.loo_residuals_, g["loo_residuals"]) < TOL
+    assert relerr(m.loo_std_, g["loo_std"]) < TOL
+    assert relerr(m.residuals_, g["residuals"]) < TOL
+    assert relerr(m.decision_function(g["Xq"]), g["decision_function"]) < TOL
+    assert relerr(m.predict_std(g["Xq"]), g["predict_std"]) < TOL
+    if g["task"] == "clf":
+        assert np.array_equal(m.predict(g["Xq"]), g["predict"])
+
+
+def test_auto_switch_pandas_and_score():
+    import pandas as pd
+    from sklearn.datasets import load_breast_cancer, load_diabetes
+
+    from neo_ls_svm_amd import NeoLSSVM
+
+    X, y = load_diabetes(return_X_y=True, as_frame=True)  # n = 442 -> dual by the reference's n <= 1024 rule
+    m = NeoLSSVM().fit(X, y)
+    assert m.dual_ and m._estimator_type == "regressor"
+    out = m.predict(X)
+    assert isinstance(out, pd.Series) and out.index.equals(X.index)
+    assert isinstance(m.predict_std(X), pd.Series)
+    assert m.score(X, y) > 0.4
+    Xc, yc = load_breast_cancer(return_X_y=True)
+    mc = NeoLSSVM(dual=False).fit(Xc, yc)  # primal, default D = 512
+    assert mc.primal_ and mc._estimator_type == "classifier" and mc.β̂_.shape == (513,)
+    assert mc.score(Xc, yc) > 0.95
+    assert 0.9 < mc.loo_score_ <= 1.0
+
+
+def test_sklearn_check_estimator_report():
+    """sklearn's conformance suite; the reference itself fails 3 version-drift checks."""
+    from sklearn.utils.estimator_checks import check_estimator
+
+    from neo_ls_svm_amd import NeoLSSVM
+
+    for kind in ("regressor", "classifier"):
+        res = check_estimator(NeoLSSVM(estimator_type=kind), on_fail=None)
+        failed = [r for r in res if r["status"] == "failed"]
+        names = sorted(r["check_name"] for r in failed)
+        print(kind, "passed", sum(r["status"] == "passed" for r in res), "failed", names)
+        assert sum(r["status"] == "passed" for r in res) >= 35
+        assert len(failed) <= 6, names

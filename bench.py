@@ -112,32 +112,27 @@ def main():
         args.gpus = world
 
     dist = torch = None
-    if world > 1:
+    if world > 1 or os.environ.get("NLS_BENCH_FORCE_DIST") == "1":
         # torch (and its bundled ROCm) must be loaded BEFORE the HIP library so that both share one runtime.
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         import torch
         import torch.distributed as dist
 
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if world == 1:  # debugging aid: exercise the torch + RCCL plumbing on a single GPU
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import numpy as np
 
     import neo_ls_svm_amd as hp
 
     ctx = hp.Context(local_rank)
-    if world > 1:
+    if dist is not None:
+        from neo_ls_svm_amd.distributed import attach
 
-        class _Buf:  # zero-copy view of the library's device buffer for torch
-            def __init__(self, ptr, count):
-                self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr, False), "version": 2}
-
-        def allreduce(ptr, count):
-            t = torch.as_tensor(_Buf(ptr, count), device=torch.device("cuda", local_rank))
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
-            torch.cuda.synchronize()
-
-        ctx.set_allreduce(allreduce, rank, world)
+        attach(ctx, dist)  # RCCL all-reduce (zero-copy on the library's device buffers) at the three exchange points
 
     n, d, D, G = cfg["n"], cfg["d"], cfg["D"], cfg["G"]
     lo, hi = (n * rank) // world, (n * (rank + 1)) // world
@@ -149,7 +144,7 @@ def main():
     del X
 
     def barrier():
-        if world > 1:
+        if dist is not None:
             dist.barrier()
             torch.cuda.synchronize()
         ctx.synchronize()
@@ -168,7 +163,7 @@ def main():
             stage[k] = stage.get(k, 0.0) + v
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -224,9 +219,9 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
     ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

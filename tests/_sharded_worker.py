@@ -1,0 +1,158 @@
+"""Worker of the world_size-2 tests (launched by the test files with RANK / WORLD_SIZE / MASTER_* set).
+
+mode "cpu": no GPU.  Exercises the product's row_shard + staged all-reduce hook over gloo, and replays the
+            library's three exchange points with the oracle standing in for the HIP stages (test infrastructure).
+mode "gpu": both ranks share GPU 0; the real library runs its sharded path, collectives over gloo.
+Prints "OK <rank>" on success.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path[:0] = [str(ROOT), str(ROOT / "oracle"), str(ROOT / "tests")]
+
+import torch  # noqa: E402  (must precede the HIP library)
+import torch.distributed as dist  # noqa: E402
+
+import numpy as np  # noqa: E402
+
+
+class FakeLib:
+    """Host-memory stand-in for the two memcpy entry points the staged hook uses."""
+
+    @staticmethod
+    def nls_memcpy_d2h(_h, dst, src, nbytes):
+        ctypes.memmove(dst, src, nbytes)
+        return 0
+
+    @staticmethod
+    def nls_memcpy_h2d(_h, dst, src, nbytes):
+        ctypes.memmove(dst, src, nbytes)
+        return 0
+
+
+class FakeCtx:
+    lib, handle, device = FakeLib(), None, 0
+
+    @staticmethod
+    def _check(rc):
+        assert rc == 0
+
+
+def problem(n=1800, d=9, D=64, clf=False):
+    rng = np.random.default_rng(123)
+    X = rng.standard_normal((n, d))
+    w = rng.standard_normal(d) / np.sqrt(d)
+    y = np.where(X @ w > 0, 1.0, -1.0) if clf else np.sin(X @ w) + 0.1 * rng.standard_normal(n)
+    s = rng.uniform(0.2, 2.0, n)
+    import neolssvm_oracle as orc
+
+    B = orc.orf_frequencies(d, D) * 0.4
+    return X, y, s, rng.standard_normal(d) * 0.1, rng.uniform(0.8, 1.2, d), B
+
+
+def run_cpu(rank, world):
+    import neolssvm_oracle as orc
+
+    from neo_ls_svm_amd.distributed import make_allreduce, row_shard
+
+    hook = make_allreduce(FakeCtx(), dist)
+
+    def allreduce(a):  # in place on a float64 (or complex128 viewed as float64) host array
+        v = a.view(np.float64).reshape(-1)
+        hook(v.ctypes.data, v.size)
+
+    # hook data path
+    buf = np.arange(10, dtype=np.float64) * (rank + 1)
+    allreduce(buf)
+    assert np.array_equal(buf, np.arange(10) * sum(range(1, world + 1)))
+
+    for clf in (False, True):
+        X, y, s, shift, scale, B = problem(clf=clf)
+        n, D1 = X.shape[0], B.shape[1] + 1
+        gam = orc.gamma_grid(64)
+        ref = orc.primal_fit_streamed(X, y, s, shift, scale, B, clf, gammas=gam)
+        lo, hi = row_shard(n, rank, world)
+        Xl, yl, sl = X[lo:hi], y[lo:hi], s[lo:hi]
+        # exchange point 1: weight sums and n
+        sums = np.array([sl.sum(), (sl * yl).sum(), float(hi - lo)])
+        allreduce(sums)
+        sn = sl / sums[0]
+        c = 1.0 / (sums[2] * D1)
+        # exchange point 2: A || b
+        phi = orc.feature_map(Xl, shift, scale, B)
+        F = sn[:, None] * phi
+        Ab = np.ascontiguousarray(np.concatenate([F.conj().T @ F, (F.conj().T @ (sn * yl))[:, None]], axis=1))
+        allreduce(Ab)
+        A, b = (Ab[:, :D1] + Ab[:, :D1].conj().T) / 2, Ab[:, D1]
+        lam, Q = np.linalg.eigh(A / c)
+        v = (Q.conj().T @ b) / c
+        P = phi @ Q
+        R = 1.0 / (gam[None, :] + lam[:, None])
+        num = np.ascontiguousarray(np.real(P * v[None, :])) @ R
+        hs = ((P.real**2 + P.imag**2) @ R) / c
+        e = (num - yl[:, None]) / (1 - (sn[:, None] ** 2) * hs)
+        if clf:
+            e = orc.clip_classifier_residuals(e, yl)
+        # exchange point 3: per-gamma error vectors
+        ae = np.abs(e)
+        vec = np.stack([sn @ ae, sn @ (ae >= 1), sn @ np.maximum(0, ae - 1)])
+        allreduce(vec)
+        obj = vec[1] + vec[2] + vec[0] if clf else vec[0]
+        opt = int(np.argmin(obj))
+        assert opt == ref["opt"], (opt, ref["opt"])
+        assert np.max(np.abs(vec[0] - ref["loo_errors_gammas"])) < 1e-10 * np.max(ref["loo_errors_gammas"])
+        assert np.max(np.abs(e[:, opt] - ref["loo_residuals"][lo:hi])) < 1e-9 * np.max(np.abs(ref["loo_residuals"]))
+        import scipy.linalg as sla
+
+        beta = sla.cho_solve(sla.cho_factor(gam[opt] * c * np.eye(D1) + A), b)
+        assert np.max(np.abs(beta - ref["beta"])) < 1e-9 * np.max(np.abs(ref["beta"]))
+
+
+def run_gpu(rank, world):
+    import neo_ls_svm_amd as hp
+    from neo_ls_svm_amd.distributed import attach, row_shard
+
+    ctx = hp.Context(0)
+    attach(ctx, dist)
+    for clf in (False, True):
+        X, y, s, shift, scale, B = problem(n=5000, d=12, D=200, clf=clf)
+        lo, hi = row_shard(X.shape[0], rank, world)
+        r = hp.primal_fit(X[lo:hi], y[lo:hi], s[lo:hi], shift, scale, B, clf, ctx=ctx)
+        A, b = hp.gram(X[lo:hi], y[lo:hi], s[lo:hi], shift, scale, B, ctx=ctx)
+        # single-rank reference on the full rows with a hook-free context
+        solo = hp.Context(0)
+        r1 = hp.primal_fit(X, y, s, shift, scale, B, clf, ctx=solo)
+        A1, b1 = hp.gram(X, y, s, shift, scale, B, ctx=solo)
+        solo.close()
+
+        def rel(a, bb):
+            return float(np.max(np.abs(a - bb)) / np.max(np.abs(bb)))
+
+        assert rel(A, A1) < 1e-12 and rel(b, b1) < 1e-12
+        assert r["opt"] == r1["opt"]
+        assert rel(r["beta"], r1["beta"]) < 1e-8
+        assert rel(r["loo_errors_gammas"], r1["loo_errors_gammas"]) < 1e-10
+        assert rel(r["L"][np.triu_indices(B.shape[1] + 1)], r1["L"][np.triu_indices(B.shape[1] + 1)]) < 1e-9
+        for k in ("loo_residuals", "loo_leverage", "loo_std", "residuals"):
+            assert r[k].shape == (hi - lo,)
+            assert rel(r[k], r1[k][lo:hi]) < 1e-8, k
+        assert abs(r["loo_score"] - r1["loo_score"]) < 1e-10
+    ctx.close()
+
+
+if __name__ == "__main__":
+    mode = sys.argv[1]
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        (run_cpu if mode == "cpu" else run_gpu)(rank, world)
+        dist.barrier()
+        print(f"OK {rank}", flush=True)
+    finally:
+        dist.destroy_process_group()

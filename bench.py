@@ -27,6 +27,8 @@ CONFIGS = {
     "c3": dict(n=1_000_000, d=128, D=4096, G=1024, name="synthetic regression n=1e6 d=128 D=4096 ORF, primal, G=1024"),
     # BASELINE.json configs[1]
     "c2": dict(n=100_000, d=64, D=1024, G=1024, name="synthetic regression n=1e5 d=64 D=1024 ORF, primal, G=1024"),
+    # one row chunk of c3 (profiling: same kernels, same D, 1/4 of the rows)
+    "c3q": dict(n=262_144, d=128, D=4096, G=1024, name="synthetic regression n=262144 d=128 D=4096 ORF, primal, G=1024"),
     # small plumbing configuration for quick checks
     "c0": dict(n=20_000, d=32, D=512, G=1024, name="synthetic regression n=2e4 d=32 D=512 ORF, primal, G=1024"),
 }

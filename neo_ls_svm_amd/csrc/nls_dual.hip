@@ -9,7 +9,7 @@ using namespace nls;
 
 namespace {
 
-constexpr size_t SMEM_REAL_D = 2 * TILE_DOUBLES * sizeof(double);
+constexpr size_t SMEM_REAL_D = 2 * 2 * TILE_DOUBLES * sizeof(double);
 
 template <int EPI>
 int launch_gemm(nls_ctx* ctx, const GemmParams& p, long M, long N) {

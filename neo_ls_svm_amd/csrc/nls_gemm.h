@@ -157,116 +157,198 @@ __device__ __forceinline__ double frag_b(const double* sm, int ks, int nt) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Main loops.  smem must hold 2 (REAL) or 4 (CPLX) tiles of TILE_DOUBLES doubles.
-// Fragments are double-buffered by hand: the ds_reads of K sub-step ks+1 are issued in front of the
-// MFMAs of sub-step ks; the sched_barrier keeps the compiler from hoisting every sub-step's reads to
-// the top of the slice (that costs ~100 VGPRs and pushes the staging registers out to scratch).
+// Main loops.  smem must hold 2 x 2 (REAL) or 2 x 4 (CPLX) tiles of TILE_DOUBLES doubles.
+//
+// Software pipeline of one K slice (4 sub-steps ks of 4 k each), per wave:
+//     ks = 0 : MFMA(ks 0)  interleaved with  ds_read frags(ks 1)
+//     ks = 1 : MFMA(ks 1)  interleaved with  ds_read frags(ks 2), ds_write slice kt+1 -> other LDS buffer,
+//                                            global loads of slice kt+2
+//     ks = 2 : MFMA(ks 2)  interleaved with  ds_read frags(ks 3)
+//     ---- one workgroup barrier: the other buffer is complete, nobody reads this one any more ----
+//     ks = 3 : MFMA(ks 3)  interleaved with  ds_read frags(next slice, ks 0) from the other buffer
+// Every MFMA group has its operands in registers one sub-step ahead, there is ONE barrier per slice, and the
+// loop body is branch free (the last slices re-load a clamped address and store into the idle buffer) so that
+// sched_group_barrier can spread the non-MFMA instructions between the MFMAs: the two waves of a SIMD run in
+// lockstep, so any burst of non-MFMA issue in one is a burst in both and leaves the matrix pipe idle
+// (profiles/r01_ablation.md).  ABL is a diagnostic switch used only by tools/ablate_gemm.
 // ------------------------------------------------------------------------------------------------
-template <class Cfg, bool A_KMAJOR, class ALoad, class BLoad>
+enum { ABL_NO_GLOAD = 1, ABL_NO_LDS_STORE = 2, ABL_NO_BARRIER = 4, ABL_NO_FRAG = 8, ABL_NO_INTERLEAVE = 16 };
+
+// sched_group_barrier masks (LLVM AMDGPU): 0x8 MFMA, 0x20 VMEM read, 0x100 DS read, 0x200 DS write.
+template <int N_MFMA, int MASK, int REPS>
+__device__ __forceinline__ void interleave() {
+#pragma unroll
+  for (int i = 0; i < REPS; ++i) {
+    __builtin_amdgcn_sched_group_barrier(0x008, N_MFMA, 0);
+    __builtin_amdgcn_sched_group_barrier(MASK, 1, 0);
+  }
+}
+
+template <class Cfg, bool A_KMAJOR, class ALoad, class BLoad, int ABL = 0>
 __device__ __forceinline__ void mainloop_real(v4d (&acc)[Cfg::MT][Cfg::NTL], const ALoad& la, const BLoad& lb,
                                               long kbegin, int ktiles, double* smem) {
-  double* smA = smem;
-  double* smB = smem + TILE_DOUBLES;
+  constexpr int BUF = 2 * TILE_DOUBLES;
+  constexpr int KS = BK / 4;
+  constexpr int NMFMA = Cfg::MT * Cfg::NTL, NFRAG = Cfg::MT + Cfg::NTL;
   v2d ra[Cfg::STAGE], rb[Cfg::STAGE];
+  if (ktiles <= 0) return;
   la.fetch(kbegin, ra);
   lb.fetch(kbegin, rb);
+  ALoad::store(smem, ra);
+  BLoad::store(smem + TILE_DOUBLES, rb);
+  la.fetch(kbegin + (ktiles > 1 ? BK : 0), ra);
+  lb.fetch(kbegin + (ktiles > 1 ? BK : 0), rb);
+  __syncthreads();
+  double a[2][Cfg::MT], b[2][Cfg::NTL];
+#pragma unroll
+  for (int i = 0; i < Cfg::MT; ++i) a[0][i] = frag_a<Cfg, A_KMAJOR>(smem, 0, i);
+#pragma unroll
+  for (int i = 0; i < Cfg::NTL; ++i) b[0][i] = frag_b<Cfg>(smem + TILE_DOUBLES, 0, i);
   for (int kt = 0; kt < ktiles; ++kt) {
-    __syncthreads();
-    ALoad::store(smA, ra);
-    BLoad::store(smB, rb);
-    __syncthreads();
-    if (kt + 1 < ktiles) {
-      la.fetch(kbegin + (long)(kt + 1) * BK, ra);
-      lb.fetch(kbegin + (long)(kt + 1) * BK, rb);
-    }
-    double a[2][Cfg::MT], b[2][Cfg::NTL];
+    const double* cur = smem + (kt & 1) * BUF;
+    double* nx = smem + ((kt + 1) & 1) * BUF;
+    const int kt2 = kt + 2 < ktiles ? kt + 2 : ktiles - 1;  // clamped: keeps the body branch free
 #pragma unroll
-    for (int i = 0; i < Cfg::MT; ++i) a[0][i] = frag_a<Cfg, A_KMAJOR>(smA, 0, i);
-#pragma unroll
-    for (int i = 0; i < Cfg::NTL; ++i) b[0][i] = frag_b<Cfg>(smB, 0, i);
-#pragma unroll
-    for (int ks = 0; ks < BK / 4; ++ks) {
-      const int cur = ks & 1, nxt = cur ^ 1;
+    for (int ks = 0; ks < KS; ++ks) {
+      const int c = ks & 1, n = c ^ 1;
       __builtin_amdgcn_sched_barrier(0);
-      if (ks + 1 < BK / 4) {
+      if (!(ABL & ABL_NO_FRAG)) {
+        const double* src = (ks + 1 < KS) ? cur : nx;
+        const int kn = (ks + 1 < KS) ? ks + 1 : 0;
 #pragma unroll
-        for (int i = 0; i < Cfg::MT; ++i) a[nxt][i] = frag_a<Cfg, A_KMAJOR>(smA, ks + 1, i);
+        for (int i = 0; i < Cfg::MT; ++i) a[n][i] = frag_a<Cfg, A_KMAJOR>(src, kn, i);
 #pragma unroll
-        for (int i = 0; i < Cfg::NTL; ++i) b[nxt][i] = frag_b<Cfg>(smB, ks + 1, i);
+        for (int i = 0; i < Cfg::NTL; ++i) b[n][i] = frag_b<Cfg>(src + TILE_DOUBLES, kn, i);
+      }
+      if (ks == 1) {
+        if (!(ABL & ABL_NO_LDS_STORE)) {
+          ALoad::store(nx, ra);
+          BLoad::store(nx + TILE_DOUBLES, rb);
+        }
+        if (!(ABL & ABL_NO_GLOAD)) {
+          la.fetch(kbegin + (long)kt2 * BK, ra);
+          lb.fetch(kbegin + (long)kt2 * BK, rb);
+        }
       }
 #pragma unroll
       for (int mt = 0; mt < Cfg::MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < Cfg::NTL; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cur][mt], b[cur][nt], acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[c][mt], b[c][nt], acc[mt][nt], 0, 0, 0);
+      if (!(ABL & ABL_NO_INTERLEAVE)) {
+        if (ks == 1) {
+          interleave<1, 0x200, 2 * Cfg::STAGE>();
+          interleave<1, 0x020, 2 * Cfg::STAGE>();
+          interleave<1, 0x100, NFRAG>();
+        } else {
+          interleave<(NMFMA / NFRAG > 0 ? NMFMA / NFRAG : 1), 0x100, NFRAG>();
+        }
+      }
+      if (ks == KS - 2 && !(ABL & ABL_NO_BARRIER)) {
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+      }
     }
   }
 }
 
-template <class Cfg, bool A_KMAJOR, class ALoad, class BLoad>
+template <class Cfg, bool A_KMAJOR, class ALoad, class BLoad, int ABL = 0>
 __device__ __forceinline__ void mainloop_cplx(v4d (&accR)[Cfg::MT][Cfg::NTL], v4d (&accI)[Cfg::MT][Cfg::NTL],
                                               const ALoad& lac, const ALoad& las, const BLoad& lbr, const BLoad& lbi,
                                               long kbegin, int ktiles, double* smem) {
-  double* smAc = smem;
-  double* smAs = smem + TILE_DOUBLES;
-  double* smBr = smem + 2 * TILE_DOUBLES;
-  double* smBi = smem + 3 * TILE_DOUBLES;
+  constexpr int BUF = 4 * TILE_DOUBLES;
+  constexpr int KS = BK / 4;
+  constexpr int NMFMA = 4 * Cfg::MT * Cfg::NTL, NFRAG = 2 * (Cfg::MT + Cfg::NTL);
+  static_assert(KS == 4, "fragment parity relies on an even number of sub-steps");
   v2d rac[Cfg::STAGE], ras[Cfg::STAGE], rbr[Cfg::STAGE], rbi[Cfg::STAGE];
+  if (ktiles <= 0) return;
   lac.fetch(kbegin, rac);
   las.fetch(kbegin, ras);
   lbr.fetch(kbegin, rbr);
   lbi.fetch(kbegin, rbi);
+  ALoad::store(smem, rac);
+  ALoad::store(smem + TILE_DOUBLES, ras);
+  BLoad::store(smem + 2 * TILE_DOUBLES, rbr);
+  BLoad::store(smem + 3 * TILE_DOUBLES, rbi);
+  {
+    const long k1 = kbegin + (ktiles > 1 ? BK : 0);
+    lac.fetch(k1, rac);
+    las.fetch(k1, ras);
+    lbr.fetch(k1, rbr);
+    lbi.fetch(k1, rbi);
+  }
+  __syncthreads();
+  double ac[2][Cfg::MT], as[2][Cfg::MT], br[2][Cfg::NTL], bi[2][Cfg::NTL];
+#pragma unroll
+  for (int i = 0; i < Cfg::MT; ++i) {
+    ac[0][i] = frag_a<Cfg, A_KMAJOR>(smem, 0, i);
+    as[0][i] = frag_a<Cfg, A_KMAJOR>(smem + TILE_DOUBLES, 0, i);
+  }
+#pragma unroll
+  for (int i = 0; i < Cfg::NTL; ++i) {
+    br[0][i] = frag_b<Cfg>(smem + 2 * TILE_DOUBLES, 0, i);
+    bi[0][i] = frag_b<Cfg>(smem + 3 * TILE_DOUBLES, 0, i);
+  }
   for (int kt = 0; kt < ktiles; ++kt) {
-    __syncthreads();
-    ALoad::store(smAc, rac);
-    ALoad::store(smAs, ras);
-    BLoad::store(smBr, rbr);
-    BLoad::store(smBi, rbi);
-    __syncthreads();
-    if (kt + 1 < ktiles) {
-      const long k1 = kbegin + (long)(kt + 1) * BK;
-      lac.fetch(k1, rac);
-      las.fetch(k1, ras);
-      lbr.fetch(k1, rbr);
-      lbi.fetch(k1, rbi);
-    }
-    double ac[2][Cfg::MT], as[2][Cfg::MT], br[2][Cfg::NTL], bi[2][Cfg::NTL];
+    const double* cur = smem + (kt & 1) * BUF;
+    double* nx = smem + ((kt + 1) & 1) * BUF;
+    const int kt2 = kt + 2 < ktiles ? kt + 2 : ktiles - 1;  // clamped: keeps the body branch free
 #pragma unroll
-    for (int i = 0; i < Cfg::MT; ++i) {
-      ac[0][i] = frag_a<Cfg, A_KMAJOR>(smAc, 0, i);
-      as[0][i] = frag_a<Cfg, A_KMAJOR>(smAs, 0, i);
-    }
-#pragma unroll
-    for (int i = 0; i < Cfg::NTL; ++i) {
-      br[0][i] = frag_b<Cfg>(smBr, 0, i);
-      bi[0][i] = frag_b<Cfg>(smBi, 0, i);
-    }
-#pragma unroll
-    for (int ks = 0; ks < BK / 4; ++ks) {
-      const int cur = ks & 1, nxt = cur ^ 1;
+    for (int ks = 0; ks < KS; ++ks) {
+      const int c = ks & 1, n = c ^ 1;
       __builtin_amdgcn_sched_barrier(0);
-      if (ks + 1 < BK / 4) {
+      if (!(ABL & ABL_NO_FRAG)) {
+        const double* src = (ks + 1 < KS) ? cur : nx;
+        const int kn = (ks + 1 < KS) ? ks + 1 : 0;
 #pragma unroll
         for (int i = 0; i < Cfg::MT; ++i) {
-          ac[nxt][i] = frag_a<Cfg, A_KMAJOR>(smAc, ks + 1, i);
-          as[nxt][i] = frag_a<Cfg, A_KMAJOR>(smAs, ks + 1, i);
+          ac[n][i] = frag_a<Cfg, A_KMAJOR>(src, kn, i);
+          as[n][i] = frag_a<Cfg, A_KMAJOR>(src + TILE_DOUBLES, kn, i);
         }
 #pragma unroll
         for (int i = 0; i < Cfg::NTL; ++i) {
-          br[nxt][i] = frag_b<Cfg>(smBr, ks + 1, i);
-          bi[nxt][i] = frag_b<Cfg>(smBi, ks + 1, i);
+          br[n][i] = frag_b<Cfg>(src + 2 * TILE_DOUBLES, kn, i);
+          bi[n][i] = frag_b<Cfg>(src + 3 * TILE_DOUBLES, kn, i);
+        }
+      }
+      if (ks == 1) {
+        if (!(ABL & ABL_NO_LDS_STORE)) {
+          ALoad::store(nx, rac);
+          ALoad::store(nx + TILE_DOUBLES, ras);
+          BLoad::store(nx + 2 * TILE_DOUBLES, rbr);
+          BLoad::store(nx + 3 * TILE_DOUBLES, rbi);
+        }
+        if (!(ABL & ABL_NO_GLOAD)) {
+          const long k2 = kbegin + (long)kt2 * BK;
+          lac.fetch(k2, rac);
+          las.fetch(k2, ras);
+          lbr.fetch(k2, rbr);
+          lbi.fetch(k2, rbi);
         }
       }
 #pragma unroll
       for (int mt = 0; mt < Cfg::MT; ++mt) {
-        const double an = -as[cur][mt];
+        const double an = -as[c][mt];
 #pragma unroll
         for (int nt = 0; nt < Cfg::NTL; ++nt) {
-          accR[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[cur][mt], br[cur][nt], accR[mt][nt], 0, 0, 0);
-          accI[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[cur][mt], bi[cur][nt], accI[mt][nt], 0, 0, 0);
-          accR[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(as[cur][mt], bi[cur][nt], accR[mt][nt], 0, 0, 0);
-          accI[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(an, br[cur][nt], accI[mt][nt], 0, 0, 0);
+          accR[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[c][mt], br[c][nt], accR[mt][nt], 0, 0, 0);
+          accI[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[c][mt], bi[c][nt], accI[mt][nt], 0, 0, 0);
+          accR[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(as[c][mt], bi[c][nt], accR[mt][nt], 0, 0, 0);
+          accI[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(an, br[c][nt], accI[mt][nt], 0, 0, 0);
         }
+      }
+      if (!(ABL & ABL_NO_INTERLEAVE)) {
+        if (ks == 1) {
+          interleave<1, 0x200, 4 * Cfg::STAGE>();
+          interleave<1, 0x020, 4 * Cfg::STAGE>();
+          interleave<1, 0x100, NFRAG>();
+        } else {
+          interleave<(NMFMA / NFRAG > 0 ? NMFMA / NFRAG : 1), 0x100, NFRAG>();
+        }
+      }
+      if (ks == KS - 2 && !(ABL & ABL_NO_BARRIER)) {
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
       }
     }
   }

@@ -2,6 +2,7 @@
 // include/neolssvm_hip.h.  Device code lives in nls_gemm.h / nls_kernels.h / nls_dual.h.
 #include "nls_host.h"
 #include "nls_kernels.h"
+#include "nls_dual_kernels.h"
 
 using namespace nls;
 
@@ -46,8 +47,8 @@ static int upload_map(nls_ctx* ctx, const double* shift, const double* scale, co
   return NLS_OK;
 }
 
-constexpr size_t SMEM_REAL = 2 * TILE_DOUBLES * sizeof(double);
-constexpr size_t SMEM_CPLX = 4 * TILE_DOUBLES * sizeof(double);
+constexpr size_t SMEM_REAL = 2 * 2 * TILE_DOUBLES * sizeof(double);  // double-buffered A, B
+constexpr size_t SMEM_CPLX = 2 * 4 * TILE_DOUBLES * sizeof(double);  // double-buffered Ac, As, Br, Bi (144 KiB)
 
 // K1 into split planes for `rows` rows starting at Xchunk.
 static int launch_featuremap_planes(nls_ctx* ctx, const MapParams& mp, const double* Xchunk, long rows, long rows_pad,
@@ -124,6 +125,11 @@ extern "C" int nls_ctx_create(int device, nls_ctx** out) {
   // Opt in to > 64 KiB of dynamic LDS for the complex tile kernels.
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gram), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_CPLX);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_rotate), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_CPLX);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_REAL);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_featuremap<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_REAL);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_featuremap<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_REAL);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<EPI_STORE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_REAL);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<EPI_RBF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_REAL);
   *out = ctx;
   return NLS_OK;
 }

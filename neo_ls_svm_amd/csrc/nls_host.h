@@ -37,6 +37,7 @@ struct nls_ctx {
   nls_allreduce_fn allreduce = nullptr;
   void* allreduce_user = nullptr;
   int rank = 0, world = 1;
+  bool use_4m = false;  // NLS_COMPLEX_4M=1: four-product complex kernels (nls_gemm.h) instead of 3M (nls_gemm3m.h)
   // stage timing
   struct Span {
     hipEvent_t a, b;

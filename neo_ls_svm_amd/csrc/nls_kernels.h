@@ -2,6 +2,7 @@
 // P3 Gram (K2), P5 rotation (K4), P6 sweep (K5), P7 selection, P8/P9 re-solve and LOO sigma.
 #pragma once
 #include "nls_gemm.h"
+#include "nls_gemm3m.h"
 
 namespace nls {
 
@@ -129,6 +130,47 @@ __global__ void __launch_bounds__(Cfg8::NTHREADS, 2)
       }
 }
 
+// 3M variant of K2 (nls_gemm3m.h) writing the same packed layout in 128 x 64 half tiles: half tile
+// h = tj (tj + 1) + tk64 (0 <= tk64 <= 2 tj + 1) is columns (tk64 & 1) * 64 .. +63 of the 128 x 128 tile
+// (tj, tk64 >> 1).  grid.x = nt (nt + 1) * nsplit.
+__global__ void __launch_bounds__(m3::NT3, 1)
+    k_gram3(const double* Fc, const double* Fs, int Kp, long rows_pad, int ntri, long rows_per_split, double* slab) {
+  using namespace m3;
+  extern __shared__ double smem[];
+  const int nhalf = 2 * ntri;  // nt (nt + 1) half tiles
+  const int half = blockIdx.x % nhalf, split = blockIdx.x / nhalf;
+  int tj = (int)((sqrt(4.0 * half + 1.0) - 1.0) * 0.5);
+  while ((tj + 1) * (tj + 2) <= half) ++tj;
+  while (tj * (tj + 1) > half) --tj;
+  const int tk64 = half - tj * (tj + 1);
+  const long r0 = (long)split * rows_per_split;
+  long r1 = r0 + rows_per_split;
+  if (r1 > rows_pad) r1 = rows_pad;
+  v4d S1[MT3][NTL3], S2[MT3][NTL3], S3[MT3][NTL3];
+  zero_acc(S1);
+  zero_acc(S2);
+  zero_acc(S3);
+  if (r1 > r0) {
+    KMajorLoader3<BM3, STAGE_A> lac{Fc, Kp, (long)tj * BM3}, las{Fs, Kp, (long)tj * BM3};
+    KMajorLoader3<BN3, STAGE_B> lbr{Fc, Kp, (long)tk64 * BN3}, lbi{Fs, Kp, (long)tk64 * BN3};
+    mainloop_3m<true>(S1, S2, S3, lac, las, lbr, lbi, r0, (int)((r1 - r0) / BK), smem);
+  }
+  const long tile128 = (long)tj * (tj + 1) / 2 + (tk64 >> 1);
+  double* outR = slab + ((long)split * ntri + tile128) * (2L * BM * BN) + (tk64 & 1) * BN3;
+  double* outI = outR + BM * BN;
+#pragma unroll
+  for (int mt = 0; mt < MT3; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NTL3; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int o = acc_row3(mt, r) * BN + acc_col3(nt);
+        const double s1 = S1[mt][nt][r], s2 = S2[mt][nt][r];
+        outR[o] = s1 + s2;                     // Ac Br + As Bi
+        outI[o] = (S3[mt][nt][r] - s1) + s2;   // Ac Bi - As Br
+      }
+}
+
 // acc[tile] += sum_split slab[split][tile], fixed order (bit-reproducible).
 __global__ void k_gram_reduce(const double* slab, int nsplit, long tile_elems_total, double* acc) {
   const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
@@ -246,6 +288,38 @@ __global__ void __launch_bounds__(Cfg8::NTHREADS, 2)
       for (int r = 0; r < 4; ++r) {
         const long row = row0 + C::acc_row(mt, r);
         const double pr = accR[mt][nt][r], pi = accI[mt][nt][r];
+        U[row * Np + col] = pr * wr - pi * wi;
+        Gm[row * Np + col] = pr * pr + pi * pi;
+      }
+  }
+}
+
+// 3M variant of K4 (nls_gemm3m.h): 128-row x 64-column tiles.  grid = (Np / 64, rows_pad / 128).
+__global__ void __launch_bounds__(m3::NT3, 1)
+    k_rotate3(const double* Fc, const double* Fs, int Kp, const double* Qr, const double* Qi, int Np, const double* vr,
+              const double* vi, double* U, double* Gm) {
+  using namespace m3;
+  extern __shared__ double smem[];
+  const long row0 = (long)blockIdx.y * BM3;
+  const long col0 = (long)blockIdx.x * BN3;
+  v4d S1[MT3][NTL3], S2[MT3][NTL3], S3[MT3][NTL3];
+  zero_acc(S1);
+  zero_acc(S2);
+  zero_acc(S3);
+  MMajorLoader3 lac{Fc, Kp, row0}, las{Fs, Kp, row0};
+  KMajorLoader3<BN3, STAGE_B> lbr{Qr, Np, col0}, lbi{Qi, Np, col0};
+  mainloop_3m<false>(S1, S2, S3, lac, las, lbr, lbi, 0, Kp / BK, smem);
+#pragma unroll
+  for (int nt = 0; nt < NTL3; ++nt) {
+    const long col = col0 + acc_col3(nt);
+    const double wr = vr[col], wi = vi[col];
+#pragma unroll
+    for (int mt = 0; mt < MT3; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long row = row0 + acc_row3(mt, r);
+        const double s1 = S1[mt][nt][r], s2 = S2[mt][nt][r];
+        const double pr = s1 + s2, pi = (S3[mt][nt][r] - s1) + s2;
         U[row * Np + col] = pr * wr - pi * wi;
         Gm[row * Np + col] = pr * pr + pi * pi;
       }

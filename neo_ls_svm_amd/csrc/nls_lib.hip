@@ -117,6 +117,7 @@ extern "C" int nls_ctx_create(int device, nls_ctx** out) {
     return rc;
   }
   ctx->hbm_bytes = prop.totalGlobalMem;
+  if (const char* e4 = std::getenv("NLS_COMPLEX_4M")) ctx->use_4m = e4[0] == '1';
   ctx->cus = prop.multiProcessorCount;
   if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess)
     return bail("hipStreamCreate", hipGetErrorString(e));
@@ -125,6 +126,8 @@ extern "C" int nls_ctx_create(int device, nls_ctx** out) {
   // Opt in to > 64 KiB of dynamic LDS for the complex tile kernels.
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gram), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_CPLX);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_rotate), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_CPLX);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gram3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)m3::SMEM3);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_rotate3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)m3::SMEM3);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_REAL);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_featuremap<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_REAL);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_featuremap<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_REAL);
@@ -344,8 +347,12 @@ static int primal_gram_phase(nls_ctx* ctx, PrimalState& st, double* timings) {
       SpanGuard g(ctx, NLS_T_GRAM);
       const long rps = round_up((rows_pad + nsplit - 1) / nsplit, BK);
       const long ns = (rows_pad + rps - 1) / rps;
-      hipLaunchKernelGGL(k_gram, dim3((unsigned)(st.ntri * ns)), dim3(Cfg8::NTHREADS), SMEM_CPLX, ctx->stream, st.Fc, st.Fs, mp.Kp,
-                         rows_pad, st.ntri, rps, slab);
+      if (ctx->use_4m)
+        hipLaunchKernelGGL(k_gram, dim3((unsigned)(st.ntri * ns)), dim3(Cfg8::NTHREADS), SMEM_CPLX, ctx->stream, st.Fc, st.Fs, mp.Kp,
+                           rows_pad, st.ntri, rps, slab);
+      else
+        hipLaunchKernelGGL(k_gram3, dim3((unsigned)(2 * st.ntri * ns)), dim3(m3::NT3), m3::SMEM3, ctx->stream, st.Fc, st.Fs, mp.Kp,
+                           rows_pad, st.ntri, rps, slab);
       HIPCHK(ctx, hipGetLastError());
       hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)((tile_elems_total + 255) / 256)), dim3(256), 0, ctx->stream, slab,
                          (int)ns, (long)tile_elems_total, st.gacc);
@@ -468,8 +475,12 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
     }
     {
       SpanGuard g(ctx, NLS_T_ROTATE);
-      hipLaunchKernelGGL(k_rotate, dim3((unsigned)(Np / BN), (unsigned)(rows_pad / BM)), dim3(Cfg8::NTHREADS), SMEM_CPLX, ctx->stream, st.Fc,
-                         st.Fs, Kp, Qr, Qi, Np, vr, vi, U, Gm);
+      if (ctx->use_4m)
+        hipLaunchKernelGGL(k_rotate, dim3((unsigned)(Np / BN), (unsigned)(rows_pad / BM)), dim3(Cfg8::NTHREADS), SMEM_CPLX, ctx->stream,
+                           st.Fc, st.Fs, Kp, Qr, Qi, Np, vr, vi, U, Gm);
+      else
+        hipLaunchKernelGGL(k_rotate3, dim3((unsigned)(Np / m3::BN3), (unsigned)(rows_pad / BM)), dim3(m3::NT3), m3::SMEM3, ctx->stream,
+                           st.Fc, st.Fs, Kp, Qr, Qi, Np, vr, vi, U, Gm);
       HIPCHK(ctx, hipGetLastError());
       tm[NLS_T_ROTATE_LAUNCHES] += 1;
       tm[NLS_T_ROTATE_FLOPS] += 8.0 * rows * (double)D1 * D1;
@@ -692,8 +703,12 @@ extern "C" int nls_primal_predict(nls_ctx* ctx, const double* X, int64_t m, int 
       HIPCHK(ctx, hipGetLastError());
     }
     if (sigma) {
-      hipLaunchKernelGGL(k_rotate, dim3((unsigned)(Np / BN), (unsigned)(rows_pad / BM)), dim3(Cfg8::NTHREADS), SMEM_CPLX, ctx->stream, Fc, Fs, Kp,
-                         Qr, Qi, Np, vr, vi, U, Gm);
+      if (ctx->use_4m)
+        hipLaunchKernelGGL(k_rotate, dim3((unsigned)(Np / BN), (unsigned)(rows_pad / BM)), dim3(Cfg8::NTHREADS), SMEM_CPLX, ctx->stream, Fc, Fs,
+                           Kp, Qr, Qi, Np, vr, vi, U, Gm);
+      else
+        hipLaunchKernelGGL(k_rotate3, dim3((unsigned)(Np / m3::BN3), (unsigned)(rows_pad / BM)), dim3(m3::NT3), m3::SMEM3, ctx->stream, Fc, Fs,
+                           Kp, Qr, Qi, Np, vr, vi, U, Gm);
       hipLaunchKernelGGL(k_rowsum_sqrt, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, Gm, Np, rows, dsig + r0);
       HIPCHK(ctx, hipGetLastError());
     }

@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <vector>
 #include "nls_gemm.h"
+#include "nls_gemm3m.h"
 using namespace nls;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP %s line %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
 
@@ -32,6 +33,45 @@ __global__ void __launch_bounds__(Cfg8::NTHREADS, 2) k_abl(const double* Fc, con
 #pragma unroll
       for (int r = 0; r < 4; ++r) s += accR[mt][nt][r] + accI[mt][nt][r];
   out[(long)blockIdx.x * C::NTHREADS + threadIdx.x] = s;
+}
+
+template <int FLAGS, bool A_KMAJOR>
+__global__ void __launch_bounds__(m3::NT3, 1) k_abl3(const double* Fc, const double* Fs, int Kp, int ktiles, double* out) {
+  using namespace m3;
+  extern __shared__ double smem[];
+  v4d S1[MT3][NTL3], S2[MT3][NTL3], S3[MT3][NTL3];
+  zero_acc(S1); zero_acc(S2); zero_acc(S3);
+  const long col0 = (long)(blockIdx.x % (Kp / BN3)) * BN3;
+  const long colA = (long)((blockIdx.x / 7) % (Kp / BM3)) * BM3;
+  using AL = typename std::conditional<A_KMAJOR, KMajorLoader3<BM3, STAGE_A>, MMajorLoader3>::type;
+  AL lac{Fc, Kp, colA}, las{Fs, Kp, colA};
+  KMajorLoader3<BN3, STAGE_B> lbr{Fc, Kp, col0}, lbi{Fs, Kp, col0};
+  mainloop_3m<A_KMAJOR, AL, FLAGS>(S1, S2, S3, lac, las, lbr, lbi, 0, ktiles, smem);
+  double s = 0;
+#pragma unroll
+  for (int mt = 0; mt < MT3; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NTL3; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s += S1[mt][nt][r] + S2[mt][nt][r] + S3[mt][nt][r];
+  out[(long)blockIdx.x * NT3 + threadIdx.x] = s;
+}
+
+template <int FLAGS, bool AK>
+void run3(const char* name, const double* Fc, const double* Fs, int Kp, int ktiles, int blocks, double* out) {
+  const size_t smem = m3::SMEM3;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_abl3<FLAGS, AK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  float best = 1e30f;
+  for (int rep = 0; rep < 3; ++rep) {
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL((k_abl3<FLAGS, AK>), dim3(blocks), dim3(m3::NT3), smem, 0, Fc, Fs, Kp, ktiles, out);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best = ms < best ? ms : best;
+  }
+  double flops4m = (double)blocks * ktiles * 16.0 * 128 * 64 * 8;  // 4M-equivalent (algorithmic) flops
+  double cyc = best * 1e-3 * 2.39e9 / ktiles / ((blocks + 255) / 256);
+  printf("%-34s %8.2f ms  %6.2f TFLOP/s (4M-equivalent)  %7.0f cycles/slice (ideal 6144)\n", name, best, flops4m / best / 1e9, cyc);
 }
 
 template <int FLAGS, bool AK>
@@ -61,6 +101,7 @@ int main() {
     size_t cnt = std::min(h.size(), (size_t)rows * Kp - off);
     CK(hipMemcpy(Fc + off, h.data(), cnt * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(Fs + off, h.data() + 7, (cnt - 7) * 8, hipMemcpyHostToDevice));
   }
+  double* out2; CK(hipMalloc(&out2, (size_t)4096 * 256 * 8));
   printf("gram-like (k-major A and B), 2048 blocks x 2048 slices, ideal = 16384 cycles/slice\n");
   run<0, true>("full", Fc, Fs, Kp, ktiles, blocks, out);
   run<NO_GLOAD, true>("no global loads", Fc, Fs, Kp, ktiles, blocks, out);
@@ -73,5 +114,15 @@ int main() {
   run<0, false>("full", Fc, Fs, Kp, 264, 2048, out);
   run<NO_GLOAD, false>("no global loads", Fc, Fs, Kp, 264, 2048, out);
   run<NO_GLOAD | NO_LDS_STORE | NO_BARRIER, false>("no gload/LDS store/barrier", Fc, Fs, Kp, 264, 2048, out);
+  printf("3M engine, 128x64 tile, 1 wave/SIMD: gram-like\n");
+  run3<0, true>("3M full", Fc, Fs, Kp, ktiles, 4096, out2);
+  run3<NO_GLOAD, true>("3M no global loads", Fc, Fs, Kp, ktiles, 4096, out2);
+  run3<NO_GLOAD | NO_LDS_STORE, true>("3M no gload, no LDS store", Fc, Fs, Kp, ktiles, 4096, out2);
+  run3<NO_GLOAD | NO_LDS_STORE | NO_BARRIER, true>("3M ... and no barrier", Fc, Fs, Kp, ktiles, 4096, out2);
+  run3<NO_GLOAD | NO_LDS_STORE | NO_BARRIER | NO_FRAG, true>("3M MFMA only", Fc, Fs, Kp, ktiles, 4096, out2);
+  run3<ABL_NO_INTERLEAVE, true>("3M full, no sched_group_barrier", Fc, Fs, Kp, ktiles, 4096, out2);
+  printf("3M rotate-like (m-major A)\n");
+  run3<0, false>("3M full", Fc, Fs, Kp, 264, 4096, out2);
+  run3<NO_GLOAD, false>("3M no global loads", Fc, Fs, Kp, 264, 4096, out2);
   return 0;
 }

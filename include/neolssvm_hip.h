@@ -8,6 +8,7 @@
  *   nls_featuremap          RandomFourierFeatures.transform              _feature_maps.py:153-203
  *                           (AffineFeatureMap.transform inside it)       _affine_feature_map.py:72-92
  *   nls_gram_only           first product of _optimize_beta_gamma        _neo_ls_svm.py:110-114,127
+ *   nls_rotate_only         leverage / numerator products of the same    _neo_ls_svm.py:128-143
  *   nls_primal_fit          NeoLSSVM._optimize_beta_gamma(phi, y, s, C)  _neo_ls_svm.py:77-189
  *                           fused with the transform that feeds it       _neo_ls_svm.py:386,401-402
  *   nls_primal_predict      decision_function / predict_std (primal)     _neo_ls_svm.py:661-665, 464-469,477
@@ -92,6 +93,13 @@ int nls_featuremap(nls_ctx* ctx, const double* X, int64_t n, int d, const double
 int nls_gram_only(nls_ctx* ctx, const double* X, const double* y, const double* s, int64_t n, int d,
                   const double* shift, const double* scale, const double* B, int D, double* A,
                   double* b);
+
+/* ---- K4: rotation with fused epilogue (test / bench hook) ---------------------------------------
+ * P = phi(X) Q;  U = Re(P o v^T),  Gm = |P|^2  (the two n x (D+1) real matrices the gamma sweep contracts,
+ * _neo_ls_svm.py:128-143 in the one-rotation form).  Q: (D+1) x (D+1) complex128 row-major, v: (D+1)
+ * complex128, both host.  U, Gm: n x (D+1) float64 host outputs, either may be NULL (timing only). */
+int nls_rotate_only(nls_ctx* ctx, const double* X, int64_t n, int d, const double* shift, const double* scale,
+                    const double* B, int D, const double* Q, const double* v, double* U, double* Gm);
 
 /* ---- primal fit ------------------------------------------------------------------------------- */
 typedef struct nls_primal_fit_args {

@@ -14,6 +14,7 @@ from .hotpath import (  # noqa: F401
     orf_frequencies,
     primal_fit,
     primal_predict,
+    rotate,
 )
 
 from .estimator import AffineSeparator, NeoLSSVM, OrthogonalRandomFourierFeatures  # noqa: E402,F401

@@ -37,6 +37,10 @@ struct nls_ctx {
   nls_allreduce_fn allreduce = nullptr;
   void* allreduce_user = nullptr;
   int rank = 0, world = 1;
+  // XCD patch shape of k_rotate3 (NLS_ROT_PATCH=RxC; 0x0 = plain order, the default: patches raise the L2 hit rate
+  // from 0.57 to 0.78 and halve the fabric traffic but run 1-4 % slower, profiles/r01_pmc_summary.md)
+  int rot_pr = 0, rot_pc = 0;
+  bool gram_patches = false;
   bool use_4m = false;  // NLS_COMPLEX_4M=1: four-product complex kernels (nls_gemm.h) instead of 3M (nls_gemm3m.h)
   // stage timing
   struct Span {

@@ -130,19 +130,59 @@ __global__ void __launch_bounds__(Cfg8::NTHREADS, 2)
       }
 }
 
-// 3M variant of K2 (nls_gemm3m.h) writing the same packed layout in 128 x 64 half tiles: half tile
-// h = tj (tj + 1) + tk64 (0 <= tk64 <= 2 tj + 1) is columns (tk64 & 1) * 64 .. +63 of the 128 x 128 tile
-// (tj, tk64 >> 1).  grid.x = nt (nt + 1) * nsplit.
+// XCD-aware tile order shared by the 3M kernels.  Workgroups are dealt round-robin over the 8 XCDs (block b runs
+// on XCD b % 8, each with its own 4 MiB L2), and 32 of them are resident per XCD.  Block b is therefore mapped to
+// patch (b / 8) / 32 of XCD b % 8 and to position (b / 8) % 32 inside that patch of PR x PC tiles: the 32 workgroups
+// that share an L2 start together on one compact patch and walk K in phase, so every A panel slice is fetched once
+// for PC tiles and every B panel slice once for PR tiles (measured on k_rotate3: L2 hit rate 0.57 -> see
+// profiles/r01_pmc_summary.md; speed only, never correctness - a different placement just hits less).
+// Returns false for the padding blocks of partial patches.
+__device__ __forceinline__ bool xcd_patch_tile_rt(int PR, int PC, long b, long tiles_r, long tiles_c, long& tr, long& tc) {
+  const long xcd = b & 7, slot = b >> 3;
+  const long patch = (slot / (PR * PC)) * 8 + xcd, within = slot % (PR * PC);
+  const long patches_c = (tiles_c + PC - 1) / PC;
+  tr = (patch / patches_c) * PR + within / PC;
+  tc = (patch % patches_c) * PC + within % PC;
+  return tr < tiles_r && tc < tiles_c;
+}
+template <int PR, int PC>
+__device__ __forceinline__ bool xcd_patch_tile(long b, long tiles_r, long tiles_c, long& tr, long& tc) {
+  const long xcd = b & 7, slot = b >> 3;
+  const long patch = (slot / (PR * PC)) * 8 + xcd, within = slot % (PR * PC);
+  const long patches_c = (tiles_c + PC - 1) / PC;
+  tr = (patch / patches_c) * PR + within / PC;
+  tc = (patch % patches_c) * PC + within % PC;
+  return tr < tiles_r && tc < tiles_c;
+}
+static inline long xcd_patch_grid(long tiles_r, long tiles_c, int PR, int PC) {
+  const long patches = ((tiles_r + PR - 1) / PR) * ((tiles_c + PC - 1) / PC);
+  return ((patches + 7) / 8) * 8 * PR * PC;
+}
+
+// 3M variant of K2 (nls_gemm3m.h) writing the same packed layout in 128 x 64 half tiles: half tile (tj, tk64),
+// 0 <= tk64 <= 2 tj + 1, is columns (tk64 & 1) * 64 .. +63 of the 128 x 128 tile (tj, tk64 >> 1).  The nt x 2 nt
+// grid.x = blocks_per_split * nsplit with blocks_per_split = nt (nt + 1) (plain order, default) or
+// xcd_patch_grid(nt, 2 nt, 4, 8) (XCD patches: L2 hit rate 0.58 -> 0.72 but unbalanced XCDs, +11 % time; kept as a knob).
 __global__ void __launch_bounds__(m3::NT3, 1)
-    k_gram3(const double* Fc, const double* Fs, int Kp, long rows_pad, int ntri, long rows_per_split, double* slab) {
+    k_gram3(const double* Fc, const double* Fs, int Kp, long rows_pad, int ntri, long rows_per_split, double* slab, int nt,
+            long blocks_per_split) {
   using namespace m3;
   extern __shared__ double smem[];
-  const int nhalf = 2 * ntri;  // nt (nt + 1) half tiles
-  const int half = blockIdx.x % nhalf, split = blockIdx.x / nhalf;
-  int tj = (int)((sqrt(4.0 * half + 1.0) - 1.0) * 0.5);
-  while ((tj + 1) * (tj + 2) <= half) ++tj;
-  while (tj * (tj + 1) > half) --tj;
-  const int tk64 = half - tj * (tj + 1);
+  const long split = blockIdx.x / blocks_per_split;
+  int tj, tk64;
+  if (blocks_per_split == 2L * ntri) {  // plain order: half tile h = tj (tj + 1) + tk64
+    const int half = (int)(blockIdx.x % blocks_per_split);
+    tj = (int)((sqrt(4.0 * half + 1.0) - 1.0) * 0.5);
+    while ((tj + 1) * (tj + 2) <= half) ++tj;
+    while (tj * (tj + 1) > half) --tj;
+    tk64 = half - tj * (tj + 1);
+  } else {  // XCD patches of 4 x 8 over the nt x 2 nt rectangle; blocks above the diagonal exit at once
+    long tjl, tkl;
+    if (!xcd_patch_tile<4, 8>(blockIdx.x % blocks_per_split, nt, 2L * nt, tjl, tkl)) return;
+    if (tkl > 2 * tjl + 1) return;
+    tj = (int)tjl;
+    tk64 = (int)tkl;
+  }
   const long r0 = (long)split * rows_per_split;
   long r1 = r0 + rows_per_split;
   if (r1 > rows_pad) r1 = rows_pad;
@@ -294,14 +334,23 @@ __global__ void __launch_bounds__(Cfg8::NTHREADS, 2)
   }
 }
 
-// 3M variant of K4 (nls_gemm3m.h): 128-row x 64-column tiles.  grid = (Np / 64, rows_pad / 128).
+// 3M variant of K4 (nls_gemm3m.h): 128-row x 64-column tiles in 4 x 8 patches per XCD.
+// grid.x = xcd_patch_grid(rows_pad / 128, Np / 64, 4, 8).
 __global__ void __launch_bounds__(m3::NT3, 1)
     k_rotate3(const double* Fc, const double* Fs, int Kp, const double* Qr, const double* Qi, int Np, const double* vr,
-              const double* vi, double* U, double* Gm) {
+              const double* vi, double* U, double* Gm, long tiles_r, int PR, int PC) {
   using namespace m3;
   extern __shared__ double smem[];
-  const long row0 = (long)blockIdx.y * BM3;
-  const long col0 = (long)blockIdx.x * BN3;
+  long tr, tc;
+  if (PR > 0) {
+    if (!xcd_patch_tile_rt(PR, PC, blockIdx.x, tiles_r, Np / BN3, tr, tc)) return;
+  } else {  // plain order: column tile fastest
+    tc = blockIdx.x % (Np / BN3);
+    tr = blockIdx.x / (Np / BN3);
+    if (tr >= tiles_r) return;
+  }
+  const long row0 = tr * BM3;
+  const long col0 = tc * BN3;
   v4d S1[MT3][NTL3], S2[MT3][NTL3], S3[MT3][NTL3];
   zero_acc(S1);
   zero_acc(S2);

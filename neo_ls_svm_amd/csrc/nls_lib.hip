@@ -47,6 +47,10 @@ static int upload_map(nls_ctx* ctx, const double* shift, const double* scale, co
   return NLS_OK;
 }
 
+static long rot_grid(nls_ctx* ctx, long tiles_r, long tiles_c) {
+  return ctx->rot_pr > 0 ? xcd_patch_grid(tiles_r, tiles_c, ctx->rot_pr, ctx->rot_pc) : tiles_r * tiles_c;
+}
+
 constexpr size_t SMEM_REAL = 2 * 2 * TILE_DOUBLES * sizeof(double);  // double-buffered A, B
 constexpr size_t SMEM_CPLX = 2 * 4 * TILE_DOUBLES * sizeof(double);  // double-buffered Ac, As, Br, Bi (144 KiB)
 
@@ -118,6 +122,8 @@ extern "C" int nls_ctx_create(int device, nls_ctx** out) {
   }
   ctx->hbm_bytes = prop.totalGlobalMem;
   if (const char* e4 = std::getenv("NLS_COMPLEX_4M")) ctx->use_4m = e4[0] == '1';
+  if (const char* ep = std::getenv("NLS_ROT_PATCH")) std::sscanf(ep, "%dx%d", &ctx->rot_pr, &ctx->rot_pc);
+  if (const char* eg = std::getenv("NLS_GRAM_PATCH")) ctx->gram_patches = eg[0] == '1';
   ctx->cus = prop.multiProcessorCount;
   if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess)
     return bail("hipStreamCreate", hipGetErrorString(e));
@@ -350,9 +356,11 @@ static int primal_gram_phase(nls_ctx* ctx, PrimalState& st, double* timings) {
       if (ctx->use_4m)
         hipLaunchKernelGGL(k_gram, dim3((unsigned)(st.ntri * ns)), dim3(Cfg8::NTHREADS), SMEM_CPLX, ctx->stream, st.Fc, st.Fs, mp.Kp,
                            rows_pad, st.ntri, rps, slab);
-      else
-        hipLaunchKernelGGL(k_gram3, dim3((unsigned)(2 * st.ntri * ns)), dim3(m3::NT3), m3::SMEM3, ctx->stream, st.Fc, st.Fs, mp.Kp,
-                           rows_pad, st.ntri, rps, slab);
+      else {
+        const long bps = ctx->gram_patches ? xcd_patch_grid(st.nt, 2L * st.nt, 4, 8) : 2L * st.ntri;
+        hipLaunchKernelGGL(k_gram3, dim3((unsigned)(bps * ns)), dim3(m3::NT3), m3::SMEM3, ctx->stream, st.Fc, st.Fs, mp.Kp, rows_pad,
+                           st.ntri, rps, slab, st.nt, bps);
+      }
       HIPCHK(ctx, hipGetLastError());
       hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)((tile_elems_total + 255) / 256)), dim3(256), 0, ctx->stream, slab,
                          (int)ns, (long)tile_elems_total, st.gacc);
@@ -393,6 +401,78 @@ extern "C" int nls_gram_only(nls_ctx* ctx, const double* X, const double* y, con
   if (A) HIPCHK(ctx, hipMemcpyAsync(A, Arm, sizeof(double2) * (size_t)D1 * D1, hipMemcpyDeviceToHost, ctx->stream));
   if (b) HIPCHK(ctx, hipMemcpyAsync(b, db, sizeof(double2) * (size_t)D1, hipMemcpyDeviceToHost, ctx->stream));
   NLSCHK(spans_collect(ctx, nullptr));
+  return NLS_OK;
+}
+
+
+// Row-major complex (D1 x D1, host layout) -> B-operand planes [Kp x Np], zero padded.
+__global__ void k_build_planes_rm(const double2* Qrm, int D1, int Kp, int Np, double* Qr, double* Qi) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.y;
+  if (k >= Np) return;
+  double2 v = make_double2(0.0, 0.0);
+  if (i < D1 && k < D1) v = Qrm[(long)i * D1 + k];
+  Qr[(long)i * Np + k] = v.x;
+  Qi[(long)i * Np + k] = v.y;
+}
+// out[i][j] = in[i][j] for j < cols (ld_in -> cols contiguous)
+__global__ void k_compact_rows(const double* in, long ld_in, long rows, int cols, double* out) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const long i = blockIdx.y;
+  if (j < cols && i < rows) out[i * cols + j] = in[i * ld_in + j];
+}
+
+extern "C" int nls_rotate_only(nls_ctx* ctx, const double* X, int64_t n, int d, const double* shift, const double* scale,
+                               const double* B, int D, const double* Q, const double* v, double* Uout, double* Gmout) {
+  if (!ctx) return NLS_ERR_ARG;
+  if (!X || !Q || !v || n < 1) return fail(ctx, NLS_ERR_ARG, "X/Q/v NULL or n < 1");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  MapParams mp;
+  NLSCHK(upload_map(ctx, shift, scale, B, d, D, &mp));
+  const int D1 = mp.D1, Kp = mp.Kp, Np = mp.Np;
+  const double* dX = nullptr;
+  NLSCHK(resident(ctx, "in.X", X, (size_t)n * d, &dX));
+  const long rc = pick_row_chunk(ctx, n, mp, 4ull * D1 * D1 * 16);
+  double *Fc = nullptr, *Fs = nullptr, *Qr = nullptr, *Qi = nullptr, *vr = nullptr, *vi = nullptr, *U = nullptr, *Gm = nullptr, *cmp = nullptr;
+  double2 *dQ = nullptr, *dv = nullptr;
+  NLSCHK(ws_get_t(ctx, "chunk.Fc", (size_t)rc * Kp, &Fc));
+  NLSCHK(ws_get_t(ctx, "chunk.Fs", (size_t)rc * Kp, &Fs));
+  NLSCHK(ws_get_t(ctx, "evd.Q", (size_t)D1 * D1, &dQ));
+  NLSCHK(ws_get_t(ctx, "chol.beta", (size_t)D1, &dv));
+  NLSCHK(ws_get_t(ctx, "rot.Qr", (size_t)Kp * Np, &Qr));
+  NLSCHK(ws_get_t(ctx, "rot.Qi", (size_t)Kp * Np, &Qi));
+  NLSCHK(ws_get_t(ctx, "rot.vr", (size_t)Np, &vr));
+  NLSCHK(ws_get_t(ctx, "rot.vi", (size_t)Np, &vi));
+  NLSCHK(ws_get_t(ctx, "chunk.U", (size_t)rc * Np, &U));
+  NLSCHK(ws_get_t(ctx, "chunk.Gm", (size_t)rc * Np, &Gm));
+  if (Uout || Gmout) NLSCHK(ws_get_t(ctx, "rot.compact", (size_t)rc * D1, &cmp));
+  HIPCHK(ctx, hipMemcpyAsync(dQ, Q, sizeof(double2) * (size_t)D1 * D1, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(dv, v, sizeof(double2) * D1, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_build_planes_rm, dim3((unsigned)((Np + 255) / 256), (unsigned)Kp), dim3(256), 0, ctx->stream, dQ, D1, Kp, Np, Qr, Qi);
+  hipLaunchKernelGGL(k_split_vec, dim3((unsigned)((Np + 255) / 256)), dim3(256), 0, ctx->stream, dv, D1, Np, vr, vi);
+  HIPCHK(ctx, hipGetLastError());
+  for (long r0 = 0; r0 < n; r0 += rc) {
+    const long rows = std::min<long>(rc, n - r0);
+    const long rows_pad = round_up(rows, BM);
+    NLSCHK(launch_featuremap_planes(ctx, mp, dX + r0 * d, rows, rows_pad, nullptr, nullptr, Fc, Fs));
+    if (ctx->use_4m)
+      hipLaunchKernelGGL(k_rotate, dim3((unsigned)(Np / BN), (unsigned)(rows_pad / BM)), dim3(Cfg8::NTHREADS), SMEM_CPLX, ctx->stream, Fc, Fs,
+                         Kp, Qr, Qi, Np, vr, vi, U, Gm);
+    else
+      hipLaunchKernelGGL(k_rotate3, dim3((unsigned)rot_grid(ctx, rows_pad / BM, Np / m3::BN3)), dim3(m3::NT3), m3::SMEM3, ctx->stream, Fc,
+                         Fs, Kp, Qr, Qi, Np, vr, vi, U, Gm, rows_pad / BM, ctx->rot_pr, ctx->rot_pc);
+    HIPCHK(ctx, hipGetLastError());
+    for (int which = 0; which < 2; ++which) {
+      double* dst = which ? Gmout : Uout;
+      if (!dst) continue;
+      hipLaunchKernelGGL(k_compact_rows, dim3((unsigned)((D1 + 255) / 256), (unsigned)rows), dim3(256), 0, ctx->stream, which ? Gm : U, (long)Np,
+                         rows, D1, cmp);
+      HIPCHK(ctx, hipGetLastError());
+      HIPCHK(ctx, hipMemcpyAsync(dst + r0 * D1, cmp, sizeof(double) * (size_t)rows * D1, hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+  }
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return NLS_OK;
 }
 
@@ -479,8 +559,8 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
         hipLaunchKernelGGL(k_rotate, dim3((unsigned)(Np / BN), (unsigned)(rows_pad / BM)), dim3(Cfg8::NTHREADS), SMEM_CPLX, ctx->stream,
                            st.Fc, st.Fs, Kp, Qr, Qi, Np, vr, vi, U, Gm);
       else
-        hipLaunchKernelGGL(k_rotate3, dim3((unsigned)(Np / m3::BN3), (unsigned)(rows_pad / BM)), dim3(m3::NT3), m3::SMEM3, ctx->stream,
-                           st.Fc, st.Fs, Kp, Qr, Qi, Np, vr, vi, U, Gm);
+        hipLaunchKernelGGL(k_rotate3, dim3((unsigned)rot_grid(ctx, rows_pad / BM, Np / m3::BN3)), dim3(m3::NT3), m3::SMEM3,
+                           ctx->stream, st.Fc, st.Fs, Kp, Qr, Qi, Np, vr, vi, U, Gm, rows_pad / BM, ctx->rot_pr, ctx->rot_pc);
       HIPCHK(ctx, hipGetLastError());
       tm[NLS_T_ROTATE_LAUNCHES] += 1;
       tm[NLS_T_ROTATE_FLOPS] += 8.0 * rows * (double)D1 * D1;
@@ -707,8 +787,8 @@ extern "C" int nls_primal_predict(nls_ctx* ctx, const double* X, int64_t m, int 
         hipLaunchKernelGGL(k_rotate, dim3((unsigned)(Np / BN), (unsigned)(rows_pad / BM)), dim3(Cfg8::NTHREADS), SMEM_CPLX, ctx->stream, Fc, Fs,
                            Kp, Qr, Qi, Np, vr, vi, U, Gm);
       else
-        hipLaunchKernelGGL(k_rotate3, dim3((unsigned)(Np / m3::BN3), (unsigned)(rows_pad / BM)), dim3(m3::NT3), m3::SMEM3, ctx->stream, Fc, Fs,
-                           Kp, Qr, Qi, Np, vr, vi, U, Gm);
+        hipLaunchKernelGGL(k_rotate3, dim3((unsigned)rot_grid(ctx, rows_pad / BM, Np / m3::BN3)), dim3(m3::NT3), m3::SMEM3, ctx->stream,
+                           Fc, Fs, Kp, Qr, Qi, Np, vr, vi, U, Gm, rows_pad / BM, ctx->rot_pr, ctx->rot_pc);
       hipLaunchKernelGGL(k_rowsum_sqrt, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, Gm, Np, rows, dsig + r0);
       HIPCHK(ctx, hipGetLastError());
     }

@@ -22,6 +22,7 @@ __all__ = [
     "orf_frequencies",
     "featuremap",
     "gram",
+    "rotate",
     "primal_fit",
     "primal_predict",
     "dual_fit",
@@ -110,6 +111,28 @@ def gram(X, y, s, shift, scale, B, ctx: Context | None = None):
         )
     )  # fmt: skip
     return A, b
+
+
+def rotate(X, shift, scale, B, Q, v, ctx: Context | None = None, want_outputs: bool = True):
+    """(U, Gm) = (Re(P o v), |P|^2) with P = phi(X) Q: the K4 kernel in isolation (``_neo_ls_svm.py:128-143``)."""
+    ctx = ctx or default_context()
+    X = _f64(X, "X")
+    n, d = X.shape
+    shift, scale, B = _map_params(shift, scale, B, d)
+    D1 = B.shape[1] + 1
+    Q = np.ascontiguousarray(Q, dtype=np.complex128)
+    v = np.ascontiguousarray(v, dtype=np.complex128)
+    if Q.shape != (D1, D1) or v.shape != (D1,):
+        raise ValueError("Q must be (D+1, D+1) and v (D+1,)")
+    U = np.empty((n, D1)) if want_outputs else None
+    Gm = np.empty((n, D1)) if want_outputs else None
+    ctx._check(
+        ctx.lib.nls_rotate_only(
+            ctx.handle, _lib._ptr(X), n, d, shift.ctypes.data, scale.ctypes.data, B.ctypes.data, B.shape[1],
+            Q.ctypes.data, v.ctypes.data, _lib._ptr(U), _lib._ptr(Gm),
+        )
+    )  # fmt: skip
+    return U, Gm
 
 
 def primal_fit(

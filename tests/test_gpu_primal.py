@@ -64,6 +64,21 @@ def test_gram_matches_oracle(name, golden_loader, hp):
         assert relerr(A * phi.size, g["A_over_c"]) < 1e-12
 
 
+@pytest.mark.parametrize("name", PRIMAL_CASES[:3])
+def test_rotation_kernel_matches_oracle(name, golden_loader, hp):
+    """K4 in isolation with a random unitary-free Q: U = Re(P v), Gm = |P|^2 (3M complex product on the GPU)."""
+    g = golden_loader(name)
+    rng = np.random.default_rng(1)
+    D1 = int(g["D"]) + 1
+    Q = (rng.standard_normal((D1, D1)) + 1j * rng.standard_normal((D1, D1))) / np.sqrt(D1)
+    v = rng.standard_normal(D1) + 1j * rng.standard_normal(D1)
+    X = g["X"][:700]
+    U, Gm = hp.rotate(X, g["shift"], g["scale"], g["B"], Q, v)
+    P = orc.feature_map(X, g["shift"], g["scale"], g["B"]) @ Q
+    assert relerr(U, np.real(P * v[None, :])) < 1e-12
+    assert relerr(Gm, P.real**2 + P.imag**2) < 1e-12
+
+
 @pytest.mark.parametrize("name", PRIMAL_CASES)
 def test_primal_fit_matches_reference_fixture(name, golden_loader, hp):
     g = golden_loader(name)

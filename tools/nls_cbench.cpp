@@ -42,6 +42,10 @@ int main(int argc, char** argv) {
       a.gammas = gam.data(); a.n = n; a.d = d; a.D = D; a.G = G; a.is_classifier = 0; a.gamma_index_in = -1;
       a.beta = beta.data(); a.loo_errors = errs.data(); a.loo_residuals = res.data(); a.loo_score = &score; a.gamma_index = &opt; a.timings = tm.data();
       rc = nls_primal_fit(ctx, &a);
+    } else if (!strcmp(what, "rotate")) {
+      static std::vector<double> Q, v;
+      if (Q.empty()) { Q.resize((size_t)2 * D1 * D1); v.resize(2 * D1); for (auto& q : Q) q = N01(rng) / std::sqrt((double)D1); for (auto& q : v) q = N01(rng); }
+      rc = nls_rotate_only(ctx, (double*)dX, n, d, shift.data(), scale.data(), B.data(), D, Q.data(), v.data(), nullptr, nullptr);
     } else if (!strcmp(what, "gram")) {
       rc = nls_gram_only(ctx, (double*)dX, (double*)dy, (double*)ds, n, d, shift.data(), scale.data(), B.data(), D, nullptr, nullptr);
     } else {

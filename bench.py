@@ -175,6 +175,16 @@ def main():
         # launches are timed with HIP events on the library's stream inside the timed region.
         launches = max(stage["rotate_launches"], 1.0)
         rot_tflops = stage["rotate_flops"] / max(stage["rotate"], 1e-12) / 1e12
+        # HBM-side traffic of the dominant kernel comes from a separate rocprofv3 PMC pass (it cannot be read live);
+        # scaled per row because every launch streams (rows x panels) with the same reuse pattern.
+        traffic = None
+        try:
+            pmc = json.loads((ROOT / "profiles" / "r01_pmc_summary.json").read_text())["k_rotate3"]
+            if pmc["D"] == D and pmc["d"] == d:
+                rows_per_launch = stage["rotate_flops"] / launches / (8.0 * (D + 1) ** 2)
+                traffic = (pmc["fetch_bytes_x2"] + pmc["write_bytes"]) * rows_per_launch / pmc["rows_per_launch"]
+        except Exception:
+            pass
         out = {
             "metric": "fits/sec (full gamma-sweep), n=1e6 d=128 D=4096" if args.config == "c3" else f"fits/sec (full gamma-sweep), {args.config}",
             "value": args.steps / elapsed,
@@ -198,13 +208,18 @@ def main():
                 "loo_score": r["loo_score"],
             },
             "roofline": {
-                "kernel": "k_rotate",
+                "kernel": "k_rotate3",
                 "bound": "mfma",
                 "achieved": rot_tflops,
                 "peak": FP64_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": rot_tflops / FP64_MFMA_PEAK_TFLOPS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_unit": "bytes/launch beyond L2 (2 x FETCH_SIZE + WRITE_SIZE, Infinity-Cache hits included), profiles/r01_pmc_summary.md",
+                "note": "achieved counts the ALGORITHMIC 8 n (D+1)^2 flops of the four-product complex GEMM; the kernel executes "
+                "the 3M form (6 n Kp Np flops), so frac can exceed 1; executed_frac is the matrix-pipe utilisation",
+                "executed_frac": 6.0 * (stage["rotate_flops"] / (8.0 * (D + 1) ** 2)) * (-(-(D + 2) // 128) * 128) * (-(-(D + 1) // 128) * 128)
+                / max(stage["rotate"], 1e-12) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
                 "avg_launch_ms": 1e3 * stage["rotate"] / launches,
                 "flops_per_launch": stage["rotate_flops"] / launches,
                 "whole_fit_tflops": (stage["rotate_flops"] + stage["gram_flops"] + stage["sweep_flops"] + stage["featuremap_flops"])

@@ -66,26 +66,34 @@ using Cfg8 = TileCfg<512, 2, 4>;
 //   k-major source S[k][m] (m contiguous): idx = t + NTHREADS it -> k = idx >> 6, m = 2 (idx & 63)
 //   m-major source S[m][k] (k contiguous): idx = t + NTHREADS it -> m = idx >> 3, k = 2 (idx & 7)
 // ------------------------------------------------------------------------------------------------
-template <class Cfg>
+template <class Cfg, bool WEIGHTED = false>
 struct KMajorPlaneLoader {  // tile of a row-major [K][ld] plane, columns col0 .. col0+127
   const double* base;
   long ld;
   long col0;
-  __device__ __forceinline__ void fetch(long k0, v2d (&r)[Cfg::STAGE]) const {
+  // Optional per-k weights (the Gram's s_i^2).  They are LOADED with the slice but only APPLIED when the slice
+  // is written to LDS one iteration later: multiplying at fetch time would make the wave wait for its own
+  // global loads in the middle of the MFMA stream (measured: Gram 849 -> 1462 ms).
+  const double* w = nullptr;
+  static constexpr int NREG = Cfg::STAGE + (WEIGHTED ? (Cfg::STAGE + 1) / 2 : 0);
+  __device__ __forceinline__ void fetch(long k0, v2d (&r)[NREG]) const {
     const int t = threadIdx.x;
 #pragma unroll
     for (int it = 0; it < Cfg::STAGE; ++it) {
       const int idx = t + Cfg::NTHREADS * it;
       const long k = k0 + (idx >> 6);
       r[it] = *reinterpret_cast<const v2d*>(base + k * ld + col0 + 2 * (idx & 63));
+      if constexpr (WEIGHTED) r[Cfg::STAGE + it / 2][it & 1] = w[k];
     }
   }
-  static __device__ __forceinline__ void store(double* sm, const v2d (&r)[Cfg::STAGE]) {
+  static __device__ __forceinline__ void store(double* sm, const v2d (&r)[NREG]) {
     const int t = threadIdx.x;
 #pragma unroll
     for (int it = 0; it < Cfg::STAGE; ++it) {
       const int idx = t + Cfg::NTHREADS * it;
-      *reinterpret_cast<v2d*>(sm + (idx >> 6) * LDT + 2 * (idx & 63)) = r[it];
+      v2d v = r[it];
+      if constexpr (WEIGHTED) v *= r[Cfg::STAGE + it / 2][it & 1];
+      *reinterpret_cast<v2d*>(sm + (idx >> 6) * LDT + 2 * (idx & 63)) = v;
     }
   }
 };
@@ -95,6 +103,7 @@ struct MMajorPlaneLoader {  // tile of a row-major [M][ld] plane, rows row0 .. r
   const double* base;
   long ld;
   long row0;
+  static constexpr int NREG = Cfg::STAGE;
   __device__ __forceinline__ void fetch(long k0, v2d (&r)[Cfg::STAGE]) const {
     const int t = threadIdx.x;
 #pragma unroll
@@ -121,6 +130,7 @@ struct XShiftLoader {
   const double* shift;
   long n, d;
   long row0;
+  static constexpr int NREG = Cfg::STAGE;
   __device__ __forceinline__ void fetch(long k0, v2d (&r)[Cfg::STAGE]) const {
     const int t = threadIdx.x;
 #pragma unroll
@@ -190,7 +200,7 @@ __device__ __forceinline__ void mainloop_real(v4d (&acc)[Cfg::MT][Cfg::NTL], con
   constexpr int BUF = 2 * TILE_DOUBLES;
   constexpr int KS = BK / 4;
   constexpr int NMFMA = Cfg::MT * Cfg::NTL, NFRAG = Cfg::MT + Cfg::NTL;
-  v2d ra[Cfg::STAGE], rb[Cfg::STAGE];
+  v2d ra[ALoad::NREG], rb[BLoad::NREG];
   if (ktiles <= 0) return;
   la.fetch(kbegin, ra);
   lb.fetch(kbegin, rb);
@@ -260,7 +270,7 @@ __device__ __forceinline__ void mainloop_cplx(v4d (&accR)[Cfg::MT][Cfg::NTL], v4
   constexpr int KS = BK / 4;
   constexpr int NMFMA = 4 * Cfg::MT * Cfg::NTL, NFRAG = 2 * (Cfg::MT + Cfg::NTL);
   static_assert(KS == 4, "fragment parity relies on an even number of sub-steps");
-  v2d rac[Cfg::STAGE], ras[Cfg::STAGE], rbr[Cfg::STAGE], rbi[Cfg::STAGE];
+  v2d rac[ALoad::NREG], ras[ALoad::NREG], rbr[BLoad::NREG], rbi[BLoad::NREG];
   if (ktiles <= 0) return;
   lac.fetch(kbegin, rac);
   las.fetch(kbegin, ras);

@@ -42,25 +42,31 @@ __device__ __forceinline__ int acc_row3(int mt, int reg) { return wave_m3() * 64
 __device__ __forceinline__ int acc_col3(int nt) { return wave_n3() * 32 + nt * 16 + (threadIdx.x & 15); }
 
 // ---- staging -------------------------------------------------------------------------------------
-template <int WIDTH, int STAGE>
+template <int WIDTH, int STAGE, bool WEIGHTED = false>
 struct KMajorLoader3 {  // tile [16][WIDTH] of a row-major [K][ld] plane, columns col0 ..
   const double* base;
   long ld;
   long col0;
+  const double* w = nullptr;  // optional per-k weights, loaded at fetch, applied at store (see nls_gemm.h)
   static constexpr int LD = WIDTH + 16;
   static constexpr int PER_ROW = WIDTH / 2;  // v2d per row
-  __device__ __forceinline__ void fetch(long k0, v2d (&r)[STAGE]) const {
+  static constexpr int NREG = STAGE + (WEIGHTED ? (STAGE + 1) / 2 : 0);
+  __device__ __forceinline__ void fetch(long k0, v2d (&r)[NREG]) const {
 #pragma unroll
     for (int it = 0; it < STAGE; ++it) {
       const int idx = threadIdx.x + NT3 * it;
-      r[it] = *reinterpret_cast<const v2d*>(base + (k0 + idx / PER_ROW) * ld + col0 + 2 * (idx % PER_ROW));
+      const long k = k0 + idx / PER_ROW;
+      r[it] = *reinterpret_cast<const v2d*>(base + k * ld + col0 + 2 * (idx % PER_ROW));
+      if constexpr (WEIGHTED) r[STAGE + it / 2][it & 1] = w[k];
     }
   }
-  static __device__ __forceinline__ void store(double* sm, const v2d (&r)[STAGE]) {
+  static __device__ __forceinline__ void store(double* sm, const v2d (&r)[NREG]) {
 #pragma unroll
     for (int it = 0; it < STAGE; ++it) {
       const int idx = threadIdx.x + NT3 * it;
-      *reinterpret_cast<v2d*>(sm + (idx / PER_ROW) * LD + 2 * (idx % PER_ROW)) = r[it];
+      v2d v = r[it];
+      if constexpr (WEIGHTED) v *= r[STAGE + it / 2][it & 1];
+      *reinterpret_cast<v2d*>(sm + (idx / PER_ROW) * LD + 2 * (idx % PER_ROW)) = v;
     }
   }
 };
@@ -69,6 +75,7 @@ struct MMajorLoader3 {  // tile [128 rows][16 k] of a row-major [M][ld] plane
   const double* base;
   long ld;
   long row0;
+  static constexpr int NREG = STAGE_A;
   __device__ __forceinline__ void fetch(long k0, v2d (&r)[STAGE_A]) const {
 #pragma unroll
     for (int it = 0; it < STAGE_A; ++it) {
@@ -100,14 +107,13 @@ __device__ __forceinline__ double frag_b3(const double* sm, int ks, int nt) {
 
 // ---- main loop -----------------------------------------------------------------------------------
 // S1 += Ac Br ; S2 += As Bi ; S3 += (Ac - As)(Br + Bi).
-template <bool A_KMAJOR, class ALoad, int ABL = 0>
+template <bool A_KMAJOR, class ALoad, class BLoad, int ABL = 0>
 __device__ __forceinline__ void mainloop_3m(v4d (&S1)[MT3][NTL3], v4d (&S2)[MT3][NTL3], v4d (&S3)[MT3][NTL3], const ALoad& lac,
-                                            const ALoad& las, const KMajorLoader3<BN3, STAGE_B>& lbr,
-                                            const KMajorLoader3<BN3, STAGE_B>& lbi, long kbegin, int ktiles, double* smem) {
-  using BLoad = KMajorLoader3<BN3, STAGE_B>;
+                                            const ALoad& las, const BLoad& lbr, const BLoad& lbi, long kbegin, int ktiles,
+                                            double* smem) {
   constexpr int KS = BK / 4;
   static_assert(KS == 4, "fragment parity relies on an even number of sub-steps");
-  v2d rac[STAGE_A], ras[STAGE_A], rbr[STAGE_B], rbi[STAGE_B];
+  v2d rac[ALoad::NREG], ras[ALoad::NREG], rbr[BLoad::NREG], rbi[BLoad::NREG];
   if (ktiles <= 0) return;
   lac.fetch(kbegin, rac);
   las.fetch(kbegin, ras);
@@ -193,7 +199,7 @@ __device__ __forceinline__ void mainloop_3m(v4d (&S1)[MT3][NTL3], v4d (&S2)[MT3]
         constexpr int NFRAG = 2 * (MT3 + NTL3);  // 12 ds_read_b64 (6 when merged into ds_read2_b64)
         if (ks == 1) {
           interleave<1, 0x200, 2 * STAGE_A + 2 * STAGE_B>();
-          interleave<1, 0x020, 2 * STAGE_A + 2 * STAGE_B>();
+          interleave<1, 0x020, 2 * ALoad::NREG + 2 * BLoad::NREG>();
         } else {
           interleave<2, 0x100, NFRAG>();
         }

@@ -13,7 +13,10 @@ constexpr int LOO_ROWS_PER_BLOCK = 256;
 // epilogue.  Output either as split planes for the solver:
 //     Fc[i][j] = rs_i cos(t_ij)/sqrt(D), Fs[i][j] = rs_i sin(t_ij)/sqrt(D)      (phi = Fc - i Fs)
 //     column D  : Fc = rs_i (bias feature, _feature_maps.py:202), Fs = 0
-//     column D+1: Fc = rs_i y_i when `target` is given (so the Gram's last row is b), else 0
+//     column D+1: Fc = rs_i y_i when `target` is given (so the Gram's last row is b), else 0.  The solver uses
+//     rs_i = s_i / sum(s) and target = y for every phase: the Gram needs S phi, the rotation and the residuals undo
+//     the row scale in their epilogues (P_i = (F_i Q) / rs_i), so one K1 pass serves all three when the planes of
+//     all rows fit in HBM.
 // or as interleaved complex128 phi for nls_featuremap.
 // grid = (Kp / 128, rows_pad / 128).
 // ------------------------------------------------------------------------------------------------
@@ -307,7 +310,7 @@ __global__ void k_compute_v(const double2* Qcm, long ldq, const double2* b, int 
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(Cfg8::NTHREADS, 2)
     k_rotate(const double* Fc, const double* Fs, int Kp, const double* Qr, const double* Qi, int Np, const double* vr,
-             const double* vi, double* U, double* Gm) {
+             const double* vi, double* U, double* Gm, const double* inv_rs) {
   extern __shared__ double smem[];
   const long row0 = (long)blockIdx.y * BM;
   const long col0 = (long)blockIdx.x * BN;
@@ -327,7 +330,8 @@ __global__ void __launch_bounds__(Cfg8::NTHREADS, 2)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const long row = row0 + C::acc_row(mt, r);
-        const double pr = accR[mt][nt][r], pi = accI[mt][nt][r];
+        const double f = inv_rs ? inv_rs[row] : 1.0;  // planes hold rs_i phi_i: undo the row scale
+        const double pr = accR[mt][nt][r] * f, pi = accI[mt][nt][r] * f;
         U[row * Np + col] = pr * wr - pi * wi;
         Gm[row * Np + col] = pr * pr + pi * pi;
       }
@@ -338,7 +342,7 @@ __global__ void __launch_bounds__(Cfg8::NTHREADS, 2)
 // grid.x = xcd_patch_grid(rows_pad / 128, Np / 64, 4, 8).
 __global__ void __launch_bounds__(m3::NT3, 1)
     k_rotate3(const double* Fc, const double* Fs, int Kp, const double* Qr, const double* Qi, int Np, const double* vr,
-              const double* vi, double* U, double* Gm, long tiles_r, int PR, int PC) {
+              const double* vi, double* U, double* Gm, const double* inv_rs, long tiles_r, int PR, int PC) {
   using namespace m3;
   extern __shared__ double smem[];
   long tr, tc;
@@ -367,8 +371,9 @@ __global__ void __launch_bounds__(m3::NT3, 1)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const long row = row0 + acc_row3(mt, r);
+        const double f = inv_rs ? inv_rs[row] : 1.0;  // planes hold rs_i phi_i: undo the row scale
         const double s1 = S1[mt][nt][r], s2 = S2[mt][nt][r];
-        const double pr = s1 + s2, pi = (S3[mt][nt][r] - s1) + s2;
+        const double pr = (s1 + s2) * f, pi = ((S3[mt][nt][r] - s1) + s2) * f;
         U[row * Np + col] = pr * wr - pi * wi;
         Gm[row * Np + col] = pr * pr + pi * pi;
       }
@@ -502,7 +507,7 @@ __global__ void k_loo_column(const double* num, const double* hs, const double* 
 // out = yhat - y (clipped for classifiers) when y != nullptr, else yhat.
 // ------------------------------------------------------------------------------------------------
 __global__ void k_plane_gemv(const double* Fc, const double* Fs, int Kp, const double* br, const double* bi, long rows,
-                             const double* y, int is_clf, double* out) {
+                             const double* y, int is_clf, double* out, const double* inv_rs) {
   const long row = blockIdx.x * (long)(blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
@@ -516,6 +521,7 @@ __global__ void k_plane_gemv(const double* Fc, const double* Fs, int Kp, const d
   }
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
   if (lane == 0) {
+    if (inv_rs) acc *= inv_rs[row];
     if (y) {
       double e = acc - y[row];
       if (is_clf && ((y[row] > 0 && e > 0) || (y[row] < 0 && e < 0))) e = 0.0;
@@ -561,6 +567,19 @@ __global__ void k_weight_sums(const double* s, const double* y, long n, double* 
   if (threadIdx.x == 0) {
     part[2L * blockIdx.x] = s0[0];
     part[2L * blockIdx.x + 1] = s1[0];
+  }
+}
+
+// Row scale of the feature planes and its inverse.  rs_i = s_i / sum(s) (_neo_ls_svm.py:110-112); a zero weight is
+// replaced by 2^-500 so that the row's features survive in the planes (its Gram contribution, ~2^-1000 relative,
+// vanishes in rounding exactly as a zero would) and P_i = (F_i Q) / rs_i is recovered exactly (power of two).
+__global__ void k_row_scales(const double* s, double inv_sum, long n, double* rs, double* inv_rs) {
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i < n) {
+    double v = s[i] * inv_sum;
+    if (!(v > 0.0)) v = 0x1p-500;
+    rs[i] = v;
+    inv_rs[i] = 1.0 / v;
   }
 }
 

@@ -78,19 +78,20 @@ static int launch_featuremap_planes(nls_ctx* ctx, const MapParams& mp, const dou
   return NLS_OK;
 }
 
-// Rows per chunk so that the per-chunk buffers (feature planes + rotation outputs) stay within budget.
-static long pick_row_chunk(nls_ctx* ctx, long n, const MapParams& mp, size_t fixed_bytes) {
+// Rows per chunk so that the per-chunk buffers stay within budget.  `per_row` = bytes of chunk buffers per row.
+static long pick_row_chunk_bytes(nls_ctx* ctx, long n, size_t per_row, size_t fixed_bytes) {
   const size_t limit = ctx->ws_limit ? ctx->ws_limit : (size_t)(0.6 * (double)ctx->hbm_bytes);
   size_t avail = limit > 2 * fixed_bytes ? limit - fixed_bytes : limit / 2;
   avail = std::min(avail, (size_t)48 << 30);  // larger chunks buy nothing once launches are >~100 ms
-  const size_t per_row = 16ull * ((size_t)mp.Kp + (size_t)mp.Np);
   long rc_max = (long)(avail / per_row) / BM * BM;
   rc_max = std::max<long>(rc_max, BM);
   const long n_pad = round_up(n, BM);
   const long nchunks = (n_pad + rc_max - 1) / rc_max;
   return round_up((n_pad + nchunks - 1) / nchunks, BM);
 }
-
+static long pick_row_chunk(nls_ctx* ctx, long n, const MapParams& mp, size_t fixed_bytes) {
+  return pick_row_chunk_bytes(ctx, n, 16ull * ((size_t)mp.Kp + (size_t)mp.Np), fixed_bytes);
+}
 // ------------------------------------------------------------------------------------------------
 // Context API
 // ------------------------------------------------------------------------------------------------
@@ -123,6 +124,7 @@ extern "C" int nls_ctx_create(int device, nls_ctx** out) {
   ctx->hbm_bytes = prop.totalGlobalMem;
   if (const char* e4 = std::getenv("NLS_COMPLEX_4M")) ctx->use_4m = e4[0] == '1';
   if (const char* ep = std::getenv("NLS_ROT_PATCH")) std::sscanf(ep, "%dx%d", &ctx->rot_pr, &ctx->rot_pc);
+  if (const char* er = std::getenv("NLS_NO_RESIDENT_PLANES")) ctx->no_resident = er[0] == '1';
   if (const char* eg = std::getenv("NLS_GRAM_PATCH")) ctx->gram_patches = eg[0] == '1';
   ctx->cus = prop.multiProcessorCount;
   if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess)
@@ -267,11 +269,36 @@ struct PrimalState {
   double c = 0;  // 1 / (n_total * D1): the reference's normalised complexity diagonal (_neo_ls_svm.py:117-118)
   const double *dX = nullptr, *dy = nullptr, *ds = nullptr;
   double* s_norm = nullptr;  // n_pad
+  double* rs = nullptr;      // n_pad  row scale of the planes: s_norm, or 2^-500 where s == 0 (0 beyond n)
+  double* inv_rs = nullptr;  // n_pad  1 / rs (0 beyond n)
+  bool resident = false;     // feature planes of ALL rows stay in HBM (one K1 pass per fit)
+  long plane_rows = 0;       // rows of the plane buffers (rc, or nchunks * rc when resident)
   double* sy = nullptr;      // n_pad  s_norm * y
   double *Fc = nullptr, *Fs = nullptr;  // rc x Kp
   int nt = 0, ntri = 0;
   double* gacc = nullptr;  // ntri x 2 x 128 x 128 tile-packed extended Gram
 };
+
+static inline double* planes_c(const PrimalState& st, long r0) { return st.Fc + (st.resident ? r0 * st.mp.Kp : 0); }
+static inline double* planes_s(const PrimalState& st, long r0) { return st.Fs + (st.resident ? r0 * st.mp.Kp : 0); }
+
+// Primal fit: keep the feature planes of all rows resident when they fit next to everything else; then only the
+// rotation outputs U, Gm are chunked.
+static void plan_primal_chunks(nls_ctx* ctx, PrimalState& st, size_t fixed_bytes) {
+  const size_t limit = ctx->ws_limit ? ctx->ws_limit : (size_t)(0.6 * (double)ctx->hbm_bytes);
+  const size_t planes_all = 16ull * (size_t)(st.n_pad + BM) * st.mp.Kp;
+  const size_t min_rot = 16ull * st.mp.Np * (size_t)std::min<long>(st.n_pad, 32768);
+  if (!ctx->no_resident && fixed_bytes + planes_all + min_rot <= limit) {
+    st.resident = true;
+    st.rc = pick_row_chunk_bytes(ctx, st.n, 16ull * st.mp.Np, fixed_bytes + planes_all);
+    const long nchunks = (st.n_pad + st.rc - 1) / st.rc;
+    st.plane_rows = nchunks * st.rc;
+  } else {
+    st.resident = false;
+    st.rc = pick_row_chunk(ctx, st.n, st.mp, fixed_bytes);
+    st.plane_rows = st.rc;
+  }
+}
 
 // Normalise the weights by the global sum (_neo_ls_svm.py:110) and set c.
 static int primal_prepare(nls_ctx* ctx, PrimalState& st, const double* X, const double* y, const double* s, long n, int d,
@@ -311,9 +338,14 @@ static int primal_prepare(nls_ctx* ctx, PrimalState& st, const double* X, const 
   st.c = 1.0 / (st.n_total * (double)st.mp.D1);
   NLSCHK(ws_get_t(ctx, "pre.s_norm", (size_t)st.n_pad, &st.s_norm));
   NLSCHK(ws_get_t(ctx, "pre.sy", (size_t)st.n_pad, &st.sy));
+  NLSCHK(ws_get_t(ctx, "pre.rs", (size_t)st.n_pad + BM, &st.rs));
+  NLSCHK(ws_get_t(ctx, "pre.inv_rs", (size_t)st.n_pad + BM, &st.inv_rs));
   HIPCHK(ctx, hipMemsetAsync(st.s_norm, 0, st.n_pad * sizeof(double), ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(st.rs, 0, (st.n_pad + BM) * sizeof(double), ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(st.inv_rs, 0, (st.n_pad + BM) * sizeof(double), ctx->stream));
   if (n > 0) {
     hipLaunchKernelGGL(k_scale_vec, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, st.ds, 1.0 / st.s_sum, n, st.s_norm);
+    hipLaunchKernelGGL(k_row_scales, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, st.ds, 1.0 / st.s_sum, n, st.rs, st.inv_rs);
     HIPCHK(ctx, hipGetLastError());
   }
   (void)timings;
@@ -328,8 +360,9 @@ static int primal_gram_phase(nls_ctx* ctx, PrimalState& st, double* timings) {
   const size_t tile_elems_total = (size_t)st.ntri * 2 * BM * BN;
   NLSCHK(ws_get_t(ctx, "gram.acc", tile_elems_total, &st.gacc));
   HIPCHK(ctx, hipMemsetAsync(st.gacc, 0, tile_elems_total * sizeof(double), ctx->stream));
-  NLSCHK(ws_get_t(ctx, "chunk.Fc", (size_t)st.rc * mp.Kp, &st.Fc));
-  NLSCHK(ws_get_t(ctx, "chunk.Fs", (size_t)st.rc * mp.Kp, &st.Fs));
+  if (st.plane_rows < st.rc) st.plane_rows = st.rc;
+  NLSCHK(ws_get_t(ctx, "chunk.Fc", (size_t)st.plane_rows * mp.Kp, &st.Fc));
+  NLSCHK(ws_get_t(ctx, "chunk.Fs", (size_t)st.plane_rows * mp.Kp, &st.Fs));
   // Row split so that one launch fills the chip several times over.
   const long target_blocks = 8L * ctx->cus;
   long nsplit = std::max<long>(1, (target_blocks + st.ntri - 1) / st.ntri);
@@ -343,7 +376,7 @@ static int primal_gram_phase(nls_ctx* ctx, PrimalState& st, double* timings) {
     const long rows_pad = round_up(rows, BM);
     {
       SpanGuard g(ctx, NLS_T_FEATUREMAP);
-      NLSCHK(launch_featuremap_planes(ctx, mp, st.dX + r0 * mp.d, rows, rows_pad, st.s_norm + r0, st.dy + r0, st.Fc, st.Fs));
+      NLSCHK(launch_featuremap_planes(ctx, mp, st.dX + r0 * mp.d, rows, rows_pad, st.rs + r0, st.dy + r0, planes_c(st, r0), planes_s(st, r0)));
       if (timings) {
         timings[NLS_T_FEATUREMAP_LAUNCHES] += 1;
         timings[NLS_T_FEATUREMAP_FLOPS] += 2.0 * rows * mp.d * mp.D;
@@ -354,12 +387,12 @@ static int primal_gram_phase(nls_ctx* ctx, PrimalState& st, double* timings) {
       const long rps = round_up((rows_pad + nsplit - 1) / nsplit, BK);
       const long ns = (rows_pad + rps - 1) / rps;
       if (ctx->use_4m)
-        hipLaunchKernelGGL(k_gram, dim3((unsigned)(st.ntri * ns)), dim3(Cfg8::NTHREADS), SMEM_CPLX, ctx->stream, st.Fc, st.Fs, mp.Kp,
-                           rows_pad, st.ntri, rps, slab);
+        hipLaunchKernelGGL(k_gram, dim3((unsigned)(st.ntri * ns)), dim3(Cfg8::NTHREADS), SMEM_CPLX, ctx->stream, planes_c(st, r0),
+                           planes_s(st, r0), mp.Kp, rows_pad, st.ntri, rps, slab);
       else {
         const long bps = ctx->gram_patches ? xcd_patch_grid(st.nt, 2L * st.nt, 4, 8) : 2L * st.ntri;
-        hipLaunchKernelGGL(k_gram3, dim3((unsigned)(bps * ns)), dim3(m3::NT3), m3::SMEM3, ctx->stream, st.Fc, st.Fs, mp.Kp, rows_pad,
-                           st.ntri, rps, slab, st.nt, bps);
+        hipLaunchKernelGGL(k_gram3, dim3((unsigned)(bps * ns)), dim3(m3::NT3), m3::SMEM3, ctx->stream, planes_c(st, r0), planes_s(st, r0),
+                           mp.Kp, rows_pad, st.ntri, rps, slab, st.nt, bps);
       }
       HIPCHK(ctx, hipGetLastError());
       hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)((tile_elems_total + 255) / 256)), dim3(256), 0, ctx->stream, slab,
@@ -387,6 +420,7 @@ extern "C" int nls_gram_only(nls_ctx* ctx, const double* X, const double* y, con
   NLSCHK(upload_map(ctx, shift, scale, B, d, D, &st.mp));
   NLSCHK(primal_prepare(ctx, st, X, y, s, n, d, nullptr));
   st.rc = pick_row_chunk(ctx, n, st.mp, 0);
+  st.plane_rows = st.rc;
   NLSCHK(primal_gram_phase(ctx, st, nullptr));
   const int D1 = st.mp.D1;
   double2 *Acm = nullptr, *Arm = nullptr, *db = nullptr;
@@ -457,10 +491,10 @@ extern "C" int nls_rotate_only(nls_ctx* ctx, const double* X, int64_t n, int d, 
     NLSCHK(launch_featuremap_planes(ctx, mp, dX + r0 * d, rows, rows_pad, nullptr, nullptr, Fc, Fs));
     if (ctx->use_4m)
       hipLaunchKernelGGL(k_rotate, dim3((unsigned)(Np / BN), (unsigned)(rows_pad / BM)), dim3(Cfg8::NTHREADS), SMEM_CPLX, ctx->stream, Fc, Fs,
-                         Kp, Qr, Qi, Np, vr, vi, U, Gm);
+                         Kp, Qr, Qi, Np, vr, vi, U, Gm, (const double*)nullptr);
     else
       hipLaunchKernelGGL(k_rotate3, dim3((unsigned)rot_grid(ctx, rows_pad / BM, Np / m3::BN3)), dim3(m3::NT3), m3::SMEM3, ctx->stream, Fc,
-                         Fs, Kp, Qr, Qi, Np, vr, vi, U, Gm, rows_pad / BM, ctx->rot_pr, ctx->rot_pc);
+                         Fs, Kp, Qr, Qi, Np, vr, vi, U, Gm, (const double*)nullptr, rows_pad / BM, ctx->rot_pr, ctx->rot_pc);
     HIPCHK(ctx, hipGetLastError());
     for (int which = 0; which < 2; ++which) {
       double* dst = which ? Gmout : Uout;
@@ -498,7 +532,7 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
   const int Gp = (int)round_up(G, BN);
   NLSCHK(primal_prepare(ctx, st, a->X, a->y, a->s, n, a->d, tm));
   const size_t fixed = 2ull * st.n_pad * Gp * 8 + 6ull * D1 * D1 * 16 + 2ull * Kp * Np * 8 + (size_t)Np * Gp * 8;
-  st.rc = pick_row_chunk(ctx, n, mp, fixed);
+  plan_primal_chunks(ctx, st, fixed);
   tm[NLS_T_ROW_CHUNK] = (double)st.rc;
 
   // ---- phase A: Gram -------------------------------------------------------------------------
@@ -547,9 +581,9 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
   for (long r0 = 0; r0 < n; r0 += st.rc) {
     const long rows = std::min<long>(st.rc, n - r0);
     const long rows_pad = round_up(rows, BM);
-    {
+    if (!st.resident) {
       SpanGuard g(ctx, NLS_T_FEATUREMAP);
-      NLSCHK(launch_featuremap_planes(ctx, mp, st.dX + r0 * mp.d, rows, rows_pad, nullptr, nullptr, st.Fc, st.Fs));
+      NLSCHK(launch_featuremap_planes(ctx, mp, st.dX + r0 * mp.d, rows, rows_pad, st.rs + r0, st.dy + r0, st.Fc, st.Fs));
       tm[NLS_T_FEATUREMAP_LAUNCHES] += 1;
       tm[NLS_T_FEATUREMAP_FLOPS] += 2.0 * rows * mp.d * mp.D;
     }
@@ -557,10 +591,10 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
       SpanGuard g(ctx, NLS_T_ROTATE);
       if (ctx->use_4m)
         hipLaunchKernelGGL(k_rotate, dim3((unsigned)(Np / BN), (unsigned)(rows_pad / BM)), dim3(Cfg8::NTHREADS), SMEM_CPLX, ctx->stream,
-                           st.Fc, st.Fs, Kp, Qr, Qi, Np, vr, vi, U, Gm);
+                           planes_c(st, r0), planes_s(st, r0), Kp, Qr, Qi, Np, vr, vi, U, Gm, st.inv_rs + r0);
       else
         hipLaunchKernelGGL(k_rotate3, dim3((unsigned)rot_grid(ctx, rows_pad / BM, Np / m3::BN3)), dim3(m3::NT3), m3::SMEM3,
-                           ctx->stream, st.Fc, st.Fs, Kp, Qr, Qi, Np, vr, vi, U, Gm, rows_pad / BM, ctx->rot_pr, ctx->rot_pc);
+                           ctx->stream, planes_c(st, r0), planes_s(st, r0), Kp, Qr, Qi, Np, vr, vi, U, Gm, st.inv_rs + r0, rows_pad / BM, ctx->rot_pr, ctx->rot_pc);
       HIPCHK(ctx, hipGetLastError());
       tm[NLS_T_ROTATE_LAUNCHES] += 1;
       tm[NLS_T_ROTATE_FLOPS] += 8.0 * rows * (double)D1 * D1;
@@ -657,16 +691,16 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
   for (long r0 = 0; r0 < n; r0 += st.rc) {
     const long rows = std::min<long>(st.rc, n - r0);
     const long rows_pad = round_up(rows, BM);
-    {
+    if (!st.resident) {
       SpanGuard g(ctx, NLS_T_FEATUREMAP);
-      NLSCHK(launch_featuremap_planes(ctx, mp, st.dX + r0 * mp.d, rows, rows_pad, nullptr, nullptr, st.Fc, st.Fs));
+      NLSCHK(launch_featuremap_planes(ctx, mp, st.dX + r0 * mp.d, rows, rows_pad, st.rs + r0, st.dy + r0, st.Fc, st.Fs));
       tm[NLS_T_FEATUREMAP_LAUNCHES] += 1;
       tm[NLS_T_FEATUREMAP_FLOPS] += 2.0 * rows * mp.d * mp.D;
     }
     {
       SpanGuard g(ctx, NLS_T_RESIDUALS);
-      hipLaunchKernelGGL(k_plane_gemv, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, st.Fc, st.Fs, Kp, br, bi, rows,
-                         st.dy + r0, is_clf, res + r0);
+      hipLaunchKernelGGL(k_plane_gemv, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, planes_c(st, r0), planes_s(st, r0), Kp, br, bi, rows,
+                         st.dy + r0, is_clf, res + r0, st.inv_rs + r0);
       HIPCHK(ctx, hipGetLastError());
     }
   }
@@ -779,16 +813,16 @@ extern "C" int nls_primal_predict(nls_ctx* ctx, const double* X, int64_t m, int 
     NLSCHK(launch_featuremap_planes(ctx, mp, dX + r0 * d, rows, rows_pad, nullptr, nullptr, Fc, Fs));
     if (yhat) {
       hipLaunchKernelGGL(k_plane_gemv, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, Fc, Fs, Kp, br, bi, rows,
-                         (const double*)nullptr, 0, dy + r0);
+                         (const double*)nullptr, 0, dy + r0, (const double*)nullptr);
       HIPCHK(ctx, hipGetLastError());
     }
     if (sigma) {
       if (ctx->use_4m)
         hipLaunchKernelGGL(k_rotate, dim3((unsigned)(Np / BN), (unsigned)(rows_pad / BM)), dim3(Cfg8::NTHREADS), SMEM_CPLX, ctx->stream, Fc, Fs,
-                           Kp, Qr, Qi, Np, vr, vi, U, Gm);
+                           Kp, Qr, Qi, Np, vr, vi, U, Gm, (const double*)nullptr);
       else
         hipLaunchKernelGGL(k_rotate3, dim3((unsigned)rot_grid(ctx, rows_pad / BM, Np / m3::BN3)), dim3(m3::NT3), m3::SMEM3, ctx->stream,
-                           Fc, Fs, Kp, Qr, Qi, Np, vr, vi, U, Gm, rows_pad / BM, ctx->rot_pr, ctx->rot_pc);
+                           Fc, Fs, Kp, Qr, Qi, Np, vr, vi, U, Gm, (const double*)nullptr, rows_pad / BM, ctx->rot_pr, ctx->rot_pc);
       hipLaunchKernelGGL(k_rowsum_sqrt, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, Gm, Np, rows, dsig + r0);
       HIPCHK(ctx, hipGetLastError());
     }

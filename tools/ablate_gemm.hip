@@ -46,7 +46,7 @@ __global__ void __launch_bounds__(m3::NT3, 1) k_abl3(const double* Fc, const dou
   using AL = typename std::conditional<A_KMAJOR, KMajorLoader3<BM3, STAGE_A>, MMajorLoader3>::type;
   AL lac{Fc, Kp, colA}, las{Fs, Kp, colA};
   KMajorLoader3<BN3, STAGE_B> lbr{Fc, Kp, col0}, lbi{Fs, Kp, col0};
-  mainloop_3m<A_KMAJOR, AL, FLAGS>(S1, S2, S3, lac, las, lbr, lbi, 0, ktiles, smem);
+  mainloop_3m<A_KMAJOR, AL, KMajorLoader3<BN3, STAGE_B>, FLAGS>(S1, S2, S3, lac, las, lbr, lbi, 0, ktiles, smem);
   double s = 0;
 #pragma unroll
   for (int mt = 0; mt < MT3; ++mt)

@@ -217,8 +217,8 @@ def main():
                 "traffic": traffic,
                 "traffic_unit": "bytes/launch beyond L2 (2 x FETCH_SIZE + WRITE_SIZE, Infinity-Cache hits included), profiles/r01_pmc_summary.md",
                 "note": "achieved counts the ALGORITHMIC 8 n (D+1)^2 flops of the four-product complex GEMM; the kernel executes "
-                "the 3M form (6 n Kp Np flops), so frac can exceed 1; executed_frac is the matrix-pipe utilisation",
-                "executed_frac": 6.0 * (stage["rotate_flops"] / (8.0 * (D + 1) ** 2)) * (-(-(D + 2) // 128) * 128) * (-(-(D + 1) // 128) * 128)
+                "the 3M form (6 n Kf Np flops, Kf = ceil(D/128)*128, Np = ceil((D+1)/64)*64), so frac can exceed 1; executed_frac is the matrix-pipe utilisation",
+                "executed_frac": 6.0 * (stage["rotate_flops"] / (8.0 * (D + 1) ** 2)) * (-(-D // 128) * 128) * (-(-(D + 1) // 64) * 64)
                 / max(stage["rotate"], 1e-12) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
                 "avg_launch_ms": 1e3 * stage["rotate"] / launches,
                 "flops_per_launch": stage["rotate_flops"] / launches,

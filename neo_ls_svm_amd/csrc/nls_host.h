@@ -40,9 +40,7 @@ struct nls_ctx {
   // XCD patch shape of k_rotate3 (NLS_ROT_PATCH=RxC; 0x0 = plain order, the default: patches raise the L2 hit rate
   // from 0.57 to 0.78 and halve the fabric traffic but run 1-4 % slower, profiles/r01_pmc_summary.md)
   int rot_pr = 0, rot_pc = 0;
-  bool gram_patches = false;
   bool no_resident = false;  // NLS_NO_RESIDENT_PLANES=1: recompute the feature planes per phase even when they would fit
-  bool use_4m = false;  // NLS_COMPLEX_4M=1: four-product complex kernels (nls_gemm.h) instead of 3M (nls_gemm3m.h)
   // stage timing
   struct Span {
     hipEvent_t a, b;

@@ -1,5 +1,12 @@
 // Kernels of the primal path.  Stage names follow SURVEY.md section 8(a): P1/P2 feature map (K1),
 // P3 Gram (K2), P5 rotation (K4), P6 sweep (K5), P7 selection, P8/P9 re-solve and LOO sigma.
+//
+// Layout convention: the feature planes hold ONLY the D random features (Kf = ceil(D / 128) * 128 columns).  The
+// bias feature phi[:, D] = 1 (_feature_maps.py:202) never enters a matrix tile - D + 1 = 4097 would cost a whole
+// extra 128-wide tile row/column (6 % of the Gram and of the rotation at D = 4096).  It is carried as
+//   * border vectors of the Gram  (k_border: sum_i conj(F_ij) rs_i, sum_i conj(F_ij) rs_i y_i, 2 scalars),
+//   * a rank-1 epilogue term of the rotation  (P_ij += M[D][j]),
+//   * a scalar in the prediction GEMV  (+ Re beta[D]).
 #pragma once
 #include "nls_gemm.h"
 #include "nls_gemm3m.h"
@@ -10,26 +17,22 @@ constexpr int LOO_ROWS_PER_BLOCK = 256;
 
 // ------------------------------------------------------------------------------------------------
 // K1: feature map.  T = (X - shift) Bs on the matrix pipe (K = d), sincos on the vector pipe in the
-// epilogue.  Output either as split planes for the solver:
-//     Fc[i][j] = rs_i cos(t_ij)/sqrt(D), Fs[i][j] = rs_i sin(t_ij)/sqrt(D)      (phi = Fc - i Fs)
-//     column D  : Fc = rs_i (bias feature, _feature_maps.py:202), Fs = 0
-//     column D+1: Fc = rs_i y_i when `target` is given (so the Gram's last row is b), else 0.  The solver uses
-//     rs_i = s_i / sum(s) and target = y for every phase: the Gram needs S phi, the rotation and the residuals undo
-//     the row scale in their epilogues (P_i = (F_i Q) / rs_i), so one K1 pass serves all three when the planes of
-//     all rows fit in HBM.
-// or as interleaved complex128 phi for nls_featuremap.
-// grid = (Kp / 128, rows_pad / 128).
+// epilogue.  Output either as split planes for the solver (phi = Fc - i Fs, scaled per row):
+//     Fc[i][j] = rs_i cos(t_ij)/sqrt(D), Fs[i][j] = rs_i sin(t_ij)/sqrt(D)   for j < D, 0 for D <= j < Kf
+// or as interleaved complex128 phi (n x (D+1), column D = 1) for nls_featuremap.
+// The solver uses rs_i = s_i / sum(s): the Gram needs S phi, the rotation and the residuals undo the row scale in
+// their epilogues (P_i = (F_i Q) / rs_i), so one K1 pass serves all three when the planes of all rows fit in HBM.
+// grid = (ceil(cols / 128), rows_pad / 128) with cols = Kf (planes) or D + 1 (complex).
 // ------------------------------------------------------------------------------------------------
 struct FeatureMapParams {
-  const double* X;      // n_total_rows x d (pointer to the first row of this chunk)
-  const double* shift;  // d
-  const double* Bs;     // dk x Kp, B / scale^T zero padded
+  const double* X;         // rows x d (pointer to the first row of this chunk)
+  const double* shift;     // d
+  const double* Bs;        // dk x Kf, B / scale^T zero padded
   const double* rowscale;  // rows (chunk-local) or nullptr (= 1)
-  const double* target;    // rows (chunk-local) or nullptr
   long rows;               // valid rows in this chunk
-  int d, dk, D, Kp;
+  int d, dk, D, Kf;
   double inv_sqrt_D;
-  double* Fc;  // rows_pad x Kp
+  double* Fc;  // rows_pad x Kf
   double* Fs;
   double* phi;  // rows x (D+1) complex interleaved (complex variant only)
 };
@@ -44,7 +47,7 @@ __global__ void __launch_bounds__(Cfg4::NTHREADS, 1) k_featuremap(FeatureMapPara
   zero_acc(acc);
   if (col0 < p.D) {
     XShiftLoader<C> la{p.X, p.shift, p.rows, p.d, row0};
-    KMajorPlaneLoader<C> lb{p.Bs, p.Kp, col0};
+    KMajorPlaneLoader<C> lb{p.Bs, p.Kf, col0};
     mainloop_real<C, false>(acc, la, lb, 0, p.dk / BK, smem);
   }
 #pragma unroll
@@ -54,7 +57,6 @@ __global__ void __launch_bounds__(Cfg4::NTHREADS, 1) k_featuremap(FeatureMapPara
       const long row = row0 + C::acc_row(mt, r);
       const bool live = row < p.rows;
       const double rs = live ? (p.rowscale ? p.rowscale[row] : 1.0) : 0.0;
-      const double tg = (live && p.target) ? p.target[row] : 0.0;
 #pragma unroll
       for (int nt = 0; nt < C::NTL; ++nt) {
         const long col = col0 + C::acc_col(nt);
@@ -64,92 +66,37 @@ __global__ void __launch_bounds__(Cfg4::NTHREADS, 1) k_featuremap(FeatureMapPara
           sincos(acc[mt][nt][r], &sv, &cv);
           c = cv * p.inv_sqrt_D * rs;
           s = sv * p.inv_sqrt_D * rs;
-        } else if (col == p.D) {
+        } else if (COMPLEX_OUT && col == p.D) {
           c = rs;
-        } else if (col == p.D + 1) {
-          c = rs * tg;
         }
         if constexpr (COMPLEX_OUT) {
           if (live && col <= p.D)
             *reinterpret_cast<double2*>(p.phi + 2 * (row * (p.D + 1) + col)) = make_double2(c, -s);
         } else {
-          p.Fc[row * p.Kp + col] = c;
-          p.Fs[row * p.Kp + col] = s;
+          p.Fc[row * p.Kf + col] = c;
+          p.Fs[row * p.Kf + col] = s;
         }
       }
     }
 }
 
-// Bs[k][j] = B[k][j] / scale[k] for k < d, j < D; zero elsewhere (dk x Kp).
-__global__ void k_build_Bs(const double* B, const double* scale, int d, int D, int dk, int Kp, double* Bs) {
+// Bs[k][j] = B[k][j] / scale[k] for k < d, j < D; zero elsewhere (dk x Kf).
+__global__ void k_build_Bs(const double* B, const double* scale, int d, int D, int dk, int Kf, double* Bs) {
   const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
-  if (idx >= (long)dk * Kp) return;
-  const int k = idx / Kp, j = idx % Kp;
+  if (idx >= (long)dk * Kf) return;
+  const int k = idx / Kf, j = idx % Kf;
   Bs[idx] = (k < d && j < D) ? B[(long)k * D + j] / scale[k] : 0.0;
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2: Hermitian Gram of the extended feature planes, lower block triangle, split over rows.
-// grid.x = ntri * nsplit; slab[(split * ntri + tile)][{R, I}][128][128].
+// XCD-aware tile order (optional, off by default).  Workgroups are dealt round-robin over the 8 XCDs (block b
+// runs on XCD b % 8, each with its own 4 MiB L2), and 32 of them are resident per XCD.  Block b is mapped to patch
+// (b / 8) / 32 of XCD b % 8 and to position (b / 8) % 32 inside that patch of PR x PC tiles, so the workgroups that
+// share an L2 start together on one compact patch and walk K in phase.  Measured on k_rotate3: L2 hit rate
+// 0.57 -> 0.78, fabric traffic halved, but 1-4 % slower (profiles/r01_pmc_summary.md): speed only, never
+// correctness.  Returns false for the padding blocks of partial patches.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void tri_decode(int t, int& tj, int& tk) {
-  // t = tj (tj + 1) / 2 + tk, 0 <= tk <= tj
-  int j = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
-  while ((j + 1) * (j + 2) / 2 <= t) ++j;
-  while (j * (j + 1) / 2 > t) --j;
-  tj = j;
-  tk = t - j * (j + 1) / 2;
-}
-
-__global__ void __launch_bounds__(Cfg8::NTHREADS, 2)
-    k_gram(const double* Fc, const double* Fs, int Kp, long rows_pad, int ntri, long rows_per_split, double* slab) {
-  extern __shared__ double smem[];
-  const int tile = blockIdx.x % ntri, split = blockIdx.x / ntri;
-  int tj, tk;
-  tri_decode(tile, tj, tk);
-  const long r0 = (long)split * rows_per_split;
-  long r1 = r0 + rows_per_split;
-  if (r1 > rows_pad) r1 = rows_pad;
-  using C = Cfg8;
-  v4d accR[C::MT][C::NTL], accI[C::MT][C::NTL];
-  zero_acc(accR);
-  zero_acc(accI);
-  if (r1 > r0) {
-    KMajorPlaneLoader<C> lac{Fc, Kp, (long)tj * BM}, las{Fs, Kp, (long)tj * BM};
-    KMajorPlaneLoader<C> lbr{Fc, Kp, (long)tk * BN}, lbi{Fs, Kp, (long)tk * BN};
-    mainloop_cplx<C, true>(accR, accI, lac, las, lbr, lbi, r0, (int)((r1 - r0) / BK), smem);
-  }
-  double* outR = slab + ((long)split * ntri + tile) * (2L * BM * BN);
-  double* outI = outR + BM * BN;
-#pragma unroll
-  for (int mt = 0; mt < C::MT; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < C::NTL; ++nt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int o = C::acc_row(mt, r) * BN + C::acc_col(nt);
-        outR[o] = accR[mt][nt][r];
-        outI[o] = accI[mt][nt][r];
-      }
-}
-
-// XCD-aware tile order shared by the 3M kernels.  Workgroups are dealt round-robin over the 8 XCDs (block b runs
-// on XCD b % 8, each with its own 4 MiB L2), and 32 of them are resident per XCD.  Block b is therefore mapped to
-// patch (b / 8) / 32 of XCD b % 8 and to position (b / 8) % 32 inside that patch of PR x PC tiles: the 32 workgroups
-// that share an L2 start together on one compact patch and walk K in phase, so every A panel slice is fetched once
-// for PC tiles and every B panel slice once for PR tiles (measured on k_rotate3: L2 hit rate 0.57 -> see
-// profiles/r01_pmc_summary.md; speed only, never correctness - a different placement just hits less).
-// Returns false for the padding blocks of partial patches.
-__device__ __forceinline__ bool xcd_patch_tile_rt(int PR, int PC, long b, long tiles_r, long tiles_c, long& tr, long& tc) {
-  const long xcd = b & 7, slot = b >> 3;
-  const long patch = (slot / (PR * PC)) * 8 + xcd, within = slot % (PR * PC);
-  const long patches_c = (tiles_c + PC - 1) / PC;
-  tr = (patch / patches_c) * PR + within / PC;
-  tc = (patch % patches_c) * PC + within % PC;
-  return tr < tiles_r && tc < tiles_c;
-}
-template <int PR, int PC>
-__device__ __forceinline__ bool xcd_patch_tile(long b, long tiles_r, long tiles_c, long& tr, long& tc) {
+__device__ __forceinline__ bool xcd_patch_tile(int PR, int PC, long b, long tiles_r, long tiles_c, long& tr, long& tc) {
   const long xcd = b & 7, slot = b >> 3;
   const long patch = (slot / (PR * PC)) * 8 + xcd, within = slot % (PR * PC);
   const long patches_c = (tiles_c + PC - 1) / PC;
@@ -162,30 +109,23 @@ static inline long xcd_patch_grid(long tiles_r, long tiles_c, int PR, int PC) {
   return ((patches + 7) / 8) * 8 * PR * PC;
 }
 
-// 3M variant of K2 (nls_gemm3m.h) writing the same packed layout in 128 x 64 half tiles: half tile (tj, tk64),
-// 0 <= tk64 <= 2 tj + 1, is columns (tk64 & 1) * 64 .. +63 of the 128 x 128 tile (tj, tk64 >> 1).  The nt x 2 nt
-// grid.x = blocks_per_split * nsplit with blocks_per_split = nt (nt + 1) (plain order, default) or
-// xcd_patch_grid(nt, 2 nt, 4, 8) (XCD patches: L2 hit rate 0.58 -> 0.72 but unbalanced XCDs, +11 % time; kept as a knob).
+// ------------------------------------------------------------------------------------------------
+// K2: Hermitian Gram A_jk = sum_i conj(F_ij) F_ik of the feature planes, lower block triangle, split over rows,
+// 3M complex product (nls_gemm3m.h).  Packed layout: 128 x 128 tile (tj, tk), tk <= tj, at index tj (tj + 1) / 2 + tk,
+// each {Re, -Im} x 128 x 128.  A workgroup computes a 128 x 64 half tile: half h = tj (tj + 1) + tk64
+// (0 <= tk64 <= 2 tj + 1) is columns (tk64 & 1) * 64 .. +63 of tile (tj, tk64 >> 1).
+// grid.x = nt (nt + 1) * nsplit;  slab[(split * ntri + tile)][{R, I}][128][128].
+// ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(m3::NT3, 1)
-    k_gram3(const double* Fc, const double* Fs, int Kp, long rows_pad, int ntri, long rows_per_split, double* slab, int nt,
-            long blocks_per_split) {
+    k_gram3(const double* Fc, const double* Fs, int Kf, long rows_pad, int ntri, long rows_per_split, double* slab) {
   using namespace m3;
   extern __shared__ double smem[];
-  const long split = blockIdx.x / blocks_per_split;
-  int tj, tk64;
-  if (blocks_per_split == 2L * ntri) {  // plain order: half tile h = tj (tj + 1) + tk64
-    const int half = (int)(blockIdx.x % blocks_per_split);
-    tj = (int)((sqrt(4.0 * half + 1.0) - 1.0) * 0.5);
-    while ((tj + 1) * (tj + 2) <= half) ++tj;
-    while (tj * (tj + 1) > half) --tj;
-    tk64 = half - tj * (tj + 1);
-  } else {  // XCD patches of 4 x 8 over the nt x 2 nt rectangle; blocks above the diagonal exit at once
-    long tjl, tkl;
-    if (!xcd_patch_tile<4, 8>(blockIdx.x % blocks_per_split, nt, 2L * nt, tjl, tkl)) return;
-    if (tkl > 2 * tjl + 1) return;
-    tj = (int)tjl;
-    tk64 = (int)tkl;
-  }
+  const int nhalf = 2 * ntri;
+  const int half = blockIdx.x % nhalf, split = blockIdx.x / nhalf;
+  int tj = (int)((sqrt(4.0 * half + 1.0) - 1.0) * 0.5);
+  while ((tj + 1) * (tj + 2) <= half) ++tj;
+  while (tj * (tj + 1) > half) --tj;
+  const int tk64 = half - tj * (tj + 1);
   const long r0 = (long)split * rows_per_split;
   long r1 = r0 + rows_per_split;
   if (r1 > rows_pad) r1 = rows_pad;
@@ -194,8 +134,8 @@ __global__ void __launch_bounds__(m3::NT3, 1)
   zero_acc(S2);
   zero_acc(S3);
   if (r1 > r0) {
-    KMajorLoader3<BM3, STAGE_A> lac{Fc, Kp, (long)tj * BM3}, las{Fs, Kp, (long)tj * BM3};
-    KMajorLoader3<BN3, STAGE_B> lbr{Fc, Kp, (long)tk64 * BN3}, lbi{Fs, Kp, (long)tk64 * BN3};
+    KMajorLoader3<BM3, STAGE_A> lac{Fc, Kf, (long)tj * BM3}, las{Fs, Kf, (long)tj * BM3};
+    KMajorLoader3<BN3, STAGE_B> lbr{Fc, Kf, (long)tk64 * BN3}, lbi{Fs, Kf, (long)tk64 * BN3};
     mainloop_3m<true>(S1, S2, S3, lac, las, lbr, lbi, r0, (int)((r1 - r0) / BK), smem);
   }
   const long tile128 = (long)tj * (tj + 1) / 2 + (tk64 >> 1);
@@ -209,35 +149,93 @@ __global__ void __launch_bounds__(m3::NT3, 1)
       for (int r = 0; r < 4; ++r) {
         const int o = acc_row3(mt, r) * BN + acc_col3(nt);
         const double s1 = S1[mt][nt][r], s2 = S2[mt][nt][r];
-        outR[o] = s1 + s2;                     // Ac Br + As Bi
-        outI[o] = (S3[mt][nt][r] - s1) + s2;   // Ac Bi - As Br
+        outR[o] = s1 + s2;                    // Fc_j Fc_k + Fs_j Fs_k =  Re A_jk
+        outI[o] = (S3[mt][nt][r] - s1) + s2;  // Fc_j Fs_k - Fs_j Fc_k = -Im A_jk
       }
 }
 
-// acc[tile] += sum_split slab[split][tile], fixed order (bit-reproducible).
-__global__ void k_gram_reduce(const double* slab, int nsplit, long tile_elems_total, double* acc) {
+// acc[i] += sum_split slab[split][i], fixed order (bit-reproducible).
+__global__ void k_gram_reduce(const double* slab, int nsplit, long elems, double* acc) {
   const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
-  if (idx >= tile_elems_total) return;
+  if (idx >= elems) return;
   double v = acc[idx];
-  for (int s = 0; s < nsplit; ++s) v += slab[(long)s * tile_elems_total + idx];
+  for (int s = 0; s < nsplit; ++s) v += slab[(long)s * elems + idx];
   acc[idx] = v;
 }
 
-// Tile-packed extended Gram -> column-major complex A (D1 x D1, full Hermitian), optionally scaled,
-// and b.  Element (j, k), j >= k of the packed Gram is (R, -I) of tile (j / 128, k / 128).
+// Border of the normal equations (bias feature and right-hand side), HBM-bound column sums of the planes:
+//   part[split][0][j] = sum_i Fc_ij rs_i        part[split][1][j] = sum_i Fs_ij rs_i          (A[j][D] = [0] + i [1])
+//   part[split][2][j] = sum_i Fc_ij rs_i y_i    part[split][3][j] = sum_i Fs_ij rs_i y_i      (b[j]    = [2] + i [3])
+//   part[split][4][0] = sum_i rs_i^2 (A[D][D]), part[split][4][1] = sum_i rs_i^2 y_i (b[D])
+// width of one split record = 4 Kf + 2.  grid = (Kf / 128, nsplit), 256 threads = 4 row lanes x 64 column pairs.
+__global__ void k_border(const double* Fc, const double* Fs, int Kf, const double* rs, const double* y, long rows,
+                         long rows_per_split, double* part) {
+  __shared__ v2d sh[4][4][64];
+  __shared__ double shq[4][2];
+  const int cp = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const long col = (long)blockIdx.x * 128 + 2 * cp;
+  const long r0 = (long)blockIdx.y * rows_per_split;
+  long r1 = r0 + rows_per_split;
+  if (r1 > rows) r1 = rows;
+  v2d a0 = {0.0, 0.0}, a1 = a0, a2 = a0, a3 = a0;
+  double q0 = 0.0, q1 = 0.0;
+  for (long i = r0 + rl; i < r1; i += 4) {
+    const double w = rs[i], wy = w * y[i];
+    const v2d c = *reinterpret_cast<const v2d*>(Fc + i * Kf + col), s = *reinterpret_cast<const v2d*>(Fs + i * Kf + col);
+    a0 += c * w;
+    a1 += s * w;
+    a2 += c * wy;
+    a3 += s * wy;
+    q0 += w * w;
+    q1 += w * wy;
+  }
+  sh[rl][0][cp] = a0;
+  sh[rl][1][cp] = a1;
+  sh[rl][2][cp] = a2;
+  sh[rl][3][cp] = a3;
+  if (cp == 0) {
+    shq[rl][0] = q0;
+    shq[rl][1] = q1;
+  }
+  __syncthreads();
+  const long width = 4L * Kf + 2;
+  double* o = part + (long)blockIdx.y * width;
+  if (rl == 0) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const v2d t = (sh[0][v][cp] + sh[1][v][cp]) + (sh[2][v][cp] + sh[3][v][cp]);
+      *reinterpret_cast<v2d*>(o + (long)v * Kf + col) = t;
+    }
+    if (blockIdx.x == 0 && cp == 0) {
+      o[4L * Kf] = (shq[0][0] + shq[1][0]) + (shq[2][0] + shq[3][0]);
+      o[4L * Kf + 1] = (shq[0][1] + shq[1][1]) + (shq[2][1] + shq[3][1]);
+    }
+  }
+}
+
+// Packed Gram tiles + border -> column-major complex A (D1 x D1, full Hermitian), optionally scaled, and b.
+// Element (j, k), j >= k, both < D, of the packed Gram is (R, -I) of tile (j / 128, k / 128).
 __device__ __forceinline__ double2 gram_elem(const double* g, int j, int k) {
   const int tj = j >> 7, tk = k >> 7;
   const double* t = g + ((long)tj * (tj + 1) / 2 + tk) * (2L * BM * BN);
   const int o = (j & 127) * BN + (k & 127);
   return make_double2(t[o], -t[BM * BN + o]);
 }
-__global__ void k_assemble_A(const double* g, int D1, double scale, double2* Acm, long lda, double2* b) {
+__global__ void k_assemble_A(const double* g, const double* border, int D, int Kf, double scale, double2* Acm, long lda,
+                             double2* b) {
+  const int D1 = D + 1;
   const int j = blockIdx.x * blockDim.x + threadIdx.x;  // row
-  const int k = blockIdx.y;                             // column
+  const int k = blockIdx.y;                             // column (k == D1: the right-hand side)
   if (j >= D1) return;
   if (k < D1) {
     double2 v;
-    if (j > k) {
+    if (j == D && k == D) {
+      v = make_double2(border[4L * Kf], 0.0);
+    } else if (j == D) {  // A[D][k] = conj(A[k][D])
+      v = make_double2(border[k], -border[Kf + k]);
+    } else if (k == D) {  // A[j][D] = sum_i conj(F_ij) rs_i
+      v = make_double2(border[j], border[Kf + j]);
+    } else if (j > k) {
       v = gram_elem(g, j, k);
     } else if (j < k) {
       v = gram_elem(g, k, j);
@@ -248,9 +246,7 @@ __global__ void k_assemble_A(const double* g, int D1, double scale, double2* Acm
     }
     Acm[(long)k * lda + j] = make_double2(v.x * scale, v.y * scale);
   } else if (k == D1 && b != nullptr) {
-    // b_j = conj(G[D1][j]) (row D+1 of the extended Gram is the target pseudo-feature)
-    double2 v = gram_elem(g, D1, j);
-    b[j] = make_double2(v.x, -v.y);
+    b[j] = (j == D) ? make_double2(border[4L * Kf + 1], 0.0) : make_double2(border[2L * Kf + j], border[3L * Kf + j]);
   }
 }
 
@@ -264,20 +260,30 @@ __global__ void k_cm_to_rm(const double2* Acm, long lda, int D1, bool conj, doub
   out[(long)i * D1 + j] = v;
 }
 
-// Q (column-major complex, eigenvector k in column k) -> B-operand planes Qr, Qi [Kp x Np], zero padded.
-__global__ void k_build_Q_planes(const double2* Qcm, long ldq, int D1, int Kp, int Np, double* Qr, double* Qi) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;  // eigen index (plane column)
-  const int i = blockIdx.y;                             // feature index (plane row)
+// Rotation matrix M (D1 x D1 complex) -> B-operand planes Mr, Mi [Kf x Np] for the feature rows 0 .. D-1 and the
+// bias row D as vectors mbr, mbi [Np]; zero padded.  Element (i, k) is read at M[i * si + k * sk], which covers
+// column-major Q (si = 1, sk = ld) and row-major matrices (si = ld, sk = 1); `upper` keeps only i <= k.
+// grid = (ceil(Np / 256), Kf + 1): blockIdx.y == Kf is the bias row.
+__global__ void k_build_rot_planes(const double2* M, long si, long sk, int D, int Kf, int Np, bool upper, double* Mr, double* Mi,
+                                   double* mbr, double* mbi) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;  // output column
+  const int i = blockIdx.y;
   if (k >= Np) return;
+  const bool bias = (i == Kf);
+  const int row = bias ? D : i;
   double2 v = make_double2(0.0, 0.0);
-  if (i < D1 && k < D1) v = Qcm[(long)k * ldq + i];
-  Qr[(long)i * Np + k] = v.x;
-  Qi[(long)i * Np + k] = v.y;
+  if ((bias || i < D) && k <= D && (!upper || row <= k)) v = M[(long)row * si + (long)k * sk];
+  if (bias) {
+    mbr[k] = v.x;
+    mbi[k] = v.y;
+  } else {
+    Mr[(long)i * Np + k] = v.x;
+    Mi[(long)i * Np + k] = v.y;
+  }
 }
 
-// v_k = (Q^H b)_k * inv_c, one block per k (column k of Q is contiguous).
-__global__ void k_compute_v(const double2* Qcm, long ldq, const double2* b, int D1, double inv_c, int Np, double* vr,
-                            double* vi) {
+// v_k = (Q^H b)_k * inv_c, one block per k (column k of the column-major Q is contiguous); zero for k >= D1.
+__global__ void k_compute_v(const double2* Qcm, long ldq, const double2* b, int D1, double inv_c, double* vr, double* vi) {
   const int k = blockIdx.x;
   __shared__ double sr[256], si[256];
   double ar = 0.0, ai = 0.0;
@@ -305,50 +311,19 @@ __global__ void k_compute_v(const double2* Qcm, long ldq, const double2* b, int 
 }
 
 // ------------------------------------------------------------------------------------------------
-// K4: rotation P = phi Q with the P5 epilogue fused: U = Re(P v), Gm = |P|^2.
-// grid = (Np / 128, rows_pad / 128).
+// K4: rotation P = phi M with the P5 epilogue fused (3M complex product, 128-row x 64-column tiles):
+//     P_ij = inv_rs_i sum_{k < D} F_ik M_kj + M_Dj ;   U = Re(P v) ,  Gm = |P|^2 .
+// grid.x = tiles_r * (Np / 64) (column tile fastest) or xcd_patch_grid(...) when PR > 0.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(Cfg8::NTHREADS, 2)
-    k_rotate(const double* Fc, const double* Fs, int Kp, const double* Qr, const double* Qi, int Np, const double* vr,
-             const double* vi, double* U, double* Gm, const double* inv_rs) {
-  extern __shared__ double smem[];
-  const long row0 = (long)blockIdx.y * BM;
-  const long col0 = (long)blockIdx.x * BN;
-  using C = Cfg8;
-  v4d accR[C::MT][C::NTL], accI[C::MT][C::NTL];
-  zero_acc(accR);
-  zero_acc(accI);
-  MMajorPlaneLoader<C> lac{Fc, Kp, row0}, las{Fs, Kp, row0};
-  KMajorPlaneLoader<C> lbr{Qr, Np, col0}, lbi{Qi, Np, col0};
-  mainloop_cplx<C, false>(accR, accI, lac, las, lbr, lbi, 0, Kp / BK, smem);
-#pragma unroll
-  for (int nt = 0; nt < C::NTL; ++nt) {
-    const long col = col0 + C::acc_col(nt);
-    const double wr = vr[col], wi = vi[col];
-#pragma unroll
-    for (int mt = 0; mt < C::MT; ++mt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const long row = row0 + C::acc_row(mt, r);
-        const double f = inv_rs ? inv_rs[row] : 1.0;  // planes hold rs_i phi_i: undo the row scale
-        const double pr = accR[mt][nt][r] * f, pi = accI[mt][nt][r] * f;
-        U[row * Np + col] = pr * wr - pi * wi;
-        Gm[row * Np + col] = pr * pr + pi * pi;
-      }
-  }
-}
-
-// 3M variant of K4 (nls_gemm3m.h): 128-row x 64-column tiles in 4 x 8 patches per XCD.
-// grid.x = xcd_patch_grid(rows_pad / 128, Np / 64, 4, 8).
 __global__ void __launch_bounds__(m3::NT3, 1)
-    k_rotate3(const double* Fc, const double* Fs, int Kp, const double* Qr, const double* Qi, int Np, const double* vr,
-              const double* vi, double* U, double* Gm, const double* inv_rs, long tiles_r, int PR, int PC) {
+    k_rotate3(const double* Fc, const double* Fs, int Kf, const double* Mr, const double* Mi, const double* mbr, const double* mbi,
+              int Np, const double* vr, const double* vi, double* U, double* Gm, const double* inv_rs, long tiles_r, int PR, int PC) {
   using namespace m3;
   extern __shared__ double smem[];
   long tr, tc;
   if (PR > 0) {
-    if (!xcd_patch_tile_rt(PR, PC, blockIdx.x, tiles_r, Np / BN3, tr, tc)) return;
-  } else {  // plain order: column tile fastest
+    if (!xcd_patch_tile(PR, PC, blockIdx.x, tiles_r, Np / BN3, tr, tc)) return;
+  } else {
     tc = blockIdx.x % (Np / BN3);
     tr = blockIdx.x / (Np / BN3);
     if (tr >= tiles_r) return;
@@ -359,13 +334,13 @@ __global__ void __launch_bounds__(m3::NT3, 1)
   zero_acc(S1);
   zero_acc(S2);
   zero_acc(S3);
-  MMajorLoader3 lac{Fc, Kp, row0}, las{Fs, Kp, row0};
-  KMajorLoader3<BN3, STAGE_B> lbr{Qr, Np, col0}, lbi{Qi, Np, col0};
-  mainloop_3m<false>(S1, S2, S3, lac, las, lbr, lbi, 0, Kp / BK, smem);
+  MMajorLoader3 lac{Fc, Kf, row0}, las{Fs, Kf, row0};
+  KMajorLoader3<BN3, STAGE_B> lbr{Mr, Np, col0}, lbi{Mi, Np, col0};
+  mainloop_3m<false>(S1, S2, S3, lac, las, lbr, lbi, 0, Kf / BK, smem);
 #pragma unroll
   for (int nt = 0; nt < NTL3; ++nt) {
     const long col = col0 + acc_col3(nt);
-    const double wr = vr[col], wi = vi[col];
+    const double wr = vr[col], wi = vi[col], br = mbr[col], bi = mbi[col];
 #pragma unroll
     for (int mt = 0; mt < MT3; ++mt)
 #pragma unroll
@@ -373,7 +348,7 @@ __global__ void __launch_bounds__(m3::NT3, 1)
         const long row = row0 + acc_row3(mt, r);
         const double f = inv_rs ? inv_rs[row] : 1.0;  // planes hold rs_i phi_i: undo the row scale
         const double s1 = S1[mt][nt][r], s2 = S2[mt][nt][r];
-        const double pr = (s1 + s2) * f, pi = ((S3[mt][nt][r] - s1) + s2) * f;
+        const double pr = (s1 + s2) * f + br, pi = ((S3[mt][nt][r] - s1) + s2) * f + bi;
         U[row * Np + col] = pr * wr - pi * wi;
         Gm[row * Np + col] = pr * pr + pi * pi;
       }
@@ -394,11 +369,11 @@ __global__ void k_rgrid(const double* lam, const double* gammas, int D1, int G, 
 __global__ void __launch_bounds__(Cfg4::NTHREADS, 2)
     k_sweep(const double* U, const double* Gm, int Np, const double* R, int Gp, double inv_c, double* num, double* hs,
             long out_row0) {
+  using C = Cfg4;
   extern __shared__ double smem[];
   const long row0 = (long)blockIdx.y * BM;
   const long col0 = (long)blockIdx.x * BN;
   const bool second = blockIdx.z == 1;
-  using C = Cfg4;
   v4d acc[C::MT][C::NTL];
   zero_acc(acc);
   MMajorPlaneLoader<C> la{second ? Gm : U, Np, row0};
@@ -449,11 +424,11 @@ __global__ void k_loo_errors(const double* num, const double* hs, const double* 
   }
 }
 
-// out[c][g] = sum_blk part[blk][c][g] in block order.
-__global__ void k_sum_partials(const double* part, long nblk, long width, double* out) {
+// out[idx] = (accumulate ? out[idx] : 0) + sum_blk part[blk][idx] in block order.
+__global__ void k_sum_partials(const double* part, long nblk, long width, double* out, int accumulate = 0) {
   const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
   if (idx >= width) return;
-  double v = 0.0;
+  double v = accumulate ? out[idx] : 0.0;
   for (long b = 0; b < nblk; ++b) v += part[b * width + idx];
   out[idx] = v;
 }
@@ -503,18 +478,18 @@ __global__ void k_loo_column(const double* num, const double* hs, const double* 
 }
 
 // ------------------------------------------------------------------------------------------------
-// K8: yhat_i = Re(phi_i . beta) = Fc_i . beta_r + Fs_i . beta_i ; one wave per row.
+// K8: yhat_i = Re(phi_i . beta) = inv_rs_i (Fc_i . beta_r + Fs_i . beta_i) + Re beta[D] ; one wave per row.
 // out = yhat - y (clipped for classifiers) when y != nullptr, else yhat.
 // ------------------------------------------------------------------------------------------------
-__global__ void k_plane_gemv(const double* Fc, const double* Fs, int Kp, const double* br, const double* bi, long rows,
-                             const double* y, int is_clf, double* out, const double* inv_rs) {
+__global__ void k_plane_gemv(const double* Fc, const double* Fs, int Kf, const double* br, const double* bi, const double2* beta,
+                             int D, long rows, const double* y, int is_clf, double* out, const double* inv_rs) {
   const long row = blockIdx.x * (long)(blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
-  const double* c = Fc + row * Kp;
-  const double* s = Fs + row * Kp;
+  const double* c = Fc + row * Kf;
+  const double* s = Fs + row * Kf;
   double acc = 0.0;
-  for (int j = 2 * lane; j < Kp; j += 128) {
+  for (int j = 2 * lane; j < Kf; j += 128) {
     const double2 cv = *reinterpret_cast<const double2*>(c + j), sv = *reinterpret_cast<const double2*>(s + j);
     const double2 rv = *reinterpret_cast<const double2*>(br + j), iv = *reinterpret_cast<const double2*>(bi + j);
     acc += cv.x * rv.x + sv.x * iv.x + cv.y * rv.y + sv.y * iv.y;
@@ -522,6 +497,7 @@ __global__ void k_plane_gemv(const double* Fc, const double* Fs, int Kp, const d
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
   if (lane == 0) {
     if (inv_rs) acc *= inv_rs[row];
+    acc += beta[D].x;
     if (y) {
       double e = acc - y[row];
       if (is_clf && ((y[row] > 0 && e > 0) || (y[row] < 0 && e < 0))) e = 0.0;
@@ -598,12 +574,19 @@ __global__ void k_conj_inplace(double2* a, long n) {
   if (i < n) a[i].y = -a[i].y;
 }
 
-// beta (complex, D1) -> planes br, bi [Kp] zero padded.
-__global__ void k_split_vec(const double2* v, int D1, int Kp, double* vr, double* vi) {
+// v (complex, `len` valid entries) -> planes vr, vi [n_out] zero padded.
+__global__ void k_split_vec(const double2* v, int len, int n_out, double* vr, double* vi) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= Kp) return;
-  vr[i] = i < D1 ? v[i].x : 0.0;
-  vi[i] = i < D1 ? v[i].y : 0.0;
+  if (i >= n_out) return;
+  vr[i] = i < len ? v[i].x : 0.0;
+  vi[i] = i < len ? v[i].y : 0.0;
+}
+
+// out[i][j] = in[i][j] for j < cols (ld_in -> cols contiguous)
+__global__ void k_compact_rows(const double* in, long ld_in, long rows, int cols, double* out) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const long i = blockIdx.y;
+  if (j < cols && i < rows) out[i * cols + j] = in[i * ld_in + j];
 }
 
 }  // namespace nls

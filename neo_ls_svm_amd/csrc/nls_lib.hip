@@ -1,5 +1,5 @@
-// Host side of libneolssvm_hip.so: context, workspace, stage orchestration and the C ABI of
-// include/neolssvm_hip.h.  Device code lives in nls_gemm.h / nls_kernels.h / nls_dual.h.
+// Host side of libneolssvm_hip.so: context, workspace, stage orchestration of the primal path and the C ABI of
+// include/neolssvm_hip.h.  Device code lives in nls_gemm.h / nls_gemm3m.h / nls_kernels.h; the dual path is nls_dual.hip.
 #include "nls_host.h"
 #include "nls_kernels.h"
 #include "nls_dual_kernels.h"
@@ -11,10 +11,13 @@ std::string g_create_error;
 // ------------------------------------------------------------------------------------------------
 // Shared stage helpers
 // ------------------------------------------------------------------------------------------------
-struct MapParams {  // device-resident parameters of the affine + ORF map
-  int d = 0, dk = 0, D = 0, D1 = 0, Kp = 0, Np = 0;
+struct MapParams {  // device-resident parameters of the affine + ORF map and the padded sizes derived from D
+  int d = 0, dk = 0;    // input columns, padded to the K slice
+  int D = 0, D1 = 0;    // features, features + bias
+  int Kf = 0;           // plane columns: ceil(D / 128) * 128
+  int Np = 0;           // rotation output columns: ceil((D + 1) / 64) * 64
   double* shift = nullptr;  // d
-  double* Bs = nullptr;     // dk x Kp
+  double* Bs = nullptr;     // dk x Kf
 };
 
 static int upload_map(nls_ctx* ctx, const double* shift, const double* scale, const double* B, int d, int D,
@@ -30,50 +33,56 @@ static int upload_map(nls_ctx* ctx, const double* shift, const double* scale, co
   mp->dk = (int)round_up(d, BK);
   mp->D = D;
   mp->D1 = D + 1;
-  mp->Kp = (int)round_up(D + 2, BN);
-  mp->Np = (int)round_up(D + 1, BN);
+  mp->Kf = (int)round_up(D, BN);
+  mp->Np = (int)round_up(D + 1, m3::BN3);  // 64-wide rotation tiles; also the K of the sweep GEMM (multiple of 16)
   double *dB = nullptr, *dscale = nullptr;
   NLSCHK(ws_get_t(ctx, "map.shift", (size_t)d, &mp->shift));
   NLSCHK(ws_get_t(ctx, "map.scale", (size_t)d, &dscale));
   NLSCHK(ws_get_t(ctx, "map.B", (size_t)d * D, &dB));
-  NLSCHK(ws_get_t(ctx, "map.Bs", (size_t)mp->dk * mp->Kp, &mp->Bs));
+  NLSCHK(ws_get_t(ctx, "map.Bs", (size_t)mp->dk * mp->Kf, &mp->Bs));
   HIPCHK(ctx, hipMemcpyAsync(mp->shift, shift, sizeof(double) * d, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(ctx, hipMemcpyAsync(dscale, scale, sizeof(double) * d, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(ctx, hipMemcpyAsync(dB, B, sizeof(double) * (size_t)d * D, hipMemcpyHostToDevice, ctx->stream));
-  const long tot = (long)mp->dk * mp->Kp;
+  const long tot = (long)mp->dk * mp->Kf;
   hipLaunchKernelGGL(k_build_Bs, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, dB, dscale, d, D,
-                     mp->dk, mp->Kp, mp->Bs);
+                     mp->dk, mp->Kf, mp->Bs);
   HIPCHK(ctx, hipGetLastError());
   return NLS_OK;
 }
 
-static long rot_grid(nls_ctx* ctx, long tiles_r, long tiles_c) {
-  return ctx->rot_pr > 0 ? xcd_patch_grid(tiles_r, tiles_c, ctx->rot_pr, ctx->rot_pc) : tiles_r * tiles_c;
-}
-
-constexpr size_t SMEM_REAL = 2 * 2 * TILE_DOUBLES * sizeof(double);  // double-buffered A, B
-constexpr size_t SMEM_CPLX = 2 * 4 * TILE_DOUBLES * sizeof(double);  // double-buffered Ac, As, Br, Bi (144 KiB)
+constexpr size_t SMEM_REAL = 2 * 2 * TILE_DOUBLES * sizeof(double);  // double-buffered A, B of the real tile engine
 
 // K1 into split planes for `rows` rows starting at Xchunk.
 static int launch_featuremap_planes(nls_ctx* ctx, const MapParams& mp, const double* Xchunk, long rows, long rows_pad,
-                                    const double* rowscale, const double* target, double* Fc, double* Fs) {
+                                    const double* rowscale, double* Fc, double* Fs) {
   FeatureMapParams p;
   p.X = Xchunk;
   p.shift = mp.shift;
   p.Bs = mp.Bs;
   p.rowscale = rowscale;
-  p.target = target;
   p.rows = rows;
   p.d = mp.d;
   p.dk = mp.dk;
   p.D = mp.D;
-  p.Kp = mp.Kp;
+  p.Kf = mp.Kf;
   p.inv_sqrt_D = 1.0 / std::sqrt((double)mp.D);
   p.Fc = Fc;
   p.Fs = Fs;
   p.phi = nullptr;
-  dim3 grid((unsigned)(mp.Kp / BN), (unsigned)(rows_pad / BM));
+  dim3 grid((unsigned)(mp.Kf / BN), (unsigned)(rows_pad / BM));
   hipLaunchKernelGGL(k_featuremap<false>, grid, dim3(Cfg4::NTHREADS), SMEM_REAL, ctx->stream, p);
+  HIPCHK(ctx, hipGetLastError());
+  return NLS_OK;
+}
+
+// K4: U, Gm for `rows_pad` rows of planes against the rotation planes Mr, Mi (+ bias row mbr, mbi).
+static int launch_rotate(nls_ctx* ctx, const MapParams& mp, const double* Fc, const double* Fs, const double* Mr, const double* Mi,
+                         const double* mbr, const double* mbi, const double* vr, const double* vi, double* U, double* Gm,
+                         const double* inv_rs, long rows_pad) {
+  const long tiles_r = rows_pad / BM, tiles_c = mp.Np / m3::BN3;
+  const long grid = ctx->rot_pr > 0 ? xcd_patch_grid(tiles_r, tiles_c, ctx->rot_pr, ctx->rot_pc) : tiles_r * tiles_c;
+  hipLaunchKernelGGL(k_rotate3, dim3((unsigned)grid), dim3(m3::NT3), m3::SMEM3, ctx->stream, Fc, Fs, mp.Kf, Mr, Mi, mbr, mbi, mp.Np,
+                     vr, vi, U, Gm, inv_rs, tiles_r, ctx->rot_pr, ctx->rot_pc);
   HIPCHK(ctx, hipGetLastError());
   return NLS_OK;
 }
@@ -90,8 +99,9 @@ static long pick_row_chunk_bytes(nls_ctx* ctx, long n, size_t per_row, size_t fi
   return round_up((n_pad + nchunks - 1) / nchunks, BM);
 }
 static long pick_row_chunk(nls_ctx* ctx, long n, const MapParams& mp, size_t fixed_bytes) {
-  return pick_row_chunk_bytes(ctx, n, 16ull * ((size_t)mp.Kp + (size_t)mp.Np), fixed_bytes);
+  return pick_row_chunk_bytes(ctx, n, 16ull * ((size_t)mp.Kf + (size_t)mp.Np), fixed_bytes);
 }
+
 // ------------------------------------------------------------------------------------------------
 // Context API
 // ------------------------------------------------------------------------------------------------
@@ -122,25 +132,22 @@ extern "C" int nls_ctx_create(int device, nls_ctx** out) {
     return rc;
   }
   ctx->hbm_bytes = prop.totalGlobalMem;
-  if (const char* e4 = std::getenv("NLS_COMPLEX_4M")) ctx->use_4m = e4[0] == '1';
+  ctx->cus = prop.multiProcessorCount;
   if (const char* ep = std::getenv("NLS_ROT_PATCH")) std::sscanf(ep, "%dx%d", &ctx->rot_pr, &ctx->rot_pc);
   if (const char* er = std::getenv("NLS_NO_RESIDENT_PLANES")) ctx->no_resident = er[0] == '1';
-  if (const char* eg = std::getenv("NLS_GRAM_PATCH")) ctx->gram_patches = eg[0] == '1';
-  ctx->cus = prop.multiProcessorCount;
   if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess)
     return bail("hipStreamCreate", hipGetErrorString(e));
   if (rocblas_create_handle(&ctx->blas) != rocblas_status_success) return bail("rocblas_create_handle", "status != success");
   rocblas_set_stream(ctx->blas, ctx->stream);
-  // Opt in to > 64 KiB of dynamic LDS for the complex tile kernels.
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gram), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_CPLX);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_rotate), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_CPLX);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gram3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)m3::SMEM3);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_rotate3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)m3::SMEM3);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_REAL);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_featuremap<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_REAL);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_featuremap<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_REAL);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<EPI_STORE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_REAL);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<EPI_RBF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_REAL);
+  // Opt in to > 64 KiB of dynamic LDS for the tile kernels.
+  auto lds = [](const void* f, size_t bytes) { (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); };
+  lds(reinterpret_cast<const void*>(k_gram3), m3::SMEM3);
+  lds(reinterpret_cast<const void*>(k_rotate3), m3::SMEM3);
+  lds(reinterpret_cast<const void*>(k_sweep), SMEM_REAL);
+  lds(reinterpret_cast<const void*>(k_featuremap<false>), SMEM_REAL);
+  lds(reinterpret_cast<const void*>(k_featuremap<true>), SMEM_REAL);
+  lds(reinterpret_cast<const void*>(k_gemm<EPI_STORE>), SMEM_REAL);
+  lds(reinterpret_cast<const void*>(k_gemm<EPI_RBF>), SMEM_REAL);
   *out = ctx;
   return NLS_OK;
 }
@@ -206,9 +213,7 @@ extern "C" int nls_device_info(nls_ctx* ctx, char* name, int name_len, int* comp
   if (!ctx) return NLS_ERR_ARG;
   hipDeviceProp_t prop;
   HIPCHK(ctx, hipGetDeviceProperties(&prop, ctx->device));
-  if (name && name_len > 0) {
-    std::snprintf(name, (size_t)name_len, "%s (%s)", prop.name, prop.gcnArchName);
-  }
+  if (name && name_len > 0) std::snprintf(name, (size_t)name_len, "%s (%s)", prop.name, prop.gcnArchName);
   if (compute_units) *compute_units = prop.multiProcessorCount;
   if (hbm_bytes) *hbm_bytes = prop.totalGlobalMem;
   return NLS_OK;
@@ -240,16 +245,15 @@ extern "C" int nls_featuremap(nls_ctx* ctx, const double* X, int64_t n, int d, c
     p.shift = mp.shift;
     p.Bs = mp.Bs;
     p.rowscale = nullptr;
-    p.target = nullptr;
     p.rows = rows;
     p.d = mp.d;
     p.dk = mp.dk;
     p.D = mp.D;
-    p.Kp = mp.Kp;
+    p.Kf = mp.Kf;
     p.inv_sqrt_D = 1.0 / std::sqrt((double)D);
     p.Fc = p.Fs = nullptr;
     p.phi = out_dev ? phi + 2 * r0 * mp.D1 : dphi;
-    dim3 grid((unsigned)(mp.Np / BN), (unsigned)(round_up(rows, BM) / BM));
+    dim3 grid((unsigned)(round_up(mp.D1, BN) / BN), (unsigned)(round_up(rows, BM) / BM));  // covers the bias column D
     hipLaunchKernelGGL(k_featuremap<true>, grid, dim3(Cfg4::NTHREADS), SMEM_REAL, ctx->stream, p);
     HIPCHK(ctx, hipGetLastError());
     if (!out_dev)
@@ -273,26 +277,26 @@ struct PrimalState {
   double* inv_rs = nullptr;  // n_pad  1 / rs (0 beyond n)
   bool resident = false;     // feature planes of ALL rows stay in HBM (one K1 pass per fit)
   long plane_rows = 0;       // rows of the plane buffers (rc, or nchunks * rc when resident)
-  double* sy = nullptr;      // n_pad  s_norm * y
-  double *Fc = nullptr, *Fs = nullptr;  // rc x Kp
+  double *Fc = nullptr, *Fs = nullptr;  // plane_rows x Kf
   int nt = 0, ntri = 0;
-  double* gacc = nullptr;  // ntri x 2 x 128 x 128 tile-packed extended Gram
+  size_t tile_elems = 0;     // ntri * 2 * 128 * 128
+  size_t gram_elems = 0;     // tile_elems + border (4 Kf + 2, padded to 8)
+  double* gacc = nullptr;    // packed Gram tiles followed by the border record: the all-reduce payload
 };
 
-static inline double* planes_c(const PrimalState& st, long r0) { return st.Fc + (st.resident ? r0 * st.mp.Kp : 0); }
-static inline double* planes_s(const PrimalState& st, long r0) { return st.Fs + (st.resident ? r0 * st.mp.Kp : 0); }
+static inline double* planes_c(const PrimalState& st, long r0) { return st.Fc + (st.resident ? r0 * st.mp.Kf : 0); }
+static inline double* planes_s(const PrimalState& st, long r0) { return st.Fs + (st.resident ? r0 * st.mp.Kf : 0); }
 
-// Primal fit: keep the feature planes of all rows resident when they fit next to everything else; then only the
-// rotation outputs U, Gm are chunked.
+// Keep the feature planes of all rows resident when they fit next to everything else; then only the rotation
+// outputs U, Gm are chunked.
 static void plan_primal_chunks(nls_ctx* ctx, PrimalState& st, size_t fixed_bytes) {
   const size_t limit = ctx->ws_limit ? ctx->ws_limit : (size_t)(0.6 * (double)ctx->hbm_bytes);
-  const size_t planes_all = 16ull * (size_t)(st.n_pad + BM) * st.mp.Kp;
+  const size_t planes_all = 16ull * (size_t)(st.n_pad + BM) * st.mp.Kf;
   const size_t min_rot = 16ull * st.mp.Np * (size_t)std::min<long>(st.n_pad, 32768);
   if (!ctx->no_resident && fixed_bytes + planes_all + min_rot <= limit) {
     st.resident = true;
     st.rc = pick_row_chunk_bytes(ctx, st.n, 16ull * st.mp.Np, fixed_bytes + planes_all);
-    const long nchunks = (st.n_pad + st.rc - 1) / st.rc;
-    st.plane_rows = nchunks * st.rc;
+    st.plane_rows = ((st.n_pad + st.rc - 1) / st.rc) * st.rc;
   } else {
     st.resident = false;
     st.rc = pick_row_chunk(ctx, st.n, st.mp, fixed_bytes);
@@ -301,8 +305,7 @@ static void plan_primal_chunks(nls_ctx* ctx, PrimalState& st, size_t fixed_bytes
 }
 
 // Normalise the weights by the global sum (_neo_ls_svm.py:110) and set c.
-static int primal_prepare(nls_ctx* ctx, PrimalState& st, const double* X, const double* y, const double* s, long n, int d,
-                          double* timings) {
+static int primal_prepare(nls_ctx* ctx, PrimalState& st, const double* X, const double* y, const double* s, long n, int d) {
   st.n = n;
   st.n_pad = round_up(std::max<long>(n, 1), BM);
   {
@@ -318,7 +321,7 @@ static int primal_prepare(nls_ctx* ctx, PrimalState& st, const double* X, const 
   HIPCHK(ctx, hipMemsetAsync(sums, 0, 4 * sizeof(double), ctx->stream));
   if (n > 0) {
     hipLaunchKernelGGL(k_weight_sums, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, st.ds, st.dy, n, part);
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(64), 0, ctx->stream, part, nblk, 2L, sums);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(64), 0, ctx->stream, part, nblk, 2L, sums, 0);
     HIPCHK(ctx, hipGetLastError());
   }
   double hn = (double)n;
@@ -337,7 +340,6 @@ static int primal_prepare(nls_ctx* ctx, PrimalState& st, const double* X, const 
     return fail(ctx, NLS_ERR_ARG, "sample weights must have a positive finite sum (got %g)", st.s_sum);
   st.c = 1.0 / (st.n_total * (double)st.mp.D1);
   NLSCHK(ws_get_t(ctx, "pre.s_norm", (size_t)st.n_pad, &st.s_norm));
-  NLSCHK(ws_get_t(ctx, "pre.sy", (size_t)st.n_pad, &st.sy));
   NLSCHK(ws_get_t(ctx, "pre.rs", (size_t)st.n_pad + BM, &st.rs));
   NLSCHK(ws_get_t(ctx, "pre.inv_rs", (size_t)st.n_pad + BM, &st.inv_rs));
   HIPCHK(ctx, hipMemsetAsync(st.s_norm, 0, st.n_pad * sizeof(double), ctx->stream));
@@ -348,35 +350,37 @@ static int primal_prepare(nls_ctx* ctx, PrimalState& st, const double* X, const 
     hipLaunchKernelGGL(k_row_scales, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, st.ds, 1.0 / st.s_sum, n, st.rs, st.inv_rs);
     HIPCHK(ctx, hipGetLastError());
   }
-  (void)timings;
   return NLS_OK;
 }
 
-// Phase A: extended Gram of F = s o [phi, y] accumulated over row chunks, all-reduced across ranks.
+// Phase A: normal equations (packed Gram tiles of F = S phi + border vectors) accumulated over row chunks and
+// all-reduced across ranks.
 static int primal_gram_phase(nls_ctx* ctx, PrimalState& st, double* timings) {
   const MapParams& mp = st.mp;
-  st.nt = mp.Kp / BM;
+  st.nt = mp.Kf / BM;
   st.ntri = st.nt * (st.nt + 1) / 2;
-  const size_t tile_elems_total = (size_t)st.ntri * 2 * BM * BN;
-  NLSCHK(ws_get_t(ctx, "gram.acc", tile_elems_total, &st.gacc));
-  HIPCHK(ctx, hipMemsetAsync(st.gacc, 0, tile_elems_total * sizeof(double), ctx->stream));
+  st.tile_elems = (size_t)st.ntri * 2 * BM * BN;
+  const long bwidth = 4L * mp.Kf + 2;
+  st.gram_elems = st.tile_elems + (size_t)round_up(bwidth, 8);
+  NLSCHK(ws_get_t(ctx, "gram.acc", st.gram_elems, &st.gacc));
+  HIPCHK(ctx, hipMemsetAsync(st.gacc, 0, st.gram_elems * sizeof(double), ctx->stream));
   if (st.plane_rows < st.rc) st.plane_rows = st.rc;
-  NLSCHK(ws_get_t(ctx, "chunk.Fc", (size_t)st.plane_rows * mp.Kp, &st.Fc));
-  NLSCHK(ws_get_t(ctx, "chunk.Fs", (size_t)st.plane_rows * mp.Kp, &st.Fs));
-  // Row split so that one launch fills the chip several times over.
-  const long target_blocks = 8L * ctx->cus;
-  long nsplit = std::max<long>(1, (target_blocks + st.ntri - 1) / st.ntri);
-  nsplit = std::min<long>(nsplit, std::max<long>(1, st.rc / (4 * BK)));
-  const long rows_per_split = round_up((st.rc + nsplit - 1) / nsplit, BK);
-  nsplit = (st.rc + rows_per_split - 1) / rows_per_split;
-  double* slab = nullptr;
-  NLSCHK(ws_get_t(ctx, "gram.slab", (size_t)nsplit * tile_elems_total, &slab));
+  NLSCHK(ws_get_t(ctx, "chunk.Fc", (size_t)st.plane_rows * mp.Kf, &st.Fc));
+  NLSCHK(ws_get_t(ctx, "chunk.Fs", (size_t)st.plane_rows * mp.Kf, &st.Fs));
+  // Row split so that one launch fills the chip several times over (one 256-thread workgroup per CU).
+  const long half_tiles = 2L * st.ntri;
+  long nsplit = std::max<long>(1, (16L * ctx->cus + half_tiles - 1) / half_tiles);
+  nsplit = std::min<long>(nsplit, std::max<long>(1, st.rc / (8 * BK)));
+  double *slab = nullptr, *bpart = nullptr;
+  NLSCHK(ws_get_t(ctx, "gram.slab", (size_t)nsplit * st.tile_elems, &slab));
+  const long bsplit_max = 256;
+  NLSCHK(ws_get_t(ctx, "gram.bpart", (size_t)bsplit_max * bwidth, &bpart));
   for (long r0 = 0; r0 < st.n; r0 += st.rc) {
     const long rows = std::min<long>(st.rc, st.n - r0);
     const long rows_pad = round_up(rows, BM);
     {
       SpanGuard g(ctx, NLS_T_FEATUREMAP);
-      NLSCHK(launch_featuremap_planes(ctx, mp, st.dX + r0 * mp.d, rows, rows_pad, st.rs + r0, st.dy + r0, planes_c(st, r0), planes_s(st, r0)));
+      NLSCHK(launch_featuremap_planes(ctx, mp, st.dX + r0 * mp.d, rows, rows_pad, st.rs + r0, planes_c(st, r0), planes_s(st, r0)));
       if (timings) {
         timings[NLS_T_FEATUREMAP_LAUNCHES] += 1;
         timings[NLS_T_FEATUREMAP_FLOPS] += 2.0 * rows * mp.d * mp.D;
@@ -386,17 +390,19 @@ static int primal_gram_phase(nls_ctx* ctx, PrimalState& st, double* timings) {
       SpanGuard g(ctx, NLS_T_GRAM);
       const long rps = round_up((rows_pad + nsplit - 1) / nsplit, BK);
       const long ns = (rows_pad + rps - 1) / rps;
-      if (ctx->use_4m)
-        hipLaunchKernelGGL(k_gram, dim3((unsigned)(st.ntri * ns)), dim3(Cfg8::NTHREADS), SMEM_CPLX, ctx->stream, planes_c(st, r0),
-                           planes_s(st, r0), mp.Kp, rows_pad, st.ntri, rps, slab);
-      else {
-        const long bps = ctx->gram_patches ? xcd_patch_grid(st.nt, 2L * st.nt, 4, 8) : 2L * st.ntri;
-        hipLaunchKernelGGL(k_gram3, dim3((unsigned)(bps * ns)), dim3(m3::NT3), m3::SMEM3, ctx->stream, planes_c(st, r0), planes_s(st, r0),
-                           mp.Kp, rows_pad, st.ntri, rps, slab, st.nt, bps);
-      }
+      hipLaunchKernelGGL(k_gram3, dim3((unsigned)(half_tiles * ns)), dim3(m3::NT3), m3::SMEM3, ctx->stream, planes_c(st, r0),
+                         planes_s(st, r0), mp.Kf, rows_pad, st.ntri, rps, slab);
       HIPCHK(ctx, hipGetLastError());
-      hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)((tile_elems_total + 255) / 256)), dim3(256), 0, ctx->stream, slab,
-                         (int)ns, (long)tile_elems_total, st.gacc);
+      hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)((st.tile_elems + 255) / 256)), dim3(256), 0, ctx->stream, slab, (int)ns,
+                         (long)st.tile_elems, st.gacc);
+      // Border: bias column and right-hand side (HBM-bound column sums of the same planes).
+      const long bsplit = std::min<long>(bsplit_max, std::max<long>(1, rows / 512));
+      const long brps = (rows + bsplit - 1) / bsplit;
+      const long bns = (rows + brps - 1) / brps;
+      hipLaunchKernelGGL(k_border, dim3((unsigned)(mp.Kf / 128), (unsigned)bns), dim3(256), 0, ctx->stream, planes_c(st, r0),
+                         planes_s(st, r0), mp.Kf, st.rs + r0, st.dy + r0, rows, brps, bpart);
+      hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)((bwidth + 255) / 256)), dim3(256), 0, ctx->stream, bpart, bns, bwidth,
+                         st.gacc + st.tile_elems, 1);
       HIPCHK(ctx, hipGetLastError());
       if (timings) {
         timings[NLS_T_GRAM_LAUNCHES] += 1;
@@ -406,8 +412,17 @@ static int primal_gram_phase(nls_ctx* ctx, PrimalState& st, double* timings) {
   }
   {
     SpanGuard g(ctx, NLS_T_ALLREDUCE);
-    NLSCHK(do_allreduce(ctx, st.gacc, tile_elems_total));
+    NLSCHK(do_allreduce(ctx, st.gacc, st.gram_elems));
   }
+  return NLS_OK;
+}
+
+static int assemble_A(nls_ctx* ctx, const PrimalState& st, double scale, double2* Acm, double2* b) {
+  const int D1 = st.mp.D1;
+  dim3 grid((unsigned)((D1 + 255) / 256), (unsigned)(D1 + 1));
+  hipLaunchKernelGGL(k_assemble_A, grid, dim3(256), 0, ctx->stream, st.gacc, st.gacc + st.tile_elems, st.mp.D, st.mp.Kf, scale, Acm,
+                     (long)D1, b);
+  HIPCHK(ctx, hipGetLastError());
   return NLS_OK;
 }
 
@@ -418,7 +433,7 @@ extern "C" int nls_gram_only(nls_ctx* ctx, const double* X, const double* y, con
   HIPCHK(ctx, hipSetDevice(ctx->device));
   PrimalState st;
   NLSCHK(upload_map(ctx, shift, scale, B, d, D, &st.mp));
-  NLSCHK(primal_prepare(ctx, st, X, y, s, n, d, nullptr));
+  NLSCHK(primal_prepare(ctx, st, X, y, s, n, d));
   st.rc = pick_row_chunk(ctx, n, st.mp, 0);
   st.plane_rows = st.rc;
   NLSCHK(primal_gram_phase(ctx, st, nullptr));
@@ -427,8 +442,7 @@ extern "C" int nls_gram_only(nls_ctx* ctx, const double* X, const double* y, con
   NLSCHK(ws_get_t(ctx, "evd.A", (size_t)D1 * D1, &Acm));
   NLSCHK(ws_get_t(ctx, "evd.Q", (size_t)D1 * D1, &Arm));
   NLSCHK(ws_get_t(ctx, "evd.b", (size_t)D1, &db));
-  dim3 grid((unsigned)((D1 + 255) / 256), (unsigned)(D1 + 1));
-  hipLaunchKernelGGL(k_assemble_A, grid, dim3(256), 0, ctx->stream, st.gacc, D1, 1.0, Acm, (long)D1, db);
+  NLSCHK(assemble_A(ctx, st, 1.0, Acm, db));
   hipLaunchKernelGGL(k_cm_to_rm, dim3((unsigned)((D1 + 255) / 256), (unsigned)D1), dim3(256), 0, ctx->stream, Acm, (long)D1, D1,
                      false, Arm);
   HIPCHK(ctx, hipGetLastError());
@@ -438,22 +452,24 @@ extern "C" int nls_gram_only(nls_ctx* ctx, const double* X, const double* y, con
   return NLS_OK;
 }
 
-
-// Row-major complex (D1 x D1, host layout) -> B-operand planes [Kp x Np], zero padded.
-__global__ void k_build_planes_rm(const double2* Qrm, int D1, int Kp, int Np, double* Qr, double* Qi) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  const int i = blockIdx.y;
-  if (k >= Np) return;
-  double2 v = make_double2(0.0, 0.0);
-  if (i < D1 && k < D1) v = Qrm[(long)i * D1 + k];
-  Qr[(long)i * Np + k] = v.x;
-  Qi[(long)i * Np + k] = v.y;
+// Device buffers of a rotation (B-operand planes, bias row, epilogue vector).
+struct RotBuffers {
+  double *Mr = nullptr, *Mi = nullptr, *mbr = nullptr, *mbi = nullptr, *vr = nullptr, *vi = nullptr;
+};
+static int rot_buffers(nls_ctx* ctx, const MapParams& mp, RotBuffers* rb) {
+  NLSCHK(ws_get_t(ctx, "rot.Mr", (size_t)mp.Kf * mp.Np, &rb->Mr));
+  NLSCHK(ws_get_t(ctx, "rot.Mi", (size_t)mp.Kf * mp.Np, &rb->Mi));
+  NLSCHK(ws_get_t(ctx, "rot.mbr", (size_t)mp.Np, &rb->mbr));
+  NLSCHK(ws_get_t(ctx, "rot.mbi", (size_t)mp.Np, &rb->mbi));
+  NLSCHK(ws_get_t(ctx, "rot.vr", (size_t)mp.Np, &rb->vr));
+  NLSCHK(ws_get_t(ctx, "rot.vi", (size_t)mp.Np, &rb->vi));
+  return NLS_OK;
 }
-// out[i][j] = in[i][j] for j < cols (ld_in -> cols contiguous)
-__global__ void k_compact_rows(const double* in, long ld_in, long rows, int cols, double* out) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  const long i = blockIdx.y;
-  if (j < cols && i < rows) out[i * cols + j] = in[i * ld_in + j];
+static int build_rot_planes(nls_ctx* ctx, const MapParams& mp, const double2* M, long si, long sk, bool upper, const RotBuffers& rb) {
+  hipLaunchKernelGGL(k_build_rot_planes, dim3((unsigned)((mp.Np + 255) / 256), (unsigned)(mp.Kf + 1)), dim3(256), 0, ctx->stream, M, si,
+                     sk, mp.D, mp.Kf, mp.Np, upper, rb.Mr, rb.Mi, rb.mbr, rb.mbi);
+  HIPCHK(ctx, hipGetLastError());
+  return NLS_OK;
 }
 
 extern "C" int nls_rotate_only(nls_ctx* ctx, const double* X, int64_t n, int d, const double* shift, const double* scale,
@@ -463,44 +479,36 @@ extern "C" int nls_rotate_only(nls_ctx* ctx, const double* X, int64_t n, int d, 
   HIPCHK(ctx, hipSetDevice(ctx->device));
   MapParams mp;
   NLSCHK(upload_map(ctx, shift, scale, B, d, D, &mp));
-  const int D1 = mp.D1, Kp = mp.Kp, Np = mp.Np;
+  const int D1 = mp.D1, Kf = mp.Kf, Np = mp.Np;
   const double* dX = nullptr;
   NLSCHK(resident(ctx, "in.X", X, (size_t)n * d, &dX));
   const long rc = pick_row_chunk(ctx, n, mp, 4ull * D1 * D1 * 16);
-  double *Fc = nullptr, *Fs = nullptr, *Qr = nullptr, *Qi = nullptr, *vr = nullptr, *vi = nullptr, *U = nullptr, *Gm = nullptr, *cmp = nullptr;
+  double *Fc = nullptr, *Fs = nullptr, *U = nullptr, *Gm = nullptr, *cmp = nullptr;
   double2 *dQ = nullptr, *dv = nullptr;
-  NLSCHK(ws_get_t(ctx, "chunk.Fc", (size_t)rc * Kp, &Fc));
-  NLSCHK(ws_get_t(ctx, "chunk.Fs", (size_t)rc * Kp, &Fs));
+  RotBuffers rb;
+  NLSCHK(ws_get_t(ctx, "chunk.Fc", (size_t)rc * Kf, &Fc));
+  NLSCHK(ws_get_t(ctx, "chunk.Fs", (size_t)rc * Kf, &Fs));
   NLSCHK(ws_get_t(ctx, "evd.Q", (size_t)D1 * D1, &dQ));
   NLSCHK(ws_get_t(ctx, "chol.beta", (size_t)D1, &dv));
-  NLSCHK(ws_get_t(ctx, "rot.Qr", (size_t)Kp * Np, &Qr));
-  NLSCHK(ws_get_t(ctx, "rot.Qi", (size_t)Kp * Np, &Qi));
-  NLSCHK(ws_get_t(ctx, "rot.vr", (size_t)Np, &vr));
-  NLSCHK(ws_get_t(ctx, "rot.vi", (size_t)Np, &vi));
+  NLSCHK(rot_buffers(ctx, mp, &rb));
   NLSCHK(ws_get_t(ctx, "chunk.U", (size_t)rc * Np, &U));
   NLSCHK(ws_get_t(ctx, "chunk.Gm", (size_t)rc * Np, &Gm));
   if (Uout || Gmout) NLSCHK(ws_get_t(ctx, "rot.compact", (size_t)rc * D1, &cmp));
   HIPCHK(ctx, hipMemcpyAsync(dQ, Q, sizeof(double2) * (size_t)D1 * D1, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(ctx, hipMemcpyAsync(dv, v, sizeof(double2) * D1, hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(k_build_planes_rm, dim3((unsigned)((Np + 255) / 256), (unsigned)Kp), dim3(256), 0, ctx->stream, dQ, D1, Kp, Np, Qr, Qi);
-  hipLaunchKernelGGL(k_split_vec, dim3((unsigned)((Np + 255) / 256)), dim3(256), 0, ctx->stream, dv, D1, Np, vr, vi);
+  NLSCHK(build_rot_planes(ctx, mp, dQ, (long)D1, 1L, false, rb));  // row-major host layout
+  hipLaunchKernelGGL(k_split_vec, dim3((unsigned)((Np + 255) / 256)), dim3(256), 0, ctx->stream, dv, D1, Np, rb.vr, rb.vi);
   HIPCHK(ctx, hipGetLastError());
   for (long r0 = 0; r0 < n; r0 += rc) {
     const long rows = std::min<long>(rc, n - r0);
     const long rows_pad = round_up(rows, BM);
-    NLSCHK(launch_featuremap_planes(ctx, mp, dX + r0 * d, rows, rows_pad, nullptr, nullptr, Fc, Fs));
-    if (ctx->use_4m)
-      hipLaunchKernelGGL(k_rotate, dim3((unsigned)(Np / BN), (unsigned)(rows_pad / BM)), dim3(Cfg8::NTHREADS), SMEM_CPLX, ctx->stream, Fc, Fs,
-                         Kp, Qr, Qi, Np, vr, vi, U, Gm, (const double*)nullptr);
-    else
-      hipLaunchKernelGGL(k_rotate3, dim3((unsigned)rot_grid(ctx, rows_pad / BM, Np / m3::BN3)), dim3(m3::NT3), m3::SMEM3, ctx->stream, Fc,
-                         Fs, Kp, Qr, Qi, Np, vr, vi, U, Gm, (const double*)nullptr, rows_pad / BM, ctx->rot_pr, ctx->rot_pc);
-    HIPCHK(ctx, hipGetLastError());
+    NLSCHK(launch_featuremap_planes(ctx, mp, dX + r0 * d, rows, rows_pad, nullptr, Fc, Fs));
+    NLSCHK(launch_rotate(ctx, mp, Fc, Fs, rb.Mr, rb.Mi, rb.mbr, rb.mbi, rb.vr, rb.vi, U, Gm, nullptr, rows_pad));
     for (int which = 0; which < 2; ++which) {
       double* dst = which ? Gmout : Uout;
       if (!dst) continue;
-      hipLaunchKernelGGL(k_compact_rows, dim3((unsigned)((D1 + 255) / 256), (unsigned)rows), dim3(256), 0, ctx->stream, which ? Gm : U, (long)Np,
-                         rows, D1, cmp);
+      hipLaunchKernelGGL(k_compact_rows, dim3((unsigned)((D1 + 255) / 256), (unsigned)rows), dim3(256), 0, ctx->stream, which ? Gm : U,
+                         (long)Np, rows, D1, cmp);
       HIPCHK(ctx, hipGetLastError());
       HIPCHK(ctx, hipMemcpyAsync(dst + r0 * D1, cmp, sizeof(double) * (size_t)rows * D1, hipMemcpyDeviceToHost, ctx->stream));
       HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -528,45 +536,40 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
   const int G = a->G, is_clf = a->is_classifier ? 1 : 0;
   NLSCHK(upload_map(ctx, a->shift, a->scale, a->B, a->d, a->D, &st.mp));
   const MapParams& mp = st.mp;
-  const int D1 = mp.D1, Kp = mp.Kp, Np = mp.Np;
+  const int D = mp.D, D1 = mp.D1, Kf = mp.Kf, Np = mp.Np;
   const int Gp = (int)round_up(G, BN);
-  NLSCHK(primal_prepare(ctx, st, a->X, a->y, a->s, n, a->d, tm));
-  const size_t fixed = 2ull * st.n_pad * Gp * 8 + 6ull * D1 * D1 * 16 + 2ull * Kp * Np * 8 + (size_t)Np * Gp * 8;
+  NLSCHK(primal_prepare(ctx, st, a->X, a->y, a->s, n, a->d));
+  const size_t fixed = 2ull * st.n_pad * Gp * 8 + 6ull * D1 * D1 * 16 + 2ull * Kf * Np * 8 + (size_t)Np * Gp * 8;
   plan_primal_chunks(ctx, st, fixed);
   tm[NLS_T_ROW_CHUNK] = (double)st.rc;
 
-  // ---- phase A: Gram -------------------------------------------------------------------------
+  // ---- phase A: normal equations ---------------------------------------------------------------
   NLSCHK(primal_gram_phase(ctx, st, tm));
 
   // ---- phase B: EVD of A / c (P4) --------------------------------------------------------------
   double2 *Acm = nullptr, *Qcm = nullptr, *db = nullptr;
-  double *lam = nullptr, *evd_e = nullptr, *Qr = nullptr, *Qi = nullptr, *vr = nullptr, *vi = nullptr, *dgam = nullptr, *R = nullptr;
+  double *lam = nullptr, *evd_e = nullptr, *dgam = nullptr, *R = nullptr;
   rocblas_int* dinfo = nullptr;
+  RotBuffers rb;
   NLSCHK(ws_get_t(ctx, "evd.A", (size_t)D1 * D1, &Acm));
   NLSCHK(ws_get_t(ctx, "evd.Q", (size_t)D1 * D1, &Qcm));
   NLSCHK(ws_get_t(ctx, "evd.b", (size_t)D1, &db));
   NLSCHK(ws_get_t(ctx, "evd.lam", (size_t)D1, &lam));
   NLSCHK(ws_get_t(ctx, "evd.e", (size_t)D1, &evd_e));
   NLSCHK(ws_get_t(ctx, "evd.info", 4, &dinfo));
-  NLSCHK(ws_get_t(ctx, "rot.Qr", (size_t)Kp * Np, &Qr));
-  NLSCHK(ws_get_t(ctx, "rot.Qi", (size_t)Kp * Np, &Qi));
-  NLSCHK(ws_get_t(ctx, "rot.vr", (size_t)Np, &vr));
-  NLSCHK(ws_get_t(ctx, "rot.vi", (size_t)Np, &vi));
+  NLSCHK(rot_buffers(ctx, mp, &rb));
   NLSCHK(ws_get_t(ctx, "sweep.gammas", (size_t)G, &dgam));
   NLSCHK(ws_get_t(ctx, "sweep.R", (size_t)Np * Gp, &R));
   HIPCHK(ctx, hipMemcpyAsync(dgam, a->gammas, sizeof(double) * G, hipMemcpyHostToDevice, ctx->stream));
   {
     SpanGuard g(ctx, NLS_T_EVD);
-    dim3 grid((unsigned)((D1 + 255) / 256), (unsigned)(D1 + 1));
-    hipLaunchKernelGGL(k_assemble_A, grid, dim3(256), 0, ctx->stream, st.gacc, D1, 1.0, Acm, (long)D1, db);
-    hipLaunchKernelGGL(k_assemble_A, grid, dim3(256), 0, ctx->stream, st.gacc, D1, 1.0 / st.c, Qcm, (long)D1, (double2*)nullptr);
-    HIPCHK(ctx, hipGetLastError());
+    NLSCHK(assemble_A(ctx, st, 1.0, Acm, db));
+    NLSCHK(assemble_A(ctx, st, 1.0 / st.c, Qcm, nullptr));
     BLASCHK(ctx, rocsolver_zheevd(ctx->blas, rocblas_evect_original, rocblas_fill_lower, D1,
                                   reinterpret_cast<rocblas_double_complex*>(Qcm), D1, lam, evd_e, dinfo));
     NLSCHK(check_info(ctx, dinfo, "rocsolver_zheevd"));
-    hipLaunchKernelGGL(k_build_Q_planes, dim3((unsigned)((Np + 255) / 256), (unsigned)Kp), dim3(256), 0, ctx->stream, Qcm, (long)D1,
-                       D1, Kp, Np, Qr, Qi);
-    hipLaunchKernelGGL(k_compute_v, dim3((unsigned)Np), dim3(256), 0, ctx->stream, Qcm, (long)D1, db, D1, 1.0 / st.c, Np, vr, vi);
+    NLSCHK(build_rot_planes(ctx, mp, Qcm, 1L, (long)D1, false, rb));  // column-major Q
+    hipLaunchKernelGGL(k_compute_v, dim3((unsigned)Np), dim3(256), 0, ctx->stream, Qcm, (long)D1, db, D1, 1.0 / st.c, rb.vr, rb.vi);
     const long tot = (long)Np * Gp;
     hipLaunchKernelGGL(k_rgrid, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, lam, dgam, D1, G, Np, Gp, R);
     HIPCHK(ctx, hipGetLastError());
@@ -583,26 +586,21 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
     const long rows_pad = round_up(rows, BM);
     if (!st.resident) {
       SpanGuard g(ctx, NLS_T_FEATUREMAP);
-      NLSCHK(launch_featuremap_planes(ctx, mp, st.dX + r0 * mp.d, rows, rows_pad, st.rs + r0, st.dy + r0, st.Fc, st.Fs));
+      NLSCHK(launch_featuremap_planes(ctx, mp, st.dX + r0 * mp.d, rows, rows_pad, st.rs + r0, st.Fc, st.Fs));
       tm[NLS_T_FEATUREMAP_LAUNCHES] += 1;
       tm[NLS_T_FEATUREMAP_FLOPS] += 2.0 * rows * mp.d * mp.D;
     }
     {
       SpanGuard g(ctx, NLS_T_ROTATE);
-      if (ctx->use_4m)
-        hipLaunchKernelGGL(k_rotate, dim3((unsigned)(Np / BN), (unsigned)(rows_pad / BM)), dim3(Cfg8::NTHREADS), SMEM_CPLX, ctx->stream,
-                           planes_c(st, r0), planes_s(st, r0), Kp, Qr, Qi, Np, vr, vi, U, Gm, st.inv_rs + r0);
-      else
-        hipLaunchKernelGGL(k_rotate3, dim3((unsigned)rot_grid(ctx, rows_pad / BM, Np / m3::BN3)), dim3(m3::NT3), m3::SMEM3,
-                           ctx->stream, planes_c(st, r0), planes_s(st, r0), Kp, Qr, Qi, Np, vr, vi, U, Gm, st.inv_rs + r0, rows_pad / BM, ctx->rot_pr, ctx->rot_pc);
-      HIPCHK(ctx, hipGetLastError());
+      NLSCHK(launch_rotate(ctx, mp, planes_c(st, r0), planes_s(st, r0), rb.Mr, rb.Mi, rb.mbr, rb.mbi, rb.vr, rb.vi, U, Gm,
+                           st.inv_rs + r0, rows_pad));
       tm[NLS_T_ROTATE_LAUNCHES] += 1;
       tm[NLS_T_ROTATE_FLOPS] += 8.0 * rows * (double)D1 * D1;
     }
     {
       SpanGuard g(ctx, NLS_T_SWEEP);
-      hipLaunchKernelGGL(k_sweep, dim3((unsigned)(Gp / BN), (unsigned)(rows_pad / BM), 2), dim3(Cfg4::NTHREADS), SMEM_REAL, ctx->stream, U, Gm,
-                         Np, R, Gp, 1.0 / st.c, num, hs, r0);
+      hipLaunchKernelGGL(k_sweep, dim3((unsigned)(Gp / BN), (unsigned)(rows_pad / BM), 2), dim3(Cfg4::NTHREADS), SMEM_REAL, ctx->stream, U,
+                         Gm, Np, R, Gp, 1.0 / st.c, num, hs, r0);
       HIPCHK(ctx, hipGetLastError());
       tm[NLS_T_SWEEP_LAUNCHES] += 1;
       tm[NLS_T_SWEEP_FLOPS] += 4.0 * rows * (double)D1 * G;
@@ -618,7 +616,7 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
     SpanGuard g(ctx, NLS_T_LOO);
     hipLaunchKernelGGL(k_loo_errors, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, num, hs, st.dy, st.s_norm, n, G, Gp, is_clf,
                        part);
-    hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)((3 * Gp + 255) / 256)), dim3(256), 0, ctx->stream, part, nblk, 3L * Gp, errs);
+    hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)((3 * Gp + 255) / 256)), dim3(256), 0, ctx->stream, part, nblk, 3L * Gp, errs, 0);
     HIPCHK(ctx, hipGetLastError());
   }
   {
@@ -658,7 +656,7 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
     SpanGuard g(ctx, NLS_T_LOO);
     hipLaunchKernelGGL(k_loo_column, dim3((unsigned)cblk), dim3(256), 0, ctx->stream, num, hs, st.dy, st.s_norm, n, Gp, opt, is_clf,
                        ybar, loo_res, loo_lev, loo_std, cpart);
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(64), 0, ctx->stream, cpart, cblk, 2L, csum);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(64), 0, ctx->stream, cpart, cblk, 2L, csum, 0);
     HIPCHK(ctx, hipGetLastError());
   }
   {
@@ -672,8 +670,8 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
   double2* dbeta = nullptr;
   double *br = nullptr, *bi = nullptr;
   NLSCHK(ws_get_t(ctx, "chol.beta", (size_t)D1, &dbeta));
-  NLSCHK(ws_get_t(ctx, "chol.br", (size_t)Kp, &br));
-  NLSCHK(ws_get_t(ctx, "chol.bi", (size_t)Kp, &bi));
+  NLSCHK(ws_get_t(ctx, "chol.br", (size_t)Kf, &br));
+  NLSCHK(ws_get_t(ctx, "chol.bi", (size_t)Kf, &bi));
   {
     SpanGuard g(ctx, NLS_T_CHOLESKY);
     hipLaunchKernelGGL(k_add_diag, dim3((unsigned)((D1 + 255) / 256)), dim3(256), 0, ctx->stream, Acm, (long)D1, D1, gamma_opt * st.c);
@@ -683,7 +681,7 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
     HIPCHK(ctx, hipMemcpyAsync(dbeta, db, sizeof(double2) * D1, hipMemcpyDeviceToDevice, ctx->stream));
     BLASCHK(ctx, rocsolver_zpotrs(ctx->blas, rocblas_fill_lower, D1, 1, reinterpret_cast<rocblas_double_complex*>(Acm), D1,
                                   reinterpret_cast<rocblas_double_complex*>(dbeta), D1));
-    hipLaunchKernelGGL(k_split_vec, dim3((unsigned)((Kp + 255) / 256)), dim3(256), 0, ctx->stream, dbeta, D1, Kp, br, bi);
+    hipLaunchKernelGGL(k_split_vec, dim3((unsigned)((Kf + 255) / 256)), dim3(256), 0, ctx->stream, dbeta, D, Kf, br, bi);
     HIPCHK(ctx, hipGetLastError());
   }
 
@@ -693,14 +691,14 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
     const long rows_pad = round_up(rows, BM);
     if (!st.resident) {
       SpanGuard g(ctx, NLS_T_FEATUREMAP);
-      NLSCHK(launch_featuremap_planes(ctx, mp, st.dX + r0 * mp.d, rows, rows_pad, st.rs + r0, st.dy + r0, st.Fc, st.Fs));
+      NLSCHK(launch_featuremap_planes(ctx, mp, st.dX + r0 * mp.d, rows, rows_pad, st.rs + r0, st.Fc, st.Fs));
       tm[NLS_T_FEATUREMAP_LAUNCHES] += 1;
       tm[NLS_T_FEATUREMAP_FLOPS] += 2.0 * rows * mp.d * mp.D;
     }
     {
       SpanGuard g(ctx, NLS_T_RESIDUALS);
-      hipLaunchKernelGGL(k_plane_gemv, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, planes_c(st, r0), planes_s(st, r0), Kp, br, bi, rows,
-                         st.dy + r0, is_clf, res + r0, st.inv_rs + r0);
+      hipLaunchKernelGGL(k_plane_gemv, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, planes_c(st, r0), planes_s(st, r0), Kf,
+                         br, bi, dbeta, D, rows, st.dy + r0, is_clf, res + r0, st.inv_rs + r0);
       HIPCHK(ctx, hipGetLastError());
     }
   }
@@ -743,17 +741,6 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
 // ------------------------------------------------------------------------------------------------
 // Primal inference (P10, P11)
 // ------------------------------------------------------------------------------------------------
-// Row-major upper-triangular complex matrix (other triangle ignored) -> planes [Kp x Np].
-__global__ void k_build_upper_planes(const double2* Urm, int D1, int Kp, int Np, double* Qr, double* Qi) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  const int i = blockIdx.y;
-  if (k >= Np) return;
-  double2 v = make_double2(0.0, 0.0);
-  if (i < D1 && k < D1 && i <= k) v = Urm[(long)i * D1 + k];
-  Qr[(long)i * Np + k] = v.x;
-  Qi[(long)i * Np + k] = v.y;
-}
-
 extern "C" int nls_primal_predict(nls_ctx* ctx, const double* X, int64_t m, int d, const double* shift, const double* scale,
                                   const double* B, int D, const double* beta, const double* L, double* yhat, double* sigma) {
   if (!ctx) return NLS_ERR_ARG;
@@ -764,26 +751,27 @@ extern "C" int nls_primal_predict(nls_ctx* ctx, const double* X, int64_t m, int 
   if (m == 0 || (!yhat && !sigma)) return NLS_OK;
   MapParams mp;
   NLSCHK(upload_map(ctx, shift, scale, B, d, D, &mp));
-  const int D1 = mp.D1, Kp = mp.Kp, Np = mp.Np;
+  const int D1 = mp.D1, Kf = mp.Kf, Np = mp.Np;
   const double* dX = nullptr;
   NLSCHK(resident(ctx, "in.X", X, (size_t)m * d, &dX));
   const long rc = pick_row_chunk(ctx, m, mp, 4ull * D1 * D1 * 16);
   double *Fc = nullptr, *Fs = nullptr, *br = nullptr, *bi = nullptr, *dy = nullptr, *dsig = nullptr;
-  NLSCHK(ws_get_t(ctx, "chunk.Fc", (size_t)rc * Kp, &Fc));
-  NLSCHK(ws_get_t(ctx, "chunk.Fs", (size_t)rc * Kp, &Fs));
+  NLSCHK(ws_get_t(ctx, "chunk.Fc", (size_t)rc * Kf, &Fc));
+  NLSCHK(ws_get_t(ctx, "chunk.Fs", (size_t)rc * Kf, &Fs));
   const long m_pad = round_up(m, BM);
   NLSCHK(ws_get_t(ctx, "out.res", (size_t)m_pad, &dy));
   NLSCHK(ws_get_t(ctx, "out.loo_std", (size_t)m_pad, &dsig));
   double2* dbeta = nullptr;
   if (yhat) {
     NLSCHK(ws_get_t(ctx, "chol.beta", (size_t)D1, &dbeta));
-    NLSCHK(ws_get_t(ctx, "chol.br", (size_t)Kp, &br));
-    NLSCHK(ws_get_t(ctx, "chol.bi", (size_t)Kp, &bi));
+    NLSCHK(ws_get_t(ctx, "chol.br", (size_t)Kf, &br));
+    NLSCHK(ws_get_t(ctx, "chol.bi", (size_t)Kf, &bi));
     HIPCHK(ctx, hipMemcpyAsync(dbeta, beta, sizeof(double2) * D1, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_split_vec, dim3((unsigned)((Kp + 255) / 256)), dim3(256), 0, ctx->stream, dbeta, D1, Kp, br, bi);
+    hipLaunchKernelGGL(k_split_vec, dim3((unsigned)((Kf + 255) / 256)), dim3(256), 0, ctx->stream, dbeta, D, Kf, br, bi);
     HIPCHK(ctx, hipGetLastError());
   }
-  double *Qr = nullptr, *Qi = nullptr, *vr = nullptr, *vi = nullptr, *U = nullptr, *Gm = nullptr;
+  RotBuffers rb;
+  double *U = nullptr, *Gm = nullptr;
   if (sigma) {
     // W = phi U^-1, sigma^2 = sum_j |W_ij|^2.  The row-major upper U read as column-major is the lower
     // triangular U^T; ztrtri(lower) inverts it in place, which read back row-major is U^-1 (upper).
@@ -791,38 +779,28 @@ extern "C" int nls_primal_predict(nls_ctx* ctx, const double* X, int64_t m, int 
     rocblas_int* dinfo = nullptr;
     NLSCHK(ws_get_t(ctx, "evd.A", (size_t)D1 * D1, &Urm));
     NLSCHK(ws_get_t(ctx, "evd.info", 4, &dinfo));
-    NLSCHK(ws_get_t(ctx, "rot.Qr", (size_t)Kp * Np, &Qr));
-    NLSCHK(ws_get_t(ctx, "rot.Qi", (size_t)Kp * Np, &Qi));
-    NLSCHK(ws_get_t(ctx, "rot.vr", (size_t)Np, &vr));
-    NLSCHK(ws_get_t(ctx, "rot.vi", (size_t)Np, &vi));
+    NLSCHK(rot_buffers(ctx, mp, &rb));
     NLSCHK(ws_get_t(ctx, "chunk.U", (size_t)rc * Np, &U));
     NLSCHK(ws_get_t(ctx, "chunk.Gm", (size_t)rc * Np, &Gm));
     HIPCHK(ctx, hipMemcpyAsync(Urm, L, sizeof(double2) * (size_t)D1 * D1, hipMemcpyHostToDevice, ctx->stream));
     BLASCHK(ctx, rocsolver_ztrtri(ctx->blas, rocblas_fill_lower, rocblas_diagonal_non_unit, D1,
                                   reinterpret_cast<rocblas_double_complex*>(Urm), D1, dinfo));
     NLSCHK(check_info(ctx, dinfo, "rocsolver_ztrtri"));
-    hipLaunchKernelGGL(k_build_upper_planes, dim3((unsigned)((Np + 255) / 256), (unsigned)Kp), dim3(256), 0, ctx->stream, Urm, D1, Kp,
-                       Np, Qr, Qi);
-    HIPCHK(ctx, hipMemsetAsync(vr, 0, sizeof(double) * Np, ctx->stream));
-    HIPCHK(ctx, hipMemsetAsync(vi, 0, sizeof(double) * Np, ctx->stream));
-    HIPCHK(ctx, hipGetLastError());
+    NLSCHK(build_rot_planes(ctx, mp, Urm, (long)D1, 1L, true, rb));
+    HIPCHK(ctx, hipMemsetAsync(rb.vr, 0, sizeof(double) * Np, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(rb.vi, 0, sizeof(double) * Np, ctx->stream));
   }
   for (long r0 = 0; r0 < m; r0 += rc) {
     const long rows = std::min<long>(rc, m - r0);
     const long rows_pad = round_up(rows, BM);
-    NLSCHK(launch_featuremap_planes(ctx, mp, dX + r0 * d, rows, rows_pad, nullptr, nullptr, Fc, Fs));
+    NLSCHK(launch_featuremap_planes(ctx, mp, dX + r0 * d, rows, rows_pad, nullptr, Fc, Fs));
     if (yhat) {
-      hipLaunchKernelGGL(k_plane_gemv, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, Fc, Fs, Kp, br, bi, rows,
+      hipLaunchKernelGGL(k_plane_gemv, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, Fc, Fs, Kf, br, bi, dbeta, D, rows,
                          (const double*)nullptr, 0, dy + r0, (const double*)nullptr);
       HIPCHK(ctx, hipGetLastError());
     }
     if (sigma) {
-      if (ctx->use_4m)
-        hipLaunchKernelGGL(k_rotate, dim3((unsigned)(Np / BN), (unsigned)(rows_pad / BM)), dim3(Cfg8::NTHREADS), SMEM_CPLX, ctx->stream, Fc, Fs,
-                           Kp, Qr, Qi, Np, vr, vi, U, Gm, (const double*)nullptr);
-      else
-        hipLaunchKernelGGL(k_rotate3, dim3((unsigned)rot_grid(ctx, rows_pad / BM, Np / m3::BN3)), dim3(m3::NT3), m3::SMEM3, ctx->stream,
-                           Fc, Fs, Kp, Qr, Qi, Np, vr, vi, U, Gm, (const double*)nullptr, rows_pad / BM, ctx->rot_pr, ctx->rot_pc);
+      NLSCHK(launch_rotate(ctx, mp, Fc, Fs, rb.Mr, rb.Mi, rb.mbr, rb.mbi, rb.vr, rb.vi, U, Gm, nullptr, rows_pad));
       hipLaunchKernelGGL(k_rowsum_sqrt, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, Gm, Np, rows, dsig + r0);
       HIPCHK(ctx, hipGetLastError());
     }
@@ -832,7 +810,3 @@ extern "C" int nls_primal_predict(nls_ctx* ctx, const double* X, int64_t m, int 
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return NLS_OK;
 }
-
-// ------------------------------------------------------------------------------------------------
-// Dual path: see nls_dual.hip (same shared library).
-// ------------------------------------------------------------------------------------------------

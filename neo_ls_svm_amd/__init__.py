@@ -13,6 +13,7 @@ from .hotpath import (  # noqa: F401
     gram,
     orf_frequencies,
     primal_fit,
+    primal_fit_sigma_grid,
     primal_predict,
     rotate,
 )
@@ -31,6 +32,7 @@ __all__ = [
     "featuremap",
     "gram",
     "primal_fit",
+    "primal_fit_sigma_grid",
     "primal_predict",
     "dual_fit",
     "dual_predict",

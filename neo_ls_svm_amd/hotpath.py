@@ -24,6 +24,7 @@ __all__ = [
     "gram",
     "rotate",
     "primal_fit",
+    "primal_fit_sigma_grid",
     "primal_predict",
     "dual_fit",
     "dual_predict",
@@ -207,6 +208,70 @@ def primal_fit(
         out["loo_yhat"] = y + out["loo_residuals"]
     out["timings"] = timings_dict(tm)
     return out
+
+
+def primal_fit_sigma_grid(
+    X,
+    y,
+    s,
+    shift,
+    scale,
+    B,
+    is_classifier: bool,
+    sigmas,
+    gammas=None,
+    ctx: Context | None = None,
+    rank: int = 0,
+    world: int = 1,
+    allgather=None,
+) -> dict:
+    """gamma x sigma leave-one-out grid (BASELINE config 5).
+
+    The reference fixes the kernel bandwidth in closed form (``_affine_separator.py:200-209``); this driver extends the
+    search with multipliers sigma_k that divide B (T / sigma_k).  For every sigma one ``primal_fit`` runs P2-P7 on the
+    gamma grid - ONE eigendecomposition per sigma is the factorisation all gammas reuse - and the (sigma, gamma) pair
+    with the smallest selection objective wins; that fit's full result is returned under ``"best"``.
+
+    Default gammas: the 32-point grid ``gamma_grid(1024)[::33]`` (exactly a sub-grid of the reference's 1024 points).
+    Multi-GPU: sigmas are dealt round-robin over ``world`` ranks, every rank holding all rows (no collective in the
+    data path); ``allgather(obj) -> list`` (e.g. ``torch.distributed.all_gather_object``) merges the small tables.
+    """
+    sigmas = np.asarray(sigmas, dtype=np.float64)
+    gammas = gamma_grid(1024)[::33] if gammas is None else np.ascontiguousarray(gammas, dtype=np.float64)
+    B = np.ascontiguousarray(B, dtype=np.float64)
+    mine = list(range(rank, sigmas.size, world))
+    rows = {}
+    best = None
+    for k in mine:
+        r = primal_fit(X, y, s, shift, scale, B / sigmas[k], is_classifier, gammas=gammas, ctx=ctx)
+        rows[k] = (r["loo_errors_gammas"], r["objective"], r["timings"]["total"])
+        score = r["objective"][r["opt"]]
+        if best is None or score < best[0]:
+            best = (score, k, r)
+    parts = allgather((rows, None if best is None else (best[0], best[1]))) if (allgather and world > 1) else [(rows, best and best[:2])]
+    table = np.full((sigmas.size, gammas.size), np.nan)
+    objective = np.full((sigmas.size, gammas.size), np.nan)
+    seconds = np.zeros(sigmas.size)
+    winner = None
+    for prt_rows, prt_best in parts:
+        for k, (errs, obj, sec) in prt_rows.items():
+            table[k], objective[k], seconds[k] = errs, obj, sec
+        if prt_best is not None and (winner is None or prt_best[0] < winner[0] or (prt_best[0] == winner[0] and prt_best[1] < winner[1])):
+            winner = tuple(prt_best)
+    k_opt = int(winner[1])
+    g_opt = int(np.argmin(objective[k_opt]))
+    return {
+        "sigmas": sigmas,
+        "gammas": gammas,
+        "loo_errors": table,
+        "objective": objective,
+        "sigma_index": k_opt,
+        "gamma_index": g_opt,
+        "sigma": float(sigmas[k_opt]),
+        "gamma": float(gammas[g_opt]),
+        "seconds_per_sigma": seconds,
+        "best": best[2] if (best is not None and best[1] == k_opt) else None,
+    }
 
 
 def primal_predict(X, shift, scale, B, beta=None, L=None, ctx: Context | None = None):

@@ -159,6 +159,23 @@ def test_sigma_grid_matches_reference(golden_loader, hp):
         assert relerr(r["loo_errors_gammas"], sg["loo_errors"][k]) < TOL
 
 
+def test_sigma_grid_driver(golden_loader, hp):
+    """The gamma x sigma driver reproduces the reference's per-sigma error tables and picks the joint minimum."""
+    sg = golden_loader("sigma_grid_reg_n3000")
+    g = golden_loader(sg["base"])
+    r = hp.primal_fit_sigma_grid(g["X"], g["y"], g["s"], g["shift"], g["scale"], g["B"], False, sg["sigmas"])
+    assert r["loo_errors"].shape == (3, 32)
+    assert relerr(r["loo_errors"], sg["loo_errors"]) < TOL
+    k, gi = np.unravel_index(np.argmin(sg["loo_errors"]), sg["loo_errors"].shape)
+    assert (r["sigma_index"], r["gamma_index"]) == (k, gi)
+    assert r["best"]["opt"] == gi and r["best"]["beta"].shape == (257,)
+    # rank-sharded sigmas (two "ranks" run in sequence here) merge to the same table
+    parts = [hp.primal_fit_sigma_grid(g["X"], g["y"], g["s"], g["shift"], g["scale"], g["B"], False, sg["sigmas"], rank=rk, world=2)
+             for rk in range(2)]  # fmt: skip
+    merged = np.where(np.isnan(parts[0]["loo_errors"]), parts[1]["loo_errors"], parts[0]["loo_errors"])
+    assert relerr(merged, sg["loo_errors"]) < TOL
+
+
 @pytest.mark.parametrize("task", ["reg", "clf"])
 def test_primal_fit_vs_oracle_seeded(task, hp):
     """Seeded synthetic problem of the BASELINE generator at a size the oracle finishes in seconds."""

@@ -208,7 +208,7 @@ def main():
             else ("gamma x sigma grids/sec (16 sigma x 32 gamma), n=1e6 d=128 D=4096" if grid_mode else f"fits/sec (full gamma-sweep), {args.config}"),
             "unit_note": "one step = the whole 16 x 32 grid (16 fits)" if grid_mode else "one step = one fit",
             "value": args.steps / elapsed,
-            "unit": "fits/s",
+            "unit": "grids/s" if grid_mode else "fits/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,

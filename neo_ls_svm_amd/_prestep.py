@@ -216,6 +216,7 @@ def fit_affine_separator(
     edge_sample_size: int = 384,
     edge_search_multiplier: int = 4,
     random_state=42,
+    normalizer=None,
 ):
     """(shift, scale, A): ``AffineSeparator.fit``, ``_affine_separator.py:107-210``.  A is None for one bin.
 
@@ -223,27 +224,37 @@ def fit_affine_separator(
     with its nearest neighbour on the other side, and keep the leading right singular vectors of the
     difference matrix.  The concatenated directions are scaled by lambda = sqrt(2 log(f/g) / (f - g)) with f / g
     the mean inter- / intra-bin squared distances of the edge samples.
+
+    Only the sampled rows are ever gathered and normalised (the reference materialises X per bin and per
+    complement, ~n d nbins doubles of copies); the random stream and the probabilities are the reference's, so
+    the draws are identical.  ``normalizer(X, y, sw) -> (shift, scale)`` overrides the shift/scale step (the GPU
+    implementation plugs in here).
     """
     X = np.asarray(X)
     y = np.ravel(np.asarray(y)).astype(X.dtype)
-    shift, scale = fit_affine_normalizer(X, y, sample_weight)
-    Xn = ((X - shift) / scale).astype(X.dtype)
+    shift, scale = (normalizer or fit_affine_normalizer)(X, y, sample_weight)
     sw = (np.ones(y.shape) if sample_weight is None else np.ravel(np.asarray(sample_weight))).astype(y.dtype)
-    masks, X_bins, n_bins, s_bins = _split_bins(Xn, y, sw)
-    if len(X_bins) <= 1:
+    labels = target_bins(y)
+    ids = [np.flatnonzero(labels == i) for i in range(np.min(labels), np.max(labels) + 1)]
+    if len(ids) <= 1:
         return shift, scale, None
-    m = int(edge_sample_size * 4 / 3) if len(X_bins) == 2 else edge_sample_size
+    n_bins = [np.sum(sw[ix]) for ix in ids]
+    p_bins = [sw[ix] / np.sum(sw[ix]) for ix in ids]
+
+    def rows(ix):  # normalised rows, gathered on demand
+        return ((X[ix, :] - shift) / scale).astype(X.dtype)
+
+    m = int(edge_sample_size * 4 / 3) if len(ids) == 2 else edge_sample_size
     gen = random_state if isinstance(random_state, np.random.RandomState) else np.random.RandomState(random_state)
     dirs, edge_in, edge_out = [], [], []
-    for i in range(len(X_bins)):
-        p_in = np.ravel(s_bins[i])
-        seeds = X_bins[i][gen.choice(len(X_bins[i]), size=m, p=p_in), :]
-        X_rest = np.vstack([Xb for j, Xb in enumerate(X_bins) if j != i])
-        s_rest = np.hstack([sw[mk] for j, mk in enumerate(masks) if j != i])
-        cand = X_rest[gen.choice(len(X_rest), size=m * edge_search_multiplier, p=np.ravel(s_rest) / np.sum(s_rest)), :]
+    for i in range(len(ids)):
+        seeds = rows(ids[i][gen.choice(len(ids[i]), size=m, p=p_bins[i])])
+        rest = np.concatenate([ix for j, ix in enumerate(ids) if j != i])
+        s_rest = sw[rest]
+        cand = rows(rest[gen.choice(len(rest), size=m * edge_search_multiplier, p=s_rest / np.sum(s_rest))])
         outside = _nearest_rows(seeds, cand)
         edge_out.append(outside)
-        cand_in = X_bins[i][gen.choice(len(X_bins[i]), size=m * edge_search_multiplier, p=p_in), :]
+        cand_in = rows(ids[i][gen.choice(len(ids[i]), size=m * edge_search_multiplier, p=p_bins[i])])
         inside = _nearest_rows(outside, cand_in)
         edge_in.append(inside)
         sv, V = _right_singular_vectors(inside - outside)

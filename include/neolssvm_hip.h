@@ -13,6 +13,7 @@
  *                           fused with the transform that feeds it       _neo_ls_svm.py:386,401-402
  *   nls_primal_predict      decision_function / predict_std (primal)     _neo_ls_svm.py:661-665, 464-469,477
  *   nls_dual_fit            NeoLSSVM._optimize_alpha_gamma(X, y, s)      _neo_ls_svm.py:191-325
+ *   nls_bin_stats           per-bin weighted medians / deviations        _affine_normalizer.py:72-79
  *   nls_dual_predict        decision_function / predict_std (dual)       _neo_ls_svm.py:666-671, 470-477
  *
  * Conventions
@@ -162,6 +163,15 @@ int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* args);
 int nls_primal_predict(nls_ctx* ctx, const double* X, int64_t m, int d, const double* shift,
                        const double* scale, const double* B, int D, const double* beta,
                        const double* L, double* yhat, double* sigma);
+
+/* ---- supervised normaliser statistics (next row after the hot path) ------------
+ * Per class bin b and input column j: the weighted median of X[bin b, j] (weighted_quantile(.., 0.5), the average of
+ * the lower- and upper-cumulative-weight interpolants, _weighted_quantile.py:35-63) and the weighted mean absolute
+ * deviation about it - the two statistics AffineNormalizer.fit builds shift_/scale_ from (_affine_normalizer.py:72-79).
+ * perm: the n row indices grouped by bin (stable order), bin_off: nbins + 1 offsets into perm.  X, s: host | device.
+ * centers, spreads: nbins x d, host. */
+int nls_bin_stats(nls_ctx* ctx, const double* X, const double* s, int64_t n, int d, const int32_t* perm,
+                  const int64_t* bin_off, int nbins, double* centers, double* spreads);
 
 /* ---- dual fit --------------------------------------------------------------------------------- */
 typedef struct nls_dual_fit_args {

@@ -140,6 +140,10 @@ SIGNATURES = {
         [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         + [C.c_void_p, C.c_void_p],
     ),
+    "nls_bin_stats": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p],
+    ),
     "nls_dual_fit": (C.c_int, [C.c_void_p, C.POINTER(DualFitArgs)]),
     "nls_dual_predict": (
         C.c_int,

@@ -145,21 +145,33 @@ def _split_bins(X, y, sw):
     return masks, X_bins, n_bins, s_bins
 
 
-def fit_affine_normalizer(X: np.ndarray, y: np.ndarray, sample_weight: np.ndarray | None = None):
+def fit_affine_normalizer(X: np.ndarray, y: np.ndarray, sample_weight: np.ndarray | None = None, stats=None):
     """(shift, scale), each 1 x d: ``AffineNormalizer.fit``, ``_affine_normalizer.py:50-117``.
 
     Per-bin weighted medians and mean absolute deviations; every pair of bins votes for a separating
     threshold (shift) and a spread (scale) with weight sqrt((n_i + n_j) (1/2 + separability)).
+    ``stats(X, labels, sw) -> (centers, spreads)`` (nbins x d each) replaces the NumPy sort-based statistics -
+    ``hotpath.bin_stats`` computes them on the GPU.
     """
     X = np.asarray(X)
     y = np.ravel(np.asarray(y)).astype(X.dtype)
     sw = (np.ones(y.shape) if sample_weight is None else np.ravel(np.asarray(sample_weight))).astype(y.dtype)
     d = X.shape[1]
-    _, X_bins, n_bins, s_bins = _split_bins(X, y, sw)
-    if len(X_bins) <= 1:
-        return np.zeros((1, d), dtype=X.dtype), np.ones((1, d), dtype=X.dtype)
-    centers = [weighted_median_columns(Xb, sb) for Xb, sb in zip(X_bins, s_bins)]
-    spreads = [sb @ np.abs(Xb - mu) for Xb, sb, mu in zip(X_bins, s_bins, centers)]
+    if stats is not None:
+        labels = target_bins(y)
+        nb = int(labels.max() - labels.min()) + 1
+        if nb <= 1:
+            return np.zeros((1, d), dtype=X.dtype), np.ones((1, d), dtype=X.dtype)
+        cen, spr = stats(X, labels, sw)
+        n_bins = np.bincount(labels - labels.min(), weights=sw, minlength=nb)
+        centers = [cen[b][None, :] for b in range(nb)]
+        spreads = [spr[b][None, :] for b in range(nb)]
+    else:
+        _, X_bins, n_bins, s_bins = _split_bins(X, y, sw)
+        if len(X_bins) <= 1:
+            return np.zeros((1, d), dtype=X.dtype), np.ones((1, d), dtype=X.dtype)
+        centers = [weighted_median_columns(Xb, sb) for Xb, sb in zip(X_bins, s_bins)]
+        spreads = [sb @ np.abs(Xb - mu) for Xb, sb, mu in zip(X_bins, s_bins, centers)]
     eps = np.finfo(X.dtype).eps
     sign = np.zeros((1, d), dtype=X.dtype)
     wsum = np.zeros((1, d), dtype=X.dtype)

@@ -2,3 +2,4 @@
 // so the two host files are compiled together).
 #include "nls_lib.hip"
 #include "nls_dual.hip"
+#include "nls_prestep.hip"

@@ -34,18 +34,25 @@ __all__ = ["NeoLSSVM", "AffineSeparator", "OrthogonalRandomFourierFeatures"]
 class AffineSeparator(BaseEstimator):
     """(x - shift) diag(1/scale) A with supervised shift/scale/A: reference ``_affine_separator.py:54-210``."""
 
-    def __init__(self, *, rank_threshold=2e-2, edge_sample_size=384, edge_search_multiplier=4, random_state=42):
+    def __init__(self, *, rank_threshold=2e-2, edge_sample_size=384, edge_search_multiplier=4, random_state=42, device=0):
         self.rank_threshold = rank_threshold
         self.edge_sample_size = edge_sample_size
         self.edge_search_multiplier = edge_search_multiplier
         self.random_state = random_state
+        self.device = device
 
     def fit(self, X, y, sample_weight=None):
         X, y = check_X_y(X, y, dtype=np.float64)
+        ctx = default_context(int(self.device))
+
+        def normalizer(Xa, ya, swa):  # per-bin weighted medians / deviations on the GPU (nls_bin_stats)
+            return _prestep.fit_affine_normalizer(Xa, ya, swa, stats=lambda A, lab, w: hotpath.bin_stats(A, lab, w, ctx=ctx))
+
         self.shift_, self.scale_, self.A_ = _prestep.fit_affine_separator(
             X,
             y,
             sample_weight,
+            normalizer=normalizer,
             rank_threshold=self.rank_threshold,
             edge_sample_size=self.edge_sample_size,
             edge_search_multiplier=self.edge_search_multiplier,

@@ -23,6 +23,7 @@ __all__ = [
     "featuremap",
     "gram",
     "rotate",
+    "bin_stats",
     "primal_fit",
     "primal_fit_sigma_grid",
     "primal_predict",
@@ -134,6 +135,27 @@ def rotate(X, shift, scale, B, Q, v, ctx: Context | None = None, want_outputs: b
         )
     )  # fmt: skip
     return U, Gm
+
+
+def bin_stats(X, labels, sample_weight=None, ctx: Context | None = None):
+    """(centers, spreads), each nbins x d: per class bin the weighted median and weighted mean absolute deviation of
+    every input column (``_affine_normalizer.py:72-79``) on the GPU (segmented radix sort + one scan per segment)."""
+    ctx = ctx or default_context()
+    X = _f64(X, "X")
+    n, d = X.shape
+    labels = np.asarray(labels)
+    lo, hi = int(labels.min()), int(labels.max())
+    nbins = hi - lo + 1
+    sw = np.ones(n) if sample_weight is None else np.ascontiguousarray(sample_weight, dtype=np.float64)
+    perm = np.argsort(labels, kind="stable").astype(np.int32)
+    off = np.zeros(nbins + 1, dtype=np.int64)
+    off[1:] = np.cumsum(np.bincount(labels - lo, minlength=nbins))
+    centers, spreads = np.empty((nbins, d)), np.empty((nbins, d))
+    ctx._check(
+        ctx.lib.nls_bin_stats(ctx.handle, _lib._ptr(X), sw.ctypes.data, n, d, perm.ctypes.data, off.ctypes.data, nbins,
+                              centers.ctypes.data, spreads.ctypes.data)
+    )  # fmt: skip
+    return centers, spreads
 
 
 def primal_fit(

@@ -69,6 +69,25 @@ def test_dual_estimator_matches_reference(name, golden_loader):
         assert np.array_equal(m.predict(g["Xq"]), g["predict"])
 
 
+@pytest.mark.parametrize("name", PRIMAL_CASES[:3] + DUAL_CASES[:2])
+def test_gpu_bin_stats_match_numpy(name, golden_loader):
+    """nls_bin_stats (segmented sort on the GPU) vs the NumPy weighted medians / deviations of the pre-step."""
+    from conftest import signed_targets
+
+    from neo_ls_svm_amd import _prestep, hotpath
+
+    g = golden_loader(name)
+    X, y, s = g["X"], signed_targets(g), g["s"].copy()
+    s[s == 0] = 1e-3  # strictly positive so that every bin has weight
+    labels = _prestep.target_bins(y)
+    cen, spr = hotpath.bin_stats(X, labels, s)
+    for b in range(labels.max() + 1):
+        m = labels == b
+        mu = _prestep.weighted_median_columns(X[m], s[m] / s[m].sum())
+        assert relerr(cen[b], mu[0]) < 1e-12
+        assert relerr(spr[b], ((s[m] / s[m].sum())[None, :] @ np.abs(X[m] - mu))[0]) < 1e-12
+
+
 def test_auto_switch_pandas_and_score():
     import pandas as pd
     from sklearn.datasets import load_breast_cancer, load_diabetes

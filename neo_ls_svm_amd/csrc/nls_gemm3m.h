@@ -200,6 +200,14 @@ __device__ __forceinline__ void mainloop_3m(v4d (&S1)[MT3][NTL3], v4d (&S2)[MT3]
         if (ks == 1) {
           interleave<1, 0x200, 2 * STAGE_A + 2 * STAGE_B>();
           interleave<1, 0x020, 2 * ALoad::NREG + 2 * BLoad::NREG>();
+        } else if (ABL & 32) {
+          interleave<1, 0x100, NFRAG>();
+        } else if (ABL & 64) {
+          interleave<3, 0x100, NFRAG / 2>();
+          interleave<1, 0x100, NFRAG / 2>();
+        } else if (ABL & 128) {  // VALU adds first, then reads 2:1
+          interleave<1, 0x002, 6>();
+          interleave<2, 0x100, NFRAG>();
         } else {
           interleave<2, 0x100, NFRAG>();
         }

@@ -369,8 +369,19 @@ static int primal_gram_phase(nls_ctx* ctx, PrimalState& st, double* timings) {
   NLSCHK(ws_get_t(ctx, "chunk.Fs", (size_t)st.plane_rows * mp.Kf, &st.Fs));
   // Row split so that one launch fills the chip several times over (one 256-thread workgroup per CU).
   const long half_tiles = 2L * st.ntri;
-  long nsplit = std::max<long>(1, (16L * ctx->cus + half_tiles - 1) / half_tiles);
-  nsplit = std::min<long>(nsplit, std::max<long>(1, st.rc / (8 * BK)));
+  long ns_lo = std::max<long>(1, (12L * ctx->cus + half_tiles - 1) / half_tiles), ns_hi = 3 * ns_lo;
+  ns_hi = std::min<long>(ns_hi, std::max<long>(1, st.rc / (8 * BK)));
+  ns_lo = std::min(ns_lo, ns_hi);
+  long nsplit = ns_lo;
+  double best_eff = 0.0;
+  for (long ns = ns_lo; ns <= ns_hi; ++ns) {  // fill the last round of workgroups (one per CU) as full as possible
+    const long blocks = half_tiles * ns, rounds = (blocks + ctx->cus - 1) / ctx->cus;
+    const double eff = (double)blocks / (double)(rounds * ctx->cus);
+    if (eff > best_eff + 1e-9) {
+      best_eff = eff;
+      nsplit = ns;
+    }
+  }
   double *slab = nullptr, *bpart = nullptr;
   NLSCHK(ws_get_t(ctx, "gram.slab", (size_t)nsplit * st.tile_elems, &slab));
   const long bsplit_max = 256;

@@ -121,6 +121,9 @@ int main() {
   run3<NO_GLOAD | NO_LDS_STORE | NO_BARRIER, true>("3M ... and no barrier", Fc, Fs, Kp, ktiles, 4096, out2);
   run3<NO_GLOAD | NO_LDS_STORE | NO_BARRIER | NO_FRAG, true>("3M MFMA only", Fc, Fs, Kp, ktiles, 4096, out2);
   run3<ABL_NO_INTERLEAVE, true>("3M full, no sched_group_barrier", Fc, Fs, Kp, ktiles, 4096, out2);
+  run3<32, true>("3M full, 1 MFMA per ds_read", Fc, Fs, Kp, ktiles, 4096, out2);
+  run3<64, true>("3M full, 3:1 then 1:1", Fc, Fs, Kp, ktiles, 4096, out2);
+  run3<128, true>("3M full, VALU first", Fc, Fs, Kp, ktiles, 4096, out2);
   printf("3M rotate-like (m-major A)\n");
   run3<0, false>("3M full", Fc, Fs, Kp, 264, 4096, out2);
   run3<NO_GLOAD, false>("3M no global loads", Fc, Fs, Kp, 264, 4096, out2);

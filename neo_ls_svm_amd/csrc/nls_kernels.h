@@ -129,29 +129,26 @@ __global__ void __launch_bounds__(m3::NT3, 1)
   const long r0 = (long)split * rows_per_split;
   long r1 = r0 + rows_per_split;
   if (r1 > rows_pad) r1 = rows_pad;
-  v4d S1[MT3][NTL3], S2[MT3][NTL3], S3[MT3][NTL3];
-  zero_acc(S1);
-  zero_acc(S2);
-  zero_acc(S3);
+  acc_zero();
   if (r1 > r0) {
     KMajorLoader3<BM3, STAGE_A> lac{Fc, Kf, (long)tj * BM3}, las{Fs, Kf, (long)tj * BM3};
     KMajorLoader3<BN3, STAGE_B> lbr{Fc, Kf, (long)tk64 * BN3}, lbi{Fs, Kf, (long)tk64 * BN3};
-    mainloop_3m<true>(S1, S2, S3, lac, las, lbr, lbi, r0, (int)((r1 - r0) / BK), smem);
+    mainloop_3m<true>(lac, las, lbr, lbi, r0, (int)((r1 - r0) / BK), smem);
   }
+  acc_settle();
   const long tile128 = (long)tj * (tj + 1) / 2 + (tk64 >> 1);
   double* outR = slab + ((long)split * ntri + tile128) * (2L * BM * BN) + (tk64 & 1) * BN3;
   double* outI = outR + BM * BN;
+  static_for<MT3 * NTL3>([&](auto tc) {
+    constexpr int t = decltype(tc)::value, mt = t / NTL3, nt = t % NTL3;
+    const v4d S1 = acc_get<ACC_S1 + t>(), S2 = acc_get<ACC_S2 + t>(), S3 = acc_get<ACC_S3 + t>();
 #pragma unroll
-  for (int mt = 0; mt < MT3; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < NTL3; ++nt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int o = acc_row3(mt, r) * BN + acc_col3(nt);
-        const double s1 = S1[mt][nt][r], s2 = S2[mt][nt][r];
-        outR[o] = s1 + s2;                    // Fc_j Fc_k + Fs_j Fs_k =  Re A_jk
-        outI[o] = (S3[mt][nt][r] - s1) + s2;  // Fc_j Fs_k - Fs_j Fc_k = -Im A_jk
-      }
+    for (int r = 0; r < 4; ++r) {
+      const int o = acc_row3(mt, r) * BN + acc_col3(nt);
+      outR[o] = S1[r] + S2[r];            // Fc_j Fc_k + Fs_j Fs_k =  Re A_jk
+      outI[o] = (S3[r] - S1[r]) + S2[r];  // Fc_j Fs_k - Fs_j Fc_k = -Im A_jk
+    }
+  });
 }
 
 // acc[i] += sum_split slab[split][i], fixed order (bit-reproducible).
@@ -330,29 +327,28 @@ __global__ void __launch_bounds__(m3::NT3, 1)
   }
   const long row0 = tr * BM3;
   const long col0 = tc * BN3;
-  v4d S1[MT3][NTL3], S2[MT3][NTL3], S3[MT3][NTL3];
-  zero_acc(S1);
-  zero_acc(S2);
-  zero_acc(S3);
+  acc_zero();
   MMajorLoader3 lac{Fc, Kf, row0}, las{Fs, Kf, row0};
   KMajorLoader3<BN3, STAGE_B> lbr{Mr, Np, col0}, lbi{Mi, Np, col0};
-  mainloop_3m<false>(S1, S2, S3, lac, las, lbr, lbi, 0, Kf / BK, smem);
-#pragma unroll
-  for (int nt = 0; nt < NTL3; ++nt) {
+  mainloop_3m<false>(lac, las, lbr, lbi, 0, Kf / BK, smem);
+  acc_settle();
+  static_for<NTL3>([&](auto ntc) {
+    constexpr int nt = decltype(ntc)::value;
     const long col = col0 + acc_col3(nt);
     const double wr = vr[col], wi = vi[col], br = mbr[col], bi = mbi[col];
-#pragma unroll
-    for (int mt = 0; mt < MT3; ++mt)
+    static_for<MT3>([&](auto mtc) {
+      constexpr int mt = decltype(mtc)::value, t = mt * NTL3 + nt;
+      const v4d S1 = acc_get<ACC_S1 + t>(), S2 = acc_get<ACC_S2 + t>(), S3 = acc_get<ACC_S3 + t>();
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const long row = row0 + acc_row3(mt, r);
         const double f = inv_rs ? inv_rs[row] : 1.0;  // planes hold rs_i phi_i: undo the row scale
-        const double s1 = S1[mt][nt][r], s2 = S2[mt][nt][r];
-        const double pr = (s1 + s2) * f + br, pi = ((S3[mt][nt][r] - s1) + s2) * f + bi;
+        const double pr = (S1[r] + S2[r]) * f + br, pi = ((S3[r] - S1[r]) + S2[r]) * f + bi;
         U[row * Np + col] = pr * wr - pi * wi;
         Gm[row * Np + col] = pr * pr + pi * pi;
       }
-  }
+    });
+  });
 }
 
 // R[j][g] = 1 / (gamma_g + lam_j) (zero padded to Np x Gp).

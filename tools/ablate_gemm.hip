@@ -39,21 +39,19 @@ template <int FLAGS, bool A_KMAJOR>
 __global__ void __launch_bounds__(m3::NT3, 1) k_abl3(const double* Fc, const double* Fs, int Kp, int ktiles, double* out) {
   using namespace m3;
   extern __shared__ double smem[];
-  v4d S1[MT3][NTL3], S2[MT3][NTL3], S3[MT3][NTL3];
-  zero_acc(S1); zero_acc(S2); zero_acc(S3);
+  acc_zero();
   const long col0 = (long)(blockIdx.x % (Kp / BN3)) * BN3;
   const long colA = (long)((blockIdx.x / 7) % (Kp / BM3)) * BM3;
   using AL = typename std::conditional<A_KMAJOR, KMajorLoader3<BM3, STAGE_A>, MMajorLoader3>::type;
   AL lac{Fc, Kp, colA}, las{Fs, Kp, colA};
   KMajorLoader3<BN3, STAGE_B> lbr{Fc, Kp, col0}, lbi{Fs, Kp, col0};
-  mainloop_3m<A_KMAJOR, AL, KMajorLoader3<BN3, STAGE_B>, FLAGS>(S1, S2, S3, lac, las, lbr, lbi, 0, ktiles, smem);
+  mainloop_3m<A_KMAJOR, AL, KMajorLoader3<BN3, STAGE_B>, FLAGS>(lac, las, lbr, lbi, 0, ktiles, smem);
+  acc_settle();
   double s = 0;
-#pragma unroll
-  for (int mt = 0; mt < MT3; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < NTL3; ++nt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) s += S1[mt][nt][r] + S2[mt][nt][r] + S3[mt][nt][r];
+  static_for<24>([&](auto t) {
+    const v4d a = acc_get<decltype(t)::value>();
+    s += a[0] + a[1] + a[2] + a[3];
+  });
   out[(long)blockIdx.x * NT3 + threadIdx.x] = s;
 }
 
@@ -121,9 +119,6 @@ int main() {
   run3<NO_GLOAD | NO_LDS_STORE | NO_BARRIER, true>("3M ... and no barrier", Fc, Fs, Kp, ktiles, 4096, out2);
   run3<NO_GLOAD | NO_LDS_STORE | NO_BARRIER | NO_FRAG, true>("3M MFMA only", Fc, Fs, Kp, ktiles, 4096, out2);
   run3<ABL_NO_INTERLEAVE, true>("3M full, no sched_group_barrier", Fc, Fs, Kp, ktiles, 4096, out2);
-  run3<32, true>("3M full, 1 MFMA per ds_read", Fc, Fs, Kp, ktiles, 4096, out2);
-  run3<64, true>("3M full, 3:1 then 1:1", Fc, Fs, Kp, ktiles, 4096, out2);
-  run3<128, true>("3M full, VALU first", Fc, Fs, Kp, ktiles, 4096, out2);
   printf("3M rotate-like (m-major A)\n");
   run3<0, false>("3M full", Fc, Fs, Kp, 264, 4096, out2);
   run3<NO_GLOAD, false>("3M no global loads", Fc, Fs, Kp, 264, 4096, out2);

@@ -34,8 +34,8 @@ __global__ void __launch_bounds__(Cfg4::NTHREADS, 2) k_gemm(GemmParams p) {
   const long col0 = (long)blockIdx.x * BN;
   v4d acc[C::MT][C::NTL];
   zero_acc(acc);
-  MMajorPlaneLoader<C> la{p.A, p.lda, row0};
-  KMajorPlaneLoader<C> lb{p.B, p.ldb, col0};
+  MMajorLoader<C::NTHREADS, BM> la{p.A, p.lda, row0};
+  KMajorLoader<C::NTHREADS, BN> lb{p.B, p.ldb, col0};
   mainloop_real<C, false>(acc, la, lb, 0, p.K / BK, smem);
 #pragma unroll
   for (int mt = 0; mt < C::MT; ++mt)

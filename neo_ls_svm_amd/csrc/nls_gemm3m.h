@@ -21,8 +21,6 @@
 //
 // BUILD FLAG: -mllvm -amdgpu-mfma-vgpr-form=1 is kept for the compiler-scheduled engine in nls_gemm.h.
 #pragma once
-#include <type_traits>
-#include <utility>
 #include "nls_gemm.h"
 
 namespace nls {
@@ -43,15 +41,6 @@ __device__ __forceinline__ int wave_m3() { return (threadIdx.x >> 6) >> 1; }
 __device__ __forceinline__ int wave_n3() { return (threadIdx.x >> 6) & 1; }
 __device__ __forceinline__ int acc_row3(int mt, int reg) { return wave_m3() * 64 + mt * 16 + ((threadIdx.x & 63) >> 4) + 4 * reg; }
 __device__ __forceinline__ int acc_col3(int nt) { return wave_n3() * 32 + nt * 16 + (threadIdx.x & 15); }
-
-template <int... I, class F>
-__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
-  (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {  // f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>)
-  static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
-}
 
 // ---- accumulators in physical AGPRs -----------------------------------------------------------------
 // Accumulator tile T (0 .. 23: S1[mt][nt] = mt * 2 + nt, S2 = 8 + ..., S3 = 16 + ...) is a[8 T : 8 T + 7].
@@ -92,59 +81,13 @@ __device__ __forceinline__ v4d acc_get() {
 }
 constexpr int ACC_S1 = 0, ACC_S2 = MT3 * NTL3, ACC_S3 = 2 * MT3 * NTL3;
 
-typedef __attribute__((address_space(3))) double lds_f64;
-typedef __attribute__((address_space(3))) v2d lds_v2d;
-// LDS pointer (32-bit) to smem + off doubles, made opaque so that the compiler keeps it in one register instead of
-// re-deriving it with VALU adds inside the loop.
-__device__ __forceinline__ lds_f64* lds_base(double* smem, int off) {
-  lds_f64* p = (lds_f64*)(smem) + off;
-  asm volatile("" : "+v"(p));
-  return p;
-}
-
-// ---- staging -------------------------------------------------------------------------------------
-// On gfx950 the fp64 MFMA shares its datapath with the vector ALU: EVERY VALU instruction a wave issues between
-// MFMAs - a 32-bit address add as much as a v_add_f64 - costs ~13.6 matrix-pipe cycles, while LDS and global
-// memory instructions and SALU are free (tools/probe_lds_mfma.hip, profiles/r01_probe_valu_cost.log).  The
-// loaders are therefore built so that the main loop needs no vector address arithmetic at all:
-//   global:  address = uniform 64-bit pointer (SGPR pair, advanced with SALU) + one loop-invariant 32-bit
-//            per-thread byte offset   -> global_load_dwordx4 v, v_off, s[base:base+1]
-//   LDS:     address = one loop-invariant per-thread base per buffer + immediate offsets.
+// ---- staging: the shared VALU-free loaders (nls_gemm.h) at this engine's geometry ----------------------------
 template <int WIDTH, int STAGE>
-struct KMajorLoader3 {  // tile [16][WIDTH] of a row-major [K][ld] plane, columns col0 ..
-  const char* base;     // uniform
-  long ldb;             // uniform row pitch in bytes
-  mutable unsigned goff;  // per thread
-  static constexpr int LD = WIDTH + 16;
-  static constexpr int PER_ROW = WIDTH / 2;      // v2d per row
-  static constexpr int ROWS_IT = NT3 / PER_ROW;  // rows covered by one pass of the 256 threads
-  static constexpr int NREG = STAGE;
-  __device__ __forceinline__ KMajorLoader3(const double* plane, long ld, long col0)
-      : base(reinterpret_cast<const char*>(plane + col0)), ldb(ld * 8),
-        goff((unsigned)((threadIdx.x / PER_ROW) * ld * 8 + (threadIdx.x % PER_ROW) * 16)) {}
-  __device__ __forceinline__ v2d fetch1(long k0, int it) const {
-    asm volatile("" : "+v"(goff));  // keeps the zero-extension next to the load: saddr + 32-bit voffset addressing
-    return *reinterpret_cast<const v2d*>(base + (k0 + it * ROWS_IT) * ldb + goff);
-  }
-  static __device__ __forceinline__ int lds_off() { return (threadIdx.x / PER_ROW) * LD + 2 * (threadIdx.x % PER_ROW); }
-  static __device__ __forceinline__ void store1(lds_f64* wr, int it, v2d v) { *(lds_v2d*)(wr + it * ROWS_IT * LD) = v; }
-};
-
-struct MMajorLoader3 {  // tile [128 rows][16 k] of a row-major [M][ld] plane
-  const char* base;
-  long ldb;
-  mutable unsigned goff;
-  static constexpr int NREG = STAGE_A;
-  __device__ __forceinline__ MMajorLoader3(const double* plane, long ld, long row0)
-      : base(reinterpret_cast<const char*>(plane + row0 * ld)), ldb(ld * 8),
-        goff((unsigned)((threadIdx.x >> 3) * ld * 8 + (threadIdx.x & 7) * 16)) {}
-  __device__ __forceinline__ v2d fetch1(long k0, int it) const {
-    asm volatile("" : "+v"(goff));
-    return *reinterpret_cast<const v2d*>(base + k0 * 8 + it * 32 * ldb + goff);
-  }
-  static __device__ __forceinline__ int lds_off() { return (threadIdx.x >> 3) * LDM + 2 * (threadIdx.x & 7); }
-  static __device__ __forceinline__ void store1(lds_f64* wr, int it, v2d v) { *(lds_v2d*)(wr + it * 32 * LDM) = v; }
-};
+using KMajorLoader3 = KMajorLoader<NT3, WIDTH>;
+using MMajorLoader3 = MMajorLoader<NT3, BM3>;
+static_assert(KMajorLoader3<BM3, STAGE_A>::NREG == STAGE_A && KMajorLoader3<BN3, STAGE_B>::NREG == STAGE_B &&
+                  MMajorLoader3::NREG == STAGE_A && KMajorLoader3<BM3, 0>::LD == LDTA && KMajorLoader3<BN3, 0>::LD == LDTB,
+              "staging plan");
 
 // Fragment reads relative to a per-lane base (frag_base_*): only immediate offsets.
 template <bool A_KMAJOR>

@@ -46,8 +46,8 @@ __global__ void __launch_bounds__(Cfg4::NTHREADS, 1) k_featuremap(FeatureMapPara
   v4d acc[C::MT][C::NTL];
   zero_acc(acc);
   if (col0 < p.D) {
-    XShiftLoader<C> la{p.X, p.shift, p.rows, p.d, row0};
-    KMajorPlaneLoader<C> lb{p.Bs, p.Kf, col0};
+    XShiftLoader<C::NTHREADS, BM> la{p.X, p.shift, p.rows, p.d, row0};
+    KMajorLoader<C::NTHREADS, BN> lb{p.Bs, p.Kf, col0};
     mainloop_real<C, false>(acc, la, lb, 0, p.dk / BK, smem);
   }
 #pragma unroll
@@ -372,8 +372,8 @@ __global__ void __launch_bounds__(Cfg4::NTHREADS, 2)
   const bool second = blockIdx.z == 1;
   v4d acc[C::MT][C::NTL];
   zero_acc(acc);
-  MMajorPlaneLoader<C> la{second ? Gm : U, Np, row0};
-  KMajorPlaneLoader<C> lb{R, Gp, col0};
+  MMajorLoader<C::NTHREADS, BM> la{second ? Gm : U, Np, row0};
+  KMajorLoader<C::NTHREADS, BN> lb{R, Gp, col0};
   mainloop_real<C, false>(acc, la, lb, 0, Np / BK, smem);
   double* out = second ? hs : num;
   const double f = second ? inv_c : 1.0;

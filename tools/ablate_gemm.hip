@@ -1,5 +1,5 @@
 // Ablation harness for the tile engine's complex main loop (diagnostic build, not part of the product).
-// Variants drop one ingredient at a time to see where the ~14% of non-MFMA time goes.
+// Variants drop one ingredient at a time to see where the non-MFMA time goes.
 //   hipcc -O3 --offload-arch=gfx950 -std=c++17 -Ineo_ls_svm_amd/csrc tools/ablate_gemm.hip -o tools/ablate_gemm
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -12,26 +12,25 @@ using namespace nls;
 
 enum { NO_GLOAD = ABL_NO_GLOAD, NO_LDS_STORE = ABL_NO_LDS_STORE, NO_BARRIER = ABL_NO_BARRIER, NO_FRAG = ABL_NO_FRAG };
 
-// The product's own main loop (nls_gemm.h) with its diagnostic ABL switch.
-template <int FLAGS, bool A_KMAJOR>
-__global__ void __launch_bounds__(Cfg8::NTHREADS, 2) k_abl(const double* Fc, const double* Fs, int Kp, int ktiles, double* out) {
-  using C = Cfg8;
+// The REAL engine (k_sweep / dual GEMMs): m-major A, k-major B, two workgroups per CU.
+template <int FLAGS>
+__global__ void __launch_bounds__(Cfg4::NTHREADS, 2) k_abl(const double* Fc, const double* Fs, int Kp, int ktiles, double* out) {
+  using C = Cfg4;
   extern __shared__ double smem[];
-  v4d accR[C::MT][C::NTL], accI[C::MT][C::NTL];
-  zero_acc(accR); zero_acc(accI);
+  v4d acc[C::MT][C::NTL];
+  zero_acc(acc);
   const long col0 = (long)(blockIdx.x % (Kp / BN)) * BN;
-  const long colA = (long)((blockIdx.x / 7) % (Kp / BN)) * BM;
-  using AL = typename std::conditional<A_KMAJOR, KMajorPlaneLoader<C>, MMajorPlaneLoader<C>>::type;
-  AL lac{Fc, Kp, colA}, las{Fs, Kp, colA};
-  KMajorPlaneLoader<C> lbr{Fc, Kp, col0}, lbi{Fs, Kp, col0};
-  mainloop_cplx<C, A_KMAJOR, AL, KMajorPlaneLoader<C>, FLAGS>(accR, accI, lac, las, lbr, lbi, 0, ktiles, smem);
+  const long row0 = (long)((blockIdx.x / 7) % 500) * BM;
+  MMajorLoader<C::NTHREADS, BM> la{Fc, Kp, row0};
+  KMajorLoader<C::NTHREADS, BN> lb{Fs, Kp, col0};
+  mainloop_real<C, false, MMajorLoader<C::NTHREADS, BM>, KMajorLoader<C::NTHREADS, BN>, FLAGS>(acc, la, lb, 0, ktiles, smem);
   double s = 0;
 #pragma unroll
   for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < C::NTL; ++nt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) s += accR[mt][nt][r] + accI[mt][nt][r];
+      for (int r = 0; r < 4; ++r) s += acc[mt][nt][r];
   out[(long)blockIdx.x * C::NTHREADS + threadIdx.x] = s;
 }
 
@@ -72,27 +71,27 @@ void run3(const char* name, const double* Fc, const double* Fs, int Kp, int ktil
   printf("%-34s %8.2f ms  %6.2f TFLOP/s (4M-equivalent)  %7.0f cycles/slice (ideal 6144)\n", name, best, flops4m / best / 1e9, cyc);
 }
 
-template <int FLAGS, bool AK>
+template <int FLAGS>
 void run(const char* name, const double* Fc, const double* Fs, int Kp, int ktiles, int blocks, double* out) {
-  const size_t smem = 8 * TILE_DOUBLES * sizeof(double);
-  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_abl<FLAGS, AK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  const size_t smem = 4 * TILE_DOUBLES * sizeof(double);
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_abl<FLAGS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   float best = 1e30f;
   for (int rep = 0; rep < 3; ++rep) {
     CK(hipEventRecord(e0));
-    hipLaunchKernelGGL((k_abl<FLAGS, AK>), dim3(blocks), dim3(Cfg8::NTHREADS), smem, 0, Fc, Fs, Kp, ktiles, out);
+    hipLaunchKernelGGL((k_abl<FLAGS>), dim3(blocks), dim3(Cfg4::NTHREADS), smem, 0, Fc, Fs, Kp, ktiles, out);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best = ms < best ? ms : best;
   }
-  double flops = (double)blocks * ktiles * 16.0 * 128 * 128 * 8;
-  double cyc = best * 1e-3 * 2.39e9 / ktiles / ((blocks + 255) / 256);
-  printf("%-34s %8.2f ms  %6.2f TFLOP/s-equivalent  %7.0f cycles/slice\n", name, best, flops / best / 1e9, cyc);
+  double flops = (double)blocks * ktiles * 16.0 * 128 * 128 * 2;
+  double cyc = best * 1e-3 * 2.39e9 / ktiles / ((blocks + 511) / 512);  // two workgroups per CU share each SIMD
+  printf("%-34s %8.2f ms  %6.2f TFLOP/s  %7.0f cycles/slice per workgroup pair (ideal 8192)\n", name, best, flops / best / 1e9, cyc);
 }
 
 int main() {
   const int Kp = 4224, rows = 65536 + 64, ktiles = 2048, blocks = 2048;
   double *Fc, *Fs, *out;
-  CK(hipMalloc(&Fc, (size_t)rows * Kp * 8)); CK(hipMalloc(&Fs, (size_t)rows * Kp * 8)); CK(hipMalloc(&out, (size_t)blocks * 512 * 8));
+  CK(hipMalloc(&Fc, (size_t)rows * Kp * 8)); CK(hipMalloc(&Fs, (size_t)rows * Kp * 8)); CK(hipMalloc(&out, (size_t)4096 * 512 * 8));
   std::vector<double> h((size_t)1 << 20);
   for (auto& v : h) v = rand() / (double)RAND_MAX - 0.5;
   for (size_t off = 0; off < (size_t)rows * Kp; off += h.size()) {
@@ -100,18 +99,11 @@ int main() {
     CK(hipMemcpy(Fc + off, h.data(), cnt * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(Fs + off, h.data() + 7, (cnt - 7) * 8, hipMemcpyHostToDevice));
   }
   double* out2; CK(hipMalloc(&out2, (size_t)4096 * 256 * 8));
-  printf("gram-like (k-major A and B), 2048 blocks x 2048 slices, ideal = 16384 cycles/slice\n");
-  run<0, true>("full", Fc, Fs, Kp, ktiles, blocks, out);
-  run<NO_GLOAD, true>("no global loads", Fc, Fs, Kp, ktiles, blocks, out);
-  run<NO_GLOAD | NO_LDS_STORE, true>("no gload, no LDS store", Fc, Fs, Kp, ktiles, blocks, out);
-  run<NO_GLOAD | NO_LDS_STORE | NO_BARRIER, true>("... and no barrier", Fc, Fs, Kp, ktiles, blocks, out);
-  run<NO_GLOAD | NO_LDS_STORE | NO_BARRIER | NO_FRAG, true>("... and no fragment reads (MFMA only)", Fc, Fs, Kp, ktiles, blocks, out);
-  run<NO_BARRIER, true>("full but no barrier (wrong results)", Fc, Fs, Kp, ktiles, blocks, out);
-  run<NO_FRAG, true>("full but no fragment reads", Fc, Fs, Kp, ktiles, blocks, out);
-  printf("rotate-like (m-major A: 264 slices of K, rows = blocks)\n");
-  run<0, false>("full", Fc, Fs, Kp, 264, 2048, out);
-  run<NO_GLOAD, false>("no global loads", Fc, Fs, Kp, 264, 2048, out);
-  run<NO_GLOAD | NO_LDS_STORE | NO_BARRIER, false>("no gload/LDS store/barrier", Fc, Fs, Kp, 264, 2048, out);
+  printf("REAL engine (sweep-like: m-major A, k-major B), 4096 blocks x 260 slices, 2 workgroups per CU\n");
+  run<0>("full", Fc, Fs, Kp, 260, 4096, out);
+  run<NO_GLOAD>("no global loads", Fc, Fs, Kp, 260, 4096, out);
+  run<NO_GLOAD | NO_LDS_STORE | NO_BARRIER>("no gload/LDS store/barrier", Fc, Fs, Kp, 260, 4096, out);
+  run<NO_GLOAD | NO_LDS_STORE | NO_BARRIER | NO_FRAG>("MFMA only", Fc, Fs, Kp, 260, 4096, out);
   printf("3M engine, 128x64 tile, 1 wave/SIMD: gram-like\n");
   run3<0, true>("3M full", Fc, Fs, Kp, ktiles, 4096, out2);
   run3<NO_GLOAD, true>("3M no global loads", Fc, Fs, Kp, ktiles, 4096, out2);

@@ -3,6 +3,7 @@
 from __future__ import annotations
 
 import ctypes
+import os
 import re
 from pathlib import Path
 
@@ -71,3 +72,17 @@ def test_host_orf_frequencies_match_fixture():
     g = load_golden("primal_reg_n2000_d48_D32")  # D < d': a single, truncated QR block
     Z = orf_frequencies(g["A_sep"].shape[1], int(g["D"]), 42)
     assert np.array_equal(Z, g["Z"])
+
+
+def test_3m_engine_agpr_invariant():
+    """The 3M engine names AGPRs a0..a191 in inline asm (csrc/nls_gemm3m.h): the compiler must allocate them to the
+    kernels and never use an AGPR itself there.  Checked on the ISA hipcc generates (cross-compile, no GPU needed)."""
+    import shutil
+    import subprocess
+    import sys
+
+    if not os.path.exists("/opt/rocm/bin/hipcc") and shutil.which("hipcc") is None:
+        pytest.skip("hipcc not available")
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "check_agpr.py")
+    r = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr

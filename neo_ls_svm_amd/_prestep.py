@@ -24,43 +24,68 @@ __all__ = ["target_bins", "weighted_median_columns", "fit_affine_normalizer", "f
 # --------------------------------------------------------------------------------------------
 # Target binning (ECDF quantisation)
 # --------------------------------------------------------------------------------------------
+def _first_break(ratio_lo, ratio_hi, ratio):
+    """Index of the first step at which the running [max lower, min upper] slope band excludes ``ratio`` (or -1)."""
+    lo = np.maximum(np.fmax.accumulate(ratio_lo), 0.0)
+    hi = np.fmin.accumulate(ratio_hi)
+    bad = ~((lo <= ratio) & (ratio <= hi))
+    hit = np.flatnonzero(bad)
+    return int(hit[0]) if hit.size else -1
+
+
 def _scan_right(xs, cum, knot, tol, cap):
     """Grow a bin [knot, nxt) to the right until its linear ECDF fit breaks ``tol`` or it exceeds ``cap``.
 
-    ``_quantizer.py:18-44``.  xs/cum carry the -inf/0 and +inf/max sentinels at both ends.
+    ``_quantizer.py:18-44`` (a sequential scan there); here the same decisions from prefix min / max arrays.
+    xs/cum carry the -inf/0 and +inf/max sentinels at both ends.  Returns (nxt, count) exactly as the scan does.
     """
-    lo, hi = 0.0, np.inf
-    nxt, count = knot, 0
-    for nxt in range(knot + 1, len(xs)):
-        count = int(cum[nxt - 1] - cum[knot - 1]) if knot > 0 else int(cum[nxt - 1])
-        if count > cap:
-            break
-        if nxt == knot + 1:
-            continue
-        dx, dy = xs[nxt - 1] - xs[knot], cum[nxt - 1] - cum[knot]
-        hi = min(hi, (dy + tol) / dx)
-        lo = max(lo, (dy - tol) / dx)
-        if not (lo <= dy / dx <= hi):
-            break
-    return nxt, count
+    last = len(xs) - 1
+    if knot + 1 > last:
+        return knot, 0
+    base = cum[knot - 1] if knot > 0 else 0
+    head = cum[knot:last]  # cum[nxt - 1] for nxt = knot + 1 .. last
+    nxt_cap = knot + 1 + int(np.searchsorted(head, base + cap, side="right"))  # first nxt whose count exceeds cap
+    stop = min(nxt_cap, last + 1)  # candidates for the slope test: nxt = knot + 2 .. stop - 1
+    nxt_tol = -1
+    if stop > knot + 2:
+        dx = xs[knot + 1:stop - 1] - xs[knot]
+        dy = cum[knot + 1:stop - 1] - cum[knot]
+        v = _first_break((dy - tol) / dx, (dy + tol) / dx, dy / dx)
+        if v >= 0:
+            nxt_tol = knot + 2 + v
+    if nxt_tol >= 0:
+        nxt = nxt_tol
+    elif nxt_cap <= last:
+        nxt = nxt_cap
+    else:
+        nxt = last
+    return nxt, int(cum[nxt - 1] - base)
 
 
 def _scan_left(xs, cum, knot, tol, cap):
     """Mirror image of ``_scan_right``: ``_quantizer.py:47-73``."""
-    lo, hi = 0.0, np.inf
-    prv, count = knot, 0
-    for prv in range(knot - 1, -1, -1):
-        count = int(cum[knot - 1] - cum[prv - 1]) if prv > 0 else int(cum[knot - 1])
-        if count > cap:
-            break
-        if knot == prv + 1:
-            continue
-        dx, dy = xs[knot - 1] - xs[prv], cum[knot - 1] - cum[prv]
-        hi = min(hi, (dy + tol) / dx)
-        lo = max(lo, (dy - tol) / dx)
-        if not (lo <= dy / dx <= hi):
-            break
-    return prv, count
+    if knot - 1 < 0:
+        return knot, 0
+    top = cum[knot - 1]
+    # count(prv) = top - (cum[prv - 1] if prv > 0 else 0) for prv = knot - 1 .. 0; it exceeds cap below prv_cap
+    below = np.concatenate(([0], cum[:knot - 1]))  # index prv -> cum[prv - 1] (0 for prv = 0), prv = 0 .. knot - 1
+    prv_cap = int(np.searchsorted(below, top - cap, side="left")) - 1  # largest prv with count > cap, or -1
+    start = max(prv_cap + 1, 0)  # candidates for the slope test: prv = knot - 2 .. start (descending)
+    prv_tol = -1
+    if knot - 2 >= start:
+        idx = np.arange(knot - 2, start - 1, -1)
+        dx = xs[knot - 1] - xs[idx]
+        dy = top - cum[idx]
+        v = _first_break((dy - tol) / dx, (dy + tol) / dx, dy / dx)
+        if v >= 0:
+            prv_tol = knot - 2 - v
+    if prv_tol >= 0:
+        prv = prv_tol
+    elif prv_cap >= 0:
+        prv = prv_cap
+    else:
+        prv = 0
+    return prv, int(top - (cum[prv - 1] if prv > 0 else 0))
 
 
 def _ecdf_bin_edges(values, max_bin_error=0.0125, max_bin_size=0.125, merge_bin_size=0.025):
@@ -103,11 +128,21 @@ def target_bins(y: np.ndarray) -> np.ndarray:
     Few distinct targets (<= ceil(sqrt(n))) are their own bins (classification); otherwise the target's
     ECDF is quantised into dynamically sized bins.
     """
+    y = np.asarray(y)
+    memo = _BINS_MEMO.get("last")  # fit() bins the same target twice (normaliser, separator): reuse the labels
+    if memo is not None and memo[0].shape == y.shape and memo[0].dtype == y.dtype and np.array_equal(memo[0], y):
+        return memo[1]
     uniq, inv = np.unique(y, return_inverse=True)
     if len(uniq) <= np.ceil(np.sqrt(len(y))):
-        return inv
-    edges = _ecdf_bin_edges(inv)  # the reference quantises the rank codes, not the raw values
-    return np.clip(np.searchsorted(edges, inv, side="right") - 1, 0, len(edges) - 2).astype(np.intp)
+        labels = inv
+    else:
+        edges = _ecdf_bin_edges(inv)  # the reference quantises the rank codes, not the raw values
+        labels = np.clip(np.searchsorted(edges, inv, side="right") - 1, 0, len(edges) - 2).astype(np.intp)
+    _BINS_MEMO["last"] = (y.copy(), labels)
+    return labels
+
+
+_BINS_MEMO: dict = {}
 
 
 # --------------------------------------------------------------------------------------------

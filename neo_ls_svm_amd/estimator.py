@@ -10,10 +10,10 @@ What differs is *where* the work happens:
     feature map, Gram, EVD, gamma sweep, Cholesky, sigma  GPU, one C-ABI call (``nls_primal_fit`` / ``nls_dual_fit``)
     inference                                             GPU (``nls_primal_predict`` / ``nls_dual_predict``)
     isotonic calibration, conformal split                 host sklearn, as ``_neo_ls_svm.py:405-441``
+    predict_quantiles / predict_interval                  ONE fused GPU predict (yhat + sigma) + the host LP layer ``conformal.py``
 
 Fitted state lives in NumPy attributes (beta, L, shift/scale/A) so the estimator pickles and predicts
-without the context that fitted it.  The conformal quantile regressors (``predict_quantiles`` /
-``predict_interval``) are outside the hot path and are not provided.
+without the context that fitted it.
 """
 
 from __future__ import annotations
@@ -26,6 +26,7 @@ from sklearn.model_selection import train_test_split
 from sklearn.utils.validation import check_array, check_consistent_length, check_is_fitted, check_X_y
 
 from . import _prestep, hotpath
+from .conformal import conformal_delta_quantiles
 from ._lib import default_context
 
 __all__ = ["NeoLSSVM", "AffineSeparator", "OrthogonalRandomFourierFeatures"]
@@ -240,6 +241,9 @@ class NeoLSSVM(BaseEstimator):
             train_size=min(1440, max(1024, (X.shape[0] * 2) // 3), X.shape[0] - 1),
             random_state=self.random_state,
         )
+        # Conformal predictors are fitted lazily per requested quantile tuple (:431-441).
+        self.conformal_l1_ = {"Δŷ": {}, "Δŷ/ŷ": {}}
+        self.conformal_l2_ = {"Δŷ": {}, "Δŷ/ŷ": {}}
         return self
 
     # ASCII aliases of the Greek attribute names.
@@ -285,12 +289,52 @@ class NeoLSSVM(BaseEstimator):
             _, sigma = hotpath.dual_predict(Xq, self.X_, L=self.L_[0], ctx=self._ctx())
         return _series_like(sigma, X)
 
+    def _yhat_sigma(self, Xa):
+        """decision_function and predict_std from ONE pass over X (one feature-map evaluation)."""
+        if self.primal_:
+            shift, scale, B = self.primal_feature_map_.map_params
+            return hotpath.primal_predict(Xa, shift, scale, B, beta=self.β̂_, L=self.L_[0], ctx=self._ctx())
+        Xq = np.ascontiguousarray(self.dual_feature_map_.transform(Xa))
+        return hotpath.dual_predict(Xq, self.X_, alpha=self.α̂_, L=self.L_[0], ctx=self._ctx())
+
+    def predict_quantiles(self, X, *, quantiles=(0.025, 0.5, 0.975), priority="accuracy"):
+        """Conformally calibrated quantiles (``:554-624``): [m x q] for a regressor, [m x q x 2] class probabilities
+        for a classifier; a DataFrame when X is one."""
+        Xa = self._check_X(X)
+        yhat, sigma = self._yhat_sigma(Xa)
+        delta = conformal_delta_quantiles(self, yhat, sigma, quantiles, priority)
+        out = yhat[:, None] + delta
+        is_clf = self._estimator_type == "classifier"
+        if is_clf:
+            pos = np.hstack([self.predict_proba_calibrator_.transform(out[:, j])[:, None] for j in range(out.shape[1])])
+            out = np.dstack([1 - pos[:, ::-1], pos])
+        elif not np.issubdtype(self.y_dtype_, np.integer):
+            out = out.astype(self.y_dtype_)
+        if hasattr(X, "dtypes") and hasattr(X, "index"):
+            import pandas as pd
+
+            if is_clf:
+                neg = pd.DataFrame(out[:, :, 0], index=X.index, columns=quantiles)
+                posd = pd.DataFrame(out[:, :, 1], index=X.index, columns=quantiles)
+                df = pd.concat([neg, posd], axis=0, keys=self.classes_, names=["class", X.index.name])
+            else:
+                df = pd.DataFrame(out, index=X.index, columns=quantiles)
+            df.columns.name = "quantile"
+            return df
+        return out
+
+    def predict_interval(self, X, *, coverage=0.95):
+        """Conformally calibrated central interval (``:636-646``): the (1-c)/2 and 1-(1-c)/2 quantiles, coverage first."""
+        lb = (1 - coverage) / 2
+        return self.predict_quantiles(X, quantiles=(lb, 1 - lb), priority="coverage")
+
     def predict(self, X, *, coverage=None, quantiles=None):
-        """Point predictions (``:719-762``).  Interval / quantile prediction is outside this package's scope."""
-        if coverage is not None or quantiles is not None:
-            raise NotImplementedError(
-                "conformal predict_quantiles / predict_interval are outside the MI355X hot path (SURVEY.md section 2, rows 6/8)"
-            )
+        """Point predictions, or an interval / quantiles when asked (``:719-762``)."""
+        assert coverage is None or quantiles is None
+        if coverage is not None:
+            return self.predict_interval(X, coverage=coverage)
+        if quantiles is not None:
+            return self.predict_quantiles(X, quantiles=quantiles)
         yhat = np.asarray(self.decision_function(X))
         if self._estimator_type == "classifier":
             sgn = np.sign(yhat)

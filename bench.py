@@ -197,7 +197,7 @@ def main():
         # scaled per row because every launch streams (rows x panels) with the same reuse pattern.
         traffic = None
         try:
-            pmc = json.loads((ROOT / "profiles" / "r01_pmc_summary.json").read_text())["k_rotate3"]
+            pmc = json.loads((ROOT / "profiles" / "r01b_pmc_summary.json").read_text())["k_rotate3"]
             if pmc["D"] == D and pmc["d"] == d:
                 rows_per_launch = stage["rotate_flops"] / launches / (8.0 * (D + 1) ** 2)
                 traffic = (pmc["fetch_bytes_x2"] + pmc["write_bytes"]) * rows_per_launch / pmc["rows_per_launch"]
@@ -235,7 +235,7 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": rot_tflops / FP64_MFMA_PEAK_TFLOPS,
                 "traffic": traffic,
-                "traffic_unit": "bytes/launch beyond L2 (2 x FETCH_SIZE + WRITE_SIZE, Infinity-Cache hits included), profiles/r01_pmc_summary.md",
+                "traffic_unit": "bytes/launch beyond L2 (2 x FETCH_SIZE + WRITE_SIZE, Infinity-Cache hits included), profiles/r01b_pmc_summary.md",
                 "note": "achieved counts the ALGORITHMIC 8 n (D+1)^2 flops of the four-product complex GEMM; the kernel executes "
                 "the 3M form (6 n Kf Np flops, Kf = ceil(D/128)*128, Np = ceil((D+1)/64)*64), so frac can exceed 1; executed_frac is the matrix-pipe utilisation",
                 "executed_frac": 6.0 * (stage["rotate_flops"] / (8.0 * (D + 1) ** 2)) * (-(-D // 128) * 128) * (-(-(D + 1) // 64) * 64)

@@ -1,12 +1,12 @@
 // Complex tile engine with the 3-multiplication (3M / Karatsuba) product - 25 % fewer fp64 MFMAs than the
-// four-product form in nls_gemm.h.
+// textbook four-product form.
 //
-// Both complex kernels of the path need   accR = Ac Br + As Bi ,  accI = Ac Bi - As Br   (nls_gemm.h).  With
+// Both complex kernels of the path need   accR = Ac Br + As Bi ,  accI = Ac Bi - As Br   .  With
 //     S1 = Ac Br ,  S2 = As Bi ,  S3 = (Ac - As)(Br + Bi) = S1 + accI - S2
 // three real accumulations give  accR = S1 + S2 ,  accI = S3 - S1 + S2 .  The difference / sum operands are formed
 // in registers from the fragments that are loaded anyway (one v_add_f64 per fragment), so LDS and HBM traffic are
 // those of the four-product kernel.  Normwise the rounding error is the same order as the 4M product (checked
-// end to end against the reference fixtures: beta, LOO residuals agree to 1e-13, profiles/r01_3m_numerics.txt).
+// end to end against the reference fixtures: beta, LOO residuals agree to 1e-13, profiles/r01b_numerics.txt).
 //
 // Geometry: 256 threads = 4 wave64s (2 x 2), one wave per SIMD, 128 x 64 output tile per workgroup, 64 x 32 per
 // wave = 4 x 2 MFMA tiles x 3 accumulators = 192 accumulator registers, which live in AGPRs a0 .. a191 for the

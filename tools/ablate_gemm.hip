@@ -110,7 +110,7 @@ int main() {
   run3<NO_GLOAD | NO_LDS_STORE, true>("3M no gload, no LDS store", Fc, Fs, Kp, ktiles, 4096, out2);
   run3<NO_GLOAD | NO_LDS_STORE | NO_BARRIER, true>("3M ... and no barrier", Fc, Fs, Kp, ktiles, 4096, out2);
   run3<NO_GLOAD | NO_LDS_STORE | NO_BARRIER | NO_FRAG, true>("3M MFMA only", Fc, Fs, Kp, ktiles, 4096, out2);
-  run3<ABL_NO_INTERLEAVE, true>("3M full, no sched_group_barrier", Fc, Fs, Kp, ktiles, 4096, out2);
+  run3<ABL_NO_INTERLEAVE, true>("3M full, side operations not interleaved", Fc, Fs, Kp, ktiles, 4096, out2);
   printf("3M rotate-like (m-major A)\n");
   run3<0, false>("3M full", Fc, Fs, Kp, 264, 4096, out2);
   run3<NO_GLOAD, false>("3M no global loads", Fc, Fs, Kp, 264, 4096, out2);

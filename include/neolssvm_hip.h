@@ -9,6 +9,8 @@
  *                           (AffineFeatureMap.transform inside it)       _affine_feature_map.py:72-92
  *   nls_gram_only           first product of _optimize_beta_gamma        _neo_ls_svm.py:110-114,127
  *   nls_rotate_only         leverage / numerator products of the same    _neo_ls_svm.py:128-143
+ *   nls_eigh_only           eigh(A / c) (primal), eigh(sn K sn) (dual)   _neo_ls_svm.py:120, 265
+ *   nls_tridiag_only        (its Householder tridiagonalisation stage)
  *   nls_primal_fit          NeoLSSVM._optimize_beta_gamma(phi, y, s, C)  _neo_ls_svm.py:77-189
  *                           fused with the transform that feeds it       _neo_ls_svm.py:386,401-402
  *   nls_primal_predict      decision_function / predict_std (primal)     _neo_ls_svm.py:661-665, 464-469,477
@@ -101,6 +103,17 @@ int nls_gram_only(nls_ctx* ctx, const double* X, const double* y, const double* 
  * complex128, both host.  U, Gm: n x (D+1) float64 host outputs, either may be NULL (timing only). */
 int nls_rotate_only(nls_ctx* ctx, const double* X, int64_t n, int d, const double* shift, const double* scale,
                     const double* B, int D, const double* Q, const double* v, double* U, double* Gm);
+
+/* ---- P4 / D2: eigendecomposition (test / bench hooks) -------------------------------------------
+ * The serial section of both fits: scipy.linalg.eigh(A / c) of the (D+1) x (D+1) Hermitian normal matrix
+ * (_neo_ls_svm.py:120) and numpy.linalg.eigh(sn K sn) of the n x n kernel (:265).  A: n x n column-major, host,
+ * complex128 (is_complex = 1) or float64 (0); only the lower triangle is read.
+ * nls_tridiag_only: A = Q T Q^H with LAPACK zhetrd / dsytrd (uplo = 'L') conventions: d[n], e[n-1], tau[n-1]
+ *   (complex128 or float64) and the reflectors written below the sub-diagonal of A (d, e on its diagonals).
+ * nls_eigh_only: eigenvalues ascending in lam[n], eigenvectors in the columns of A.  NLS_EVD=rocsolver in the
+ *   environment selects rocSOLVER's zheevd / dsyevd for every eigendecomposition of the library. */
+int nls_tridiag_only(nls_ctx* ctx, void* A, int n, int is_complex, double* d, double* e, void* tau);
+int nls_eigh_only(nls_ctx* ctx, void* A, int n, int is_complex, double* lam);
 
 /* ---- primal fit ------------------------------------------------------------------------------- */
 typedef struct nls_primal_fit_args {

@@ -8,6 +8,7 @@ from ._lib import Context, DeviceArray, NlsError, default_context, load_library 
 from .hotpath import (  # noqa: F401
     dual_fit,
     dual_predict,
+    eigh,
     featuremap,
     gamma_grid,
     gram,
@@ -16,6 +17,7 @@ from .hotpath import (  # noqa: F401
     primal_fit_sigma_grid,
     primal_predict,
     rotate,
+    tridiagonalize,
 )
 
 from .estimator import AffineSeparator, NeoLSSVM, OrthogonalRandomFourierFeatures  # noqa: E402,F401
@@ -38,4 +40,6 @@ __all__ = [
     "dual_predict",
     "gamma_grid",
     "orf_frequencies",
+    "eigh",
+    "tridiagonalize",
 ]

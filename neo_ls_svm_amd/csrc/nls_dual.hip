@@ -142,12 +142,12 @@ extern "C" int nls_dual_fit(nls_ctx* ctx, const nls_dual_fit_args* a) {
     tm[NLS_T_GRAM_FLOPS] += 2.0 * n * n * r;
   }
   // ---- D2: EVD of sn K sn ------------------------------------------------------------------------
+  double* Qev = nullptr;  // eigenvectors: in Q (rocSOLVER path) or in the EVD's own workspace
   {
     SpanGuard g(ctx, NLS_T_EVD);
     hipLaunchKernelGGL(k_dual_scale_sym, grid2(n, n), dim3(256), 0, ctx->stream, F, n_pad, d_sn, n, Q, n);
     HIPCHK(ctx, hipGetLastError());
-    BLASCHK(ctx, rocsolver_dsyevd(ctx->blas, rocblas_evect_original, rocblas_fill_lower, (rocblas_int)n, Q, (rocblas_int)n, lam, evd_e, dinfo));
-    NLSCHK(check_info(ctx, dinfo, "rocsolver_dsyevd"));
+    NLSCHK(evd_symmetric(ctx, Q, (int)n, lam, evd_e, dinfo, &Qev));
   }
   // ---- D3: reduced sweep -------------------------------------------------------------------------
   double *T = nullptr, *HD = nullptr, *AG = nullptr, *FA = nullptr;
@@ -157,8 +157,8 @@ extern "C" int nls_dual_fit(nls_ctx* ctx, const nls_dual_fit_args* a) {
   NLSCHK(ws_get_t(ctx, "dual.FA", (size_t)n_pad * Gp, &FA));
   {
     SpanGuard g(ctx, NLS_T_ROTATE);
-    hipLaunchKernelGGL(k_dual_build_W, grid2(n_pad, n_pad), dim3(256), 0, ctx->stream, Q, n, d_sn, W, n_pad);
-    hipLaunchKernelGGL(k_dual_qty, dim3((unsigned)n), dim3(256), 0, ctx->stream, Q, n, d_sn, dy, qy);
+    hipLaunchKernelGGL(k_dual_build_W, grid2(n_pad, n_pad), dim3(256), 0, ctx->stream, Qev, n, d_sn, W, n_pad);
+    hipLaunchKernelGGL(k_dual_qty, dim3((unsigned)n), dim3(256), 0, ctx->stream, Qev, n, d_sn, dy, qy);
     hipLaunchKernelGGL(k_zero_diag_copy, grid2(n_pad, n_pad), dim3(256), 0, ctx->stream, F, n_pad, n_pad, n, F0);
     HIPCHK(ctx, hipGetLastError());
     NLSCHK(gemm_store(ctx, F0, n_pad, W, n_pad, M, n_pad, n_pad, n_pad, n_pad));

@@ -1,0 +1,186 @@
+// Eigendecomposition of the path's Hermitian / real symmetric matrices (P4: _neo_ls_svm.py:120, D2: :265):
+// tridiagonalisation by the three-kernels-per-column panel of nls_trd.h, then rocSOLVER's divide-and-conquer
+// (stedc) on the tridiagonal matrix and its back-transformation (unmtr / ormtr).  NLS_EVD=rocsolver selects the
+// all-rocSOLVER zheevd / dsyevd instead.
+#include "nls_host.h"
+#include "nls_trd.h"
+
+namespace nls {
+
+static inline rocblas_status trd_rank2k(rocblas_handle h, int n2, int k, const trd::Z* V, long ldv, const trd::Z* W, long ldw, trd::Z* C, long ldc) {
+  const rocblas_double_complex minus_one(-1.0, 0.0);
+  const double one = 1.0;
+  return rocblas_zher2k(h, rocblas_fill_lower, rocblas_operation_none, n2, k, &minus_one, reinterpret_cast<const rocblas_double_complex*>(V),
+                        (rocblas_int)ldv, reinterpret_cast<const rocblas_double_complex*>(W), (rocblas_int)ldw, &one,
+                        reinterpret_cast<rocblas_double_complex*>(C), (rocblas_int)ldc);
+}
+static inline rocblas_status trd_rank2k(rocblas_handle h, int n2, int k, const double* V, long ldv, const double* W, long ldw, double* C, long ldc) {
+  const double minus_one = -1.0, one = 1.0;
+  return rocblas_dsyr2k(h, rocblas_fill_lower, rocblas_operation_none, n2, k, &minus_one, V, (rocblas_int)ldv, W, (rocblas_int)ldw, &one, C,
+                        (rocblas_int)ldc);
+}
+
+// A: n x n column-major (lda), lower triangle in, reflectors + (d, e on the diagonals) out; d[n], e[n-1], tau[n-1].
+template <class T>
+static int trd_fused(nls_ctx* ctx, T* A, int n, long lda, double* d, double* e, T* tau) {
+  using namespace trd;
+  if (n < 1) return NLS_OK;
+  const int NSC = (n + TS - 1) / TS, NSR = (n + RT - 1) / RT;  // column / row strips of the matrix-vector tiles
+  const int nrb = (n + ROWT - 1) / ROWT;
+  const int ndot_max = (n + RD - 1) / RD;
+  Args<T> a{};
+  a.A = A;
+  a.lda = lda;
+  a.n = n;
+  a.d = d;
+  a.e = e;
+  a.tau = tau;
+  a.nrowblocks = nrb;
+  NLSCHK(ws_get_t(ctx, "trd.W", (size_t)n * NB, &a.W));
+  NLSCHK(ws_get_t(ctx, "trd.wtmp", (size_t)n, &a.wtmp));
+  NLSCHK(ws_get_t(ctx, "trd.xvec", (size_t)n, &a.xvec));
+  NLSCHK(ws_get_t(ctx, "trd.ylow", (size_t)NSC * n, &a.ylow));
+  NLSCHK(ws_get_t(ctx, "trd.yup", (size_t)NSR * n, &a.yup));
+  NLSCHK(ws_get_t(ctx, "trd.zpart", (size_t)ndot_max * 2 * NB, &a.zpart));
+  NLSCHK(ws_get_t(ctx, "trd.spart", (size_t)nrb, &a.spart));
+  NLSCHK(ws_get_t(ctx, "trd.pnorm", (size_t)nrb, &a.pnorm));
+  HIPCHK(ctx, hipMemsetAsync(a.W, 0, sizeof(T) * (size_t)n * NB, ctx->stream));
+  BLASCHK(ctx, rocblas_set_stream(ctx->blas, ctx->stream));
+  for (int j0 = 0; j0 < n; j0 += NB) {
+    const int jend = std::min(j0 + NB, n);
+    a.j0 = j0;
+    for (int j = j0; j < jend; ++j) {
+      a.j = j;
+      const int i = j - j0;
+      a.ndot = i > 0 ? (n - j - 1 + RD - 1) / RD : 0;
+      hipLaunchKernelGGL(k_trd_column<T>, dim3(nrb), dim3(ROWT * TPR), 0, ctx->stream, a);
+      if (j < n - 1) {
+        const int S0 = (j + 1) / TS;
+        const int K = NSC - S0, ntiles = K * (K + 1) / 2;
+        hipLaunchKernelGGL(k_trd_hemv<T>, dim3(ntiles + a.ndot), dim3(256), 0, ctx->stream, a, S0, ntiles);
+        hipLaunchKernelGGL(k_trd_finish<T>, dim3(nrb), dim3(ROWT * TPR), 0, ctx->stream, a, S0, NSR);
+      }
+    }
+    HIPCHK(ctx, hipGetLastError());
+    const int jl = std::min(jend - 1, n - 2);  // last column of the panel that has a reflector
+    const int n2 = n - jend;
+    if (n2 > 0) {
+      hipLaunchKernelGGL(k_trd_panel_end<T>, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, a, jl);
+      BLASCHK(ctx, trd_rank2k(ctx->blas, n2, jend - j0, A + jend + (long)j0 * lda, lda, a.W + jend, n, A + jend + (long)jend * lda, lda));
+    }
+    if (jl >= j0)
+      hipLaunchKernelGGL(k_trd_restore_subdiag<T>, dim3(1), dim3(64), 0, ctx->stream, A, lda, e, j0, jl - j0 + 1);
+    HIPCHK(ctx, hipGetLastError());
+  }
+  return NLS_OK;
+}
+
+static bool evd_use_rocsolver() {
+  const char* m = std::getenv("NLS_EVD");
+  return m && std::string(m) == "rocsolver";
+}
+
+// Hermitian: A (n x n complex column-major, lower) is destroyed; eigenvalues ascending in lam, eigenvectors
+// (columns) in *Q, which is either A itself (rocSOLVER path) or the workspace "evd.C".
+static int evd_hermitian(nls_ctx* ctx, double2* A, int n, double* lam, double* e_work, rocblas_int* dinfo, double2** Q) {
+  BLASCHK(ctx, rocblas_set_stream(ctx->blas, ctx->stream));
+  if (evd_use_rocsolver() || n < 3) {
+    BLASCHK(ctx, rocsolver_zheevd(ctx->blas, rocblas_evect_original, rocblas_fill_lower, n, reinterpret_cast<rocblas_double_complex*>(A), n, lam,
+                                  e_work, dinfo));
+    NLSCHK(check_info(ctx, dinfo, "rocsolver_zheevd"));
+    *Q = A;
+    return NLS_OK;
+  }
+  trd::Z* tau = nullptr;
+  double2* C = nullptr;
+  NLSCHK(ws_get_t(ctx, "evd.tau", (size_t)n, &tau));
+  NLSCHK(ws_get_t(ctx, "evd.C", (size_t)n * n, &C));
+  NLSCHK(trd_fused<trd::Z>(ctx, reinterpret_cast<trd::Z*>(A), n, n, lam, e_work, tau));
+  BLASCHK(ctx, rocsolver_zstedc(ctx->blas, rocblas_evect_tridiagonal, n, lam, e_work, reinterpret_cast<rocblas_double_complex*>(C), n, dinfo));
+  NLSCHK(check_info(ctx, dinfo, "rocsolver_zstedc"));
+  BLASCHK(ctx, rocsolver_zunmtr(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, n, n,
+                                reinterpret_cast<rocblas_double_complex*>(A), n, reinterpret_cast<rocblas_double_complex*>(tau),
+                                reinterpret_cast<rocblas_double_complex*>(C), n));
+  *Q = C;
+  return NLS_OK;
+}
+
+static int evd_symmetric(nls_ctx* ctx, double* A, int n, double* lam, double* e_work, rocblas_int* dinfo, double** Q) {
+  BLASCHK(ctx, rocblas_set_stream(ctx->blas, ctx->stream));
+  if (evd_use_rocsolver() || n < 3) {
+    BLASCHK(ctx, rocsolver_dsyevd(ctx->blas, rocblas_evect_original, rocblas_fill_lower, n, A, n, lam, e_work, dinfo));
+    NLSCHK(check_info(ctx, dinfo, "rocsolver_dsyevd"));
+    *Q = A;
+    return NLS_OK;
+  }
+  double *tau = nullptr, *C = nullptr;
+  NLSCHK(ws_get_t(ctx, "evd.taur", (size_t)n, &tau));
+  NLSCHK(ws_get_t(ctx, "evd.Cr", (size_t)n * n, &C));
+  NLSCHK(trd_fused<double>(ctx, A, n, n, lam, e_work, tau));
+  BLASCHK(ctx, rocsolver_dstedc(ctx->blas, rocblas_evect_tridiagonal, n, lam, e_work, C, n, dinfo));
+  NLSCHK(check_info(ctx, dinfo, "rocsolver_dstedc"));
+  BLASCHK(ctx, rocsolver_dormtr(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, n, n, A, n, tau, C, n));
+  *Q = C;
+  return NLS_OK;
+}
+
+}  // namespace nls
+
+using namespace nls;
+
+extern "C" int nls_tridiag_only(nls_ctx* ctx, void* A, int n, int is_complex, double* d, double* e, void* tau) {
+  if (!ctx) return NLS_ERR_ARG;
+  if (!A || !d || !e || !tau || n < 1) return fail(ctx, NLS_ERR_ARG, "nls_tridiag_only: null pointer or n < 1");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const size_t esz = is_complex ? 16 : 8;
+  void *dA = nullptr, *dtau = nullptr;
+  double *dd = nullptr, *de = nullptr;
+  NLSCHK(ws_get(ctx, "hook.A", esz * (size_t)n * n, &dA));
+  NLSCHK(ws_get(ctx, "hook.tau", esz * (size_t)n, &dtau));
+  NLSCHK(ws_get_t(ctx, "hook.d", (size_t)n, &dd));
+  NLSCHK(ws_get_t(ctx, "hook.e", (size_t)n, &de));
+  HIPCHK(ctx, hipMemcpyAsync(dA, A, esz * (size_t)n * n, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(dtau, 0, esz * (size_t)n, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(de, 0, sizeof(double) * n, ctx->stream));
+  if (is_complex)
+    NLSCHK(trd_fused<trd::Z>(ctx, static_cast<trd::Z*>(dA), n, n, dd, de, static_cast<trd::Z*>(dtau)));
+  else
+    NLSCHK(trd_fused<double>(ctx, static_cast<double*>(dA), n, n, dd, de, static_cast<double*>(dtau)));
+  HIPCHK(ctx, hipMemcpyAsync(A, dA, esz * (size_t)n * n, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(d, dd, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+  if (n > 1) {
+    HIPCHK(ctx, hipMemcpyAsync(e, de, sizeof(double) * (n - 1), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(tau, dtau, esz * (size_t)(n - 1), hipMemcpyDeviceToHost, ctx->stream));
+  }
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return NLS_OK;
+}
+
+extern "C" int nls_eigh_only(nls_ctx* ctx, void* A, int n, int is_complex, double* lam) {
+  if (!ctx) return NLS_ERR_ARG;
+  if (!A || !lam || n < 1) return fail(ctx, NLS_ERR_ARG, "nls_eigh_only: null pointer or n < 1");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const size_t esz = is_complex ? 16 : 8;
+  void* dA = nullptr;
+  double *dlam = nullptr, *de = nullptr;
+  rocblas_int* dinfo = nullptr;
+  NLSCHK(ws_get(ctx, "hook.A", esz * (size_t)n * n, &dA));
+  NLSCHK(ws_get_t(ctx, "hook.d", (size_t)n, &dlam));
+  NLSCHK(ws_get_t(ctx, "hook.e", (size_t)n, &de));
+  NLSCHK(ws_get_t(ctx, "evd.info", 4, &dinfo));
+  HIPCHK(ctx, hipMemcpyAsync(dA, A, esz * (size_t)n * n, hipMemcpyHostToDevice, ctx->stream));
+  void* Q = nullptr;
+  if (is_complex) {
+    double2* q = nullptr;
+    NLSCHK(evd_hermitian(ctx, static_cast<double2*>(dA), n, dlam, de, dinfo, &q));
+    Q = q;
+  } else {
+    double* q = nullptr;
+    NLSCHK(evd_symmetric(ctx, static_cast<double*>(dA), n, dlam, de, dinfo, &q));
+    Q = q;
+  }
+  HIPCHK(ctx, hipMemcpyAsync(A, Q, esz * (size_t)n * n, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(lam, dlam, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return NLS_OK;
+}

@@ -199,7 +199,7 @@ __device__ __forceinline__ void mainloop_real(v4d (&acc)[Cfg::MT][Cfg::NTL], con
                                               long kbegin, int ktiles, double* smem) {
   constexpr int BUF = 2 * TILE_DOUBLES;
   constexpr int KS = BK / 4;
-  constexpr int NMFMA = Cfg::MT * Cfg::NTL, NFRAG = Cfg::MT + Cfg::NTL;
+  constexpr int NFRAG = Cfg::MT + Cfg::NTL;
   constexpr int SA = ALoad::NREG, SB = BLoad::NREG;
   static_assert(KS == 4, "fragment parity relies on an even number of sub-steps");
   v2d ra[SA], rb[SB];

@@ -576,11 +576,10 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
     SpanGuard g(ctx, NLS_T_EVD);
     NLSCHK(assemble_A(ctx, st, 1.0, Acm, db));
     NLSCHK(assemble_A(ctx, st, 1.0 / st.c, Qcm, nullptr));
-    BLASCHK(ctx, rocsolver_zheevd(ctx->blas, rocblas_evect_original, rocblas_fill_lower, D1,
-                                  reinterpret_cast<rocblas_double_complex*>(Qcm), D1, lam, evd_e, dinfo));
-    NLSCHK(check_info(ctx, dinfo, "rocsolver_zheevd"));
-    NLSCHK(build_rot_planes(ctx, mp, Qcm, 1L, (long)D1, false, rb));  // column-major Q
-    hipLaunchKernelGGL(k_compute_v, dim3((unsigned)Np), dim3(256), 0, ctx->stream, Qcm, (long)D1, db, D1, 1.0 / st.c, rb.vr, rb.vi);
+    double2* Qev = nullptr;  // eigenvectors: in Qcm (rocSOLVER path) or in the EVD's own workspace
+    NLSCHK(evd_hermitian(ctx, Qcm, D1, lam, evd_e, dinfo, &Qev));
+    NLSCHK(build_rot_planes(ctx, mp, Qev, 1L, (long)D1, false, rb));  // column-major Q
+    hipLaunchKernelGGL(k_compute_v, dim3((unsigned)Np), dim3(256), 0, ctx->stream, Qev, (long)D1, db, D1, 1.0 / st.c, rb.vr, rb.vi);
     const long tot = (long)Np * Gp;
     hipLaunchKernelGGL(k_rgrid, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, lam, dgam, D1, G, Np, Gp, R);
     HIPCHK(ctx, hipGetLastError());

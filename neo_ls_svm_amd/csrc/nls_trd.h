@@ -1,0 +1,440 @@
+// Householder tridiagonalisation of a Hermitian / real symmetric matrix (lower triangle, column-major), LAPACK
+// zhetrd / dsytrd conventions for d, e, tau and the reflectors left below the sub-diagonal - the serial section of
+// the path (P4: eigh(A / c), _neo_ls_svm.py:120; D2: eigh(sn K sn), :265).
+//
+// Why not rocsolver_zhetrd: its panel runs FIVE kernels per column (a 16 us matrix-vector product and four 4-5 us
+// vector kernels, profiles/r01b_c3_kernel_stats_summary.md) - 140 of the 219 ms of zheevd(4097) and 25 of the 28 ms
+// of zheevd(1025).  Here a column is THREE kernels, and the matrix-vector product reads the lower triangle once
+// (it sits in the 256 MB Infinity Cache: 134 MB at n = 4097):
+//   k_trd_column : x = A[j:, j] - V W[j, :]^H - W V[j, :]^H   (blocked zlatrd update of the column), d[j], |x|^2 partials
+//   k_trd_hemv   : y = A22 x on 64 x 64 tiles of the lower triangle - every tile adds its A x contribution to its
+//                  rows and its A^H x contribution to its columns - plus the short products W^H x, V^H x
+//   k_trd_finish : larfg scalars (beta, tau), v, w' = tau (A22 v - V (W^H v) - W (V^H v)), partials of w'^H v
+// The reflector is never formed before the product: with alpha = x[j+1], v = (x - beta e1) / (alpha - beta) and
+// A22 v = (A22 x - beta A22[:, 0]) / (alpha - beta), so the product runs on the un-normalised column while the norm
+// is still being reduced.  The last step of zlatrd, w = w' - tau/2 (w'^H v) v, needs a global scalar and is applied
+// by the NEXT column's k_trd_column.  All reductions go through per-block partials summed in a fixed order: results
+// are bit-reproducible.  After nb = 32 columns the trailing matrix gets the rank-2nb update (rocBLAS her2k / syr2k).
+// Not done: LAPACK's rescaling loop for |beta| < safmin (the matrices of this path are O(1)).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace nls {
+namespace trd {
+
+struct Z {
+  double re, im;
+};
+__device__ __forceinline__ Z operator+(Z a, Z b) { return {a.re + b.re, a.im + b.im}; }
+__device__ __forceinline__ Z operator-(Z a, Z b) { return {a.re - b.re, a.im - b.im}; }
+__device__ __forceinline__ Z operator*(Z a, Z b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+__device__ __forceinline__ Z operator*(double s, Z a) { return {s * a.re, s * a.im}; }
+__device__ __forceinline__ Z conj_(Z a) { return {a.re, -a.im}; }
+__device__ __forceinline__ double conj_(double a) { return a; }
+__device__ __forceinline__ double real_(Z a) { return a.re; }
+__device__ __forceinline__ double real_(double a) { return a; }
+__device__ __forceinline__ double imag_(Z a) { return a.im; }
+__device__ __forceinline__ double imag_(double) { return 0.0; }
+__device__ __forceinline__ double abs2_(Z a) { return a.re * a.re + a.im * a.im; }
+__device__ __forceinline__ double abs2_(double a) { return a * a; }
+template <class T>
+__device__ __forceinline__ T make_(double re, double im);
+template <>
+__device__ __forceinline__ Z make_<Z>(double re, double im) { return {re, im}; }
+template <>
+__device__ __forceinline__ double make_<double>(double re, double) { return re; }
+__device__ __forceinline__ Z inv_(Z a) {  // 1 / a
+  const double s = 1.0 / (a.re * a.re + a.im * a.im);
+  return {a.re * s, -a.im * s};
+}
+__device__ __forceinline__ double inv_(double a) { return 1.0 / a; }
+// component-wise select: a ternary on the struct itself is lowered through memory and keeps the arrays in scratch
+__device__ __forceinline__ Z sel_(bool c, Z a, Z b) { return {c ? a.re : b.re, c ? a.im : b.im}; }
+__device__ __forceinline__ double sel_(bool c, double a, double b) { return c ? a : b; }
+__device__ __forceinline__ Z shfl_xor_(Z a, int m) { return {__shfl_xor(a.re, m, 64), __shfl_xor(a.im, m, 64)}; }
+__device__ __forceinline__ double shfl_xor_(double a, int m) { return __shfl_xor(a, m, 64); }
+template <class T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) v = v + shfl_xor_(v, m);
+  return v;
+}
+
+constexpr int NB = 32;    // panel width
+constexpr int TS = 64;    // hemv tile edge
+constexpr int TPR = 8;    // threads per row in the row kernels (they split the panel columns / partial strips)
+constexpr int ROWT = 32;  // rows per block of the row kernels (256 threads)
+template <class T>
+__device__ __forceinline__ T row_sum(T v) {  // sum over the TPR consecutive lanes of one row, same value in all of them
+#pragma unroll
+  for (int m = 1; m < TPR; m <<= 1) v = v + shfl_xor_(v, m);
+  return v;
+}
+
+// larfg scalars from alpha = x[j+1] and xnorm^2 = |x[j+2:]|^2  (zlarfg / dlarfg)
+template <class T>
+struct Larfg {
+  double beta;
+  T tau, scale;  // scale = 1 / (alpha - beta)
+  bool identity;  // H = I (tau = 0)
+};
+template <class T>
+__device__ __forceinline__ Larfg<T> larfg(T alpha, double xnorm2) {
+  Larfg<T> h;
+  const double ar = real_(alpha), ai = imag_(alpha);
+  if (xnorm2 == 0.0 && ai == 0.0) {
+    h.identity = true;
+    h.beta = ar;
+    h.tau = make_<T>(0.0, 0.0);
+    h.scale = make_<T>(0.0, 0.0);
+    return h;
+  }
+  h.identity = false;
+  const double nrm = sqrt(ar * ar + ai * ai + xnorm2);
+  h.beta = ar >= 0.0 ? -nrm : nrm;
+  h.tau = make_<T>((h.beta - ar) / h.beta, -ai / h.beta);
+  h.scale = inv_(alpha - make_<T>(h.beta, 0.0));
+  return h;
+}
+
+template <class T>
+struct Args {
+  T* A;      // n x n column-major, lower triangle; columns < j hold the reflectors (explicit 1 on the sub-diagonal inside the panel)
+  long lda;
+  int n;
+  T* W;       // n x NB
+  T* wtmp;    // n: w' of the previous column (before the - tau/2 (w'^H v) v step)
+  T* xvec;    // n: the current column's x for rows > j, 0 above
+  T* ylow;    // [strips][n]  A x contributions per column strip
+  T* yup;     // [strips][n]  A^H x contributions per row strip
+  T* zpart;   // [dot blocks][2 NB]  partials of W^H x (first NB) and V^H x
+  T* spart;   // [row blocks]  partials of w'^H v of the previous column
+  double* pnorm;  // [row blocks]  partials of |x[j+2:]|^2
+  double* d;
+  double* e;
+  T* tau;
+  int j0, j;  // panel start, current column
+  int nrowblocks, ndot;
+};
+
+// Sum of cnt per-block partials, computed by the first wave of the block in a fixed order (lane-strided, then a
+// shuffle tree) and broadcast through shared memory.  Call with all threads of the block.
+template <class T>
+__device__ __forceinline__ T sum_partials(const T* p, int cnt, T* slot) {
+  if (threadIdx.x < 64) {
+    T s = make_<T>(0.0, 0.0);
+    for (int b = threadIdx.x; b < cnt; b += 64) s = s + p[b];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) *slot = s;
+  }
+  __syncthreads();
+  return *slot;
+}
+
+// ---- k1: column update -------------------------------------------------------------------------
+// 256 threads = 32 rows x TPR sub-lanes; sub-lane q takes the panel columns p = q, q + TPR, ...
+// Every global load that does not depend on the reduced scalar is issued before the first barrier.
+template <class T>
+__global__ void __launch_bounds__(ROWT * TPR) k_trd_column(Args<T> a) {
+  __shared__ double red[ROWT];
+  __shared__ T wj[NB], vj[NB], slot;
+  constexpr int PPT = NB / TPR;  // panel columns per sub-lane
+  const int j = a.j, i = a.j - a.j0, n = a.n;
+  const int q = threadIdx.x % TPR, rl = threadIdx.x / TPR;
+  const long r = (long)blockIdx.x * ROWT + rl;
+  const bool live = r < n && r >= j;
+  // ---- loads
+  T sp = make_<T>(0.0, 0.0);
+  if (i > 0 && threadIdx.x < 64)
+    for (int b = threadIdx.x; b < a.nrowblocks; b += 64) sp = sp + a.spart[b];
+  const T tau_prev = i > 0 ? a.tau[j - 1] : make_<T>(0.0, 0.0);
+  T wrow = make_<T>(0.0, 0.0), vrow = make_<T>(0.0, 0.0);  // row j of W', V for p = threadIdx.x
+  if (threadIdx.x < i) {
+    wrow = threadIdx.x == i - 1 ? a.wtmp[j] : a.W[(long)j + (long)threadIdx.x * n];
+    vrow = a.A[(long)j + (long)(a.j0 + threadIdx.x) * a.lda];
+  }
+  T xa = make_<T>(0.0, 0.0), wt = make_<T>(0.0, 0.0), vprev = make_<T>(0.0, 0.0), vv[PPT], ww[PPT];
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) vv[k] = ww[k] = make_<T>(0.0, 0.0);
+  if (live) {
+    xa = a.A[r + (long)j * a.lda];
+    if (i > 0) {
+      wt = a.wtmp[r];
+      vprev = a.A[r + (long)(j - 1) * a.lda];
+    }
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+      const int p = q + TPR * k;
+      if (p < i) {
+        vv[k] = a.A[r + (long)(a.j0 + p) * a.lda];
+        if (p < i - 1) ww[k] = a.W[r + (long)p * n];
+      }
+    }
+  }
+  // ---- alpha2 = -tau/2 (w'^H v) of the previous column; row j of W (final) and V, conjugated
+  T alpha2 = make_<T>(0.0, 0.0);
+  if (i > 0) {
+    if (threadIdx.x < 64) {
+      sp = wave_sum(sp);
+      if (threadIdx.x == 0) slot = sp;
+    }
+    __syncthreads();
+    alpha2 = (-0.5) * (tau_prev * slot);
+  }
+  if (threadIdx.x < i) {
+    wj[threadIdx.x] = conj_(threadIdx.x == i - 1 ? wrow + alpha2 * vrow : wrow);
+    vj[threadIdx.x] = conj_(vrow);
+  }
+  __syncthreads();
+  // ---- x = A[:, j] - V W[j, :]^H - W V[j, :]^H
+  double nrm = 0.0;
+  T corr = make_<T>(0.0, 0.0);
+  if (live) {
+    const T wlast = wt + alpha2 * vprev;  // final W[r][i - 1]
+    if (i > 0 && q == (i - 1) % TPR) a.W[r + (long)(i - 1) * n] = wlast;
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+      const int p = q + TPR * k;
+      if (p < i) corr = corr + vv[k] * wj[p] + (p == i - 1 ? wlast : ww[k]) * vj[p];
+    }
+  }
+  corr = row_sum(corr);
+  if (r < n && q == 0) {
+    if (!live) {
+      a.xvec[r] = make_<T>(0.0, 0.0);
+    } else {
+      T x = xa - corr;
+      if (r == j) {
+        x = make_<T>(real_(x), 0.0);
+        a.d[j] = real_(x);
+      }
+      a.A[r + (long)j * a.lda] = x;
+      a.xvec[r] = r > j ? x : make_<T>(0.0, 0.0);
+      if (r >= j + 2) nrm = abs2_(x);
+    }
+  }
+  if (q == 0) red[rl] = nrm;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const double t = wave_sum(threadIdx.x < ROWT ? red[threadIdx.x] : 0.0);
+    if (threadIdx.x == 0) a.pnorm[blockIdx.x] = t;
+  }
+}
+
+// ---- k2: y = A22 x on lower-triangle tiles, and the short products W^H x, V^H x -------------------------------
+// Tile blocks: 64 x 64; lane = row, wave = 16 columns whose loads are all in flight at once.  Tile (R, C) adds
+// sum_c A[r][c] x[c]  to ylow[C][r]  (one slot per column strip) and  sum_r conj(A[r][c]) x[r]  (r > c) to yup[R][c]
+// (one slot per row strip); k_trd_finish sums the slots.  Enumeration: R >= C over the active strips, row by row.
+// Dot blocks (after the tile blocks): RD = 64 rows each; wave w takes the panel columns p = w, w + 4, ... of W and V.
+constexpr int RT = 64;   // rows per matrix-vector tile (= TS)
+constexpr int RD = 64;   // rows per dot block
+constexpr int GW = 8;         // columns per butterfly group (8 keeps the kernel at ~100 registers, no scratch)
+
+// Column sums of v[0..8) over the 64 lanes by halving: after the step with mask m a lane keeps half of its values
+// (which half: its bit m) summed with its partner's - 7 exchanges, then 3 plain steps, instead of 8 x 6.
+// Result for column 4 b5 + 2 b4 + b3 (bits of the lane index) in v[0] of the lanes with (lane & 7) == 0.
+template <class T>
+__device__ __forceinline__ void butterfly8(T (&v)[GW], int lane) {
+#pragma unroll
+  for (int h = 4, m = 32; h >= 1; h >>= 1, m >>= 1) {
+    const bool hi = lane & m;
+#pragma unroll
+    for (int k = 0; k < h; ++k) {
+      const T send = sel_(hi, v[k], v[k + h]);
+      const T keep = sel_(hi, v[k + h], v[k]);
+      v[k] = keep + shfl_xor_(send, m);
+    }
+  }
+  v[0] = v[0] + shfl_xor_(v[0], 4);
+  v[0] = v[0] + shfl_xor_(v[0], 2);
+  v[0] = v[0] + shfl_xor_(v[0], 1);
+}
+__device__ __forceinline__ int butterfly_col(int lane) { return ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1); }
+
+template <class T>
+__global__ void __launch_bounds__(256, 2) k_trd_hemv(Args<T> a, int S0, int ntiles) {
+  __shared__ T sh[4][TS];
+  const int n = a.n, j = a.j, i = a.j - a.j0;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if ((int)blockIdx.x < ntiles) {
+    // tile (R, C) of RT x TS = 64 x 64; lane = row, wave w = columns 16 w .. 16 w + 15 (all 16 loads in flight at once)
+    int t = blockIdx.x, Rr = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+    while ((Rr + 1) * (Rr + 2) / 2 <= t) ++Rr;
+    while (Rr * (Rr + 1) / 2 > t) --Rr;
+    const int R = S0 + Rr, C = S0 + (t - Rr * (Rr + 1) / 2);
+    const long r = (long)R * RT + lane;
+    const T xr = r < n ? a.xvec[r] : make_<T>(0.0, 0.0);
+    T av[2 * GW];
+#pragma unroll
+    for (int cc = 0; cc < 2 * GW; ++cc) {
+      const long c = (long)C * TS + 2 * GW * w + cc;
+      av[cc] = make_<T>(0.0, 0.0);
+      if (r < n && c < n && r >= c) av[cc] = a.A[r + c * a.lda];
+    }
+    T low = make_<T>(0.0, 0.0);
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      T up[GW];  // this row's contribution to the columns of the group: conj(A[r][c]) x[r]
+#pragma unroll
+      for (int cc = 0; cc < GW; ++cc) {
+        const long c = (long)C * TS + 2 * GW * w + GW * g + cc;
+        T v = av[GW * g + cc];
+        if (r == c) v = make_<T>(real_(v), 0.0);
+        const T xc = c < n ? a.xvec[c] : make_<T>(0.0, 0.0);
+        low = low + v * xc;
+        up[cc] = sel_(r > c, conj_(v) * xr, make_<T>(0.0, 0.0));
+      }
+      butterfly8(up, lane);
+      if ((lane & 7) == 0) {
+        const long c = (long)C * TS + 2 * GW * w + GW * g + butterfly_col(lane);
+        if (c < n) a.yup[(long)R * n + c] = up[0];
+      }
+    }
+    sh[w][lane] = low;
+    __syncthreads();
+    if (w == 0 && r < n) a.ylow[(long)C * n + r] = ((sh[0][lane] + sh[1][lane]) + sh[2][lane]) + sh[3][lane];
+  } else {
+    // dot block: RD = 64 rows (lane = row); wave w takes the panel columns p = w, w + 4, ... of W and of V, all loads first
+    const int b = blockIdx.x - ntiles;
+    const long r = (long)j + 1 + (long)b * RD + lane;
+    const bool live = r < n;
+    const T xr = live ? a.xvec[r] : make_<T>(0.0, 0.0);
+    T mw[GW], mv[GW];
+#pragma unroll
+    for (int k = 0; k < GW; ++k) {
+      const int p = w + 4 * k;
+      mw[k] = mv[k] = make_<T>(0.0, 0.0);
+      if (live && p < i) {
+        mw[k] = a.W[r + (long)p * n];
+        mv[k] = a.A[r + (long)(a.j0 + p) * a.lda];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < GW; ++k) {
+      mw[k] = conj_(mw[k]) * xr;
+      mv[k] = conj_(mv[k]) * xr;
+    }
+    butterfly8(mw, lane);
+    butterfly8(mv, lane);
+    if ((lane & 7) == 0) {
+      const int p = w + 4 * butterfly_col(lane);
+      a.zpart[(long)b * 2 * NB + p] = sel_(p < i, mw[0], make_<T>(0.0, 0.0));
+      a.zpart[(long)b * 2 * NB + NB + p] = sel_(p < i, mv[0], make_<T>(0.0, 0.0));
+    }
+  }
+}
+
+// ---- k3: reflector, w', partials of w'^H v -------------------------------------------------------------------
+// Same layout as k_trd_column; all loads that do not depend on the reduced scalars come first.
+template <class T>
+__global__ void __launch_bounds__(ROWT * TPR) k_trd_finish(Args<T> a, int S0, int NS) {
+  __shared__ T zsh[4][2 * NB], zw[NB], zv[NB], red[ROWT];
+  __shared__ double dslot;
+  constexpr int PPT = NB / TPR;
+  const int n = a.n, j = a.j, i = a.j - a.j0;
+  const int q = threadIdx.x % TPR, rl = threadIdx.x / TPR;
+  const long r = (long)blockIdx.x * ROWT + rl;
+  const bool live = r < n && r >= j + 1;
+  // ---- loads
+  double pn = 0.0;
+  if (threadIdx.x < 64)
+    for (int b = threadIdx.x; b < a.nrowblocks; b += 64) pn += a.pnorm[b];
+  const T alpha = a.xvec[j + 1];
+  T zp = make_<T>(0.0, 0.0);  // thread (slot = t % 64, part = t / 64) sums the dot partials b = part, part + 4, ...
+  {
+    const int slot = threadIdx.x % (2 * NB), part = threadIdx.x / (2 * NB);
+    if (slot % NB < i)
+      for (int b = part; b < a.ndot; b += 4) zp = zp + a.zpart[(long)b * 2 * NB + slot];
+  }
+  T zrow = make_<T>(0.0, 0.0);  // row j + 1 of W (slots < NB) and of V
+  if (threadIdx.x < 2 * NB && threadIdx.x % NB < i) {
+    const int p = threadIdx.x % NB;
+    zrow = threadIdx.x >= NB ? a.A[(long)(j + 1) + (long)(a.j0 + p) * a.lda] : a.W[(long)(j + 1) + (long)p * n];
+  }
+  T y = make_<T>(0.0, 0.0), xr = make_<T>(0.0, 0.0), t0 = make_<T>(0.0, 0.0), vv[PPT], ww[PPT];
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) vv[k] = ww[k] = make_<T>(0.0, 0.0);
+  if (live) {
+    for (int C = S0 + q; C <= (int)(r / TS); C += TPR) y = y + a.ylow[(long)C * n + r];
+    for (int R = (int)(r / RT) + q; R < NS; R += TPR) y = y + a.yup[(long)R * n + r];  // NS: number of RT-row strips
+    xr = a.xvec[r];
+    t0 = a.A[r + (long)(j + 1) * a.lda];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+      const int p = q + TPR * k;
+      if (p < i) {
+        vv[k] = a.A[r + (long)(a.j0 + p) * a.lda];
+        ww[k] = a.W[r + (long)p * n];
+      }
+    }
+  }
+  // ---- reductions of the scalars
+  if (threadIdx.x < 64) {
+    pn = wave_sum(pn);
+    if (threadIdx.x == 0) dslot = pn;
+  }
+  zsh[threadIdx.x / (2 * NB)][threadIdx.x % (2 * NB)] = zp;
+  __syncthreads();
+  const Larfg<T> h = larfg<T>(alpha, dslot);
+  const T beta = make_<T>(h.beta, 0.0);
+  if (threadIdx.x < 2 * NB) {  // W^H v and V^H v from the products with x
+    const int p = threadIdx.x % NB;
+    T z = make_<T>(0.0, 0.0);
+    if (p < i && !h.identity)
+      z = ((((zsh[0][threadIdx.x] + zsh[1][threadIdx.x]) + zsh[2][threadIdx.x]) + zsh[3][threadIdx.x]) - beta * conj_(zrow)) * h.scale;
+    if (threadIdx.x >= NB) zv[p] = z; else zw[p] = z;
+  }
+  __syncthreads();
+  // ---- v, w'
+  T corr = make_<T>(0.0, 0.0);
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) {
+    const int p = q + TPR * k;
+    if (live && p < i) corr = corr + vv[k] * zw[p] + ww[k] * zv[p];
+  }
+  y = row_sum(y);
+  corr = row_sum(corr);
+  T sv = make_<T>(0.0, 0.0);
+  if (live && q == 0) {
+    T v, wp = make_<T>(0.0, 0.0);
+    if (h.identity) {
+      v = make_<T>(r == j + 1 ? 1.0 : 0.0, 0.0);
+    } else {
+      v = r == j + 1 ? make_<T>(1.0, 0.0) : xr * h.scale;
+      if (r == j + 1) t0 = make_<T>(real_(t0), 0.0);
+      wp = h.tau * ((y - beta * t0) * h.scale - corr);
+    }
+    a.wtmp[r] = wp;
+    a.A[r + (long)j * a.lda] = v;
+    sv = conj_(wp) * v;
+  }
+  if (r == 0 && q == 0) {
+    a.e[j] = h.beta;
+    a.tau[j] = h.tau;
+  }
+  if (q == 0) red[rl] = sv;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const T t = wave_sum(sel_(threadIdx.x < ROWT, red[threadIdx.x % ROWT], make_<T>(0.0, 0.0)));
+    if (threadIdx.x == 0) a.spart[blockIdx.x] = t;
+  }
+}
+
+// End of a panel (last column jl): finish column jl - j0 of W for the rows the rank-2nb update reads.
+template <class T>
+__global__ void k_trd_panel_end(Args<T> a, int jl) {
+  __shared__ T slot;
+  const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const T alpha2 = (-0.5) * (a.tau[jl] * sum_partials(a.spart, a.nrowblocks, &slot));
+  if (r >= a.n || r <= jl) return;
+  a.W[r + (long)(jl - a.j0) * a.n] = a.wtmp[r] + alpha2 * a.A[r + (long)jl * a.lda];
+}
+// After the trailing update: put e back on the sub-diagonal of the panel's columns (LAPACK layout).
+template <class T>
+__global__ void k_trd_restore_subdiag(T* A, long lda, const double* e, int j0, int cnt) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < cnt) A[(long)(j0 + p + 1) + (long)(j0 + p) * lda] = make_<T>(e[j0 + p], 0.0);
+}
+
+}  // namespace trd
+}  // namespace nls

@@ -24,6 +24,8 @@ __all__ = [
     "gram",
     "rotate",
     "bin_stats",
+    "tridiagonalize",
+    "eigh",
     "primal_fit",
     "primal_fit_sigma_grid",
     "primal_predict",
@@ -135,6 +137,38 @@ def rotate(X, shift, scale, B, Q, v, ctx: Context | None = None, want_outputs: b
         )
     )  # fmt: skip
     return U, Gm
+
+
+def tridiagonalize(A, ctx: Context | None = None):
+    """(d, e, tau, reflectors) of the Householder tridiagonalisation A = Q T Q^H, LAPACK ``zhetrd`` / ``dsytrd``
+    conventions with ``uplo='L'`` - the first stage of the eigendecompositions at ``_neo_ls_svm.py:120`` and ``:265``.
+    Only the lower triangle of the (complex Hermitian or real symmetric) matrix is read."""
+    ctx = ctx or default_context()
+    A = np.asarray(A)
+    cplx = np.iscomplexobj(A)
+    Af = np.asfortranarray(A, dtype=np.complex128 if cplx else np.float64).copy(order="F")
+    n = Af.shape[0]
+    if Af.shape != (n, n) or n < 1:
+        raise ValueError("A must be a non-empty square matrix")
+    d, e = np.empty(n), np.zeros(max(n - 1, 1))
+    tau = np.zeros(max(n - 1, 1), dtype=Af.dtype)
+    ctx._check(ctx.lib.nls_tridiag_only(ctx.handle, Af.ctypes.data, n, int(cplx), d.ctypes.data, e.ctypes.data, tau.ctypes.data))
+    return d, e[: n - 1], tau[: n - 1], Af
+
+
+def eigh(A, ctx: Context | None = None):
+    """(eigenvalues ascending, eigenvectors in columns) of a Hermitian / real symmetric matrix given by its lower
+    triangle: ``scipy.linalg.eigh`` at ``_neo_ls_svm.py:120`` / ``numpy.linalg.eigh`` at ``:265``."""
+    ctx = ctx or default_context()
+    A = np.asarray(A)
+    cplx = np.iscomplexobj(A)
+    Af = np.asfortranarray(A, dtype=np.complex128 if cplx else np.float64).copy(order="F")
+    n = Af.shape[0]
+    if Af.shape != (n, n) or n < 1:
+        raise ValueError("A must be a non-empty square matrix")
+    lam = np.empty(n)
+    ctx._check(ctx.lib.nls_eigh_only(ctx.handle, Af.ctypes.data, n, int(cplx), lam.ctypes.data))
+    return lam, Af
 
 
 def bin_stats(X, labels, sample_weight=None, ctx: Context | None = None):

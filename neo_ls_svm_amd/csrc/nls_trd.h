@@ -62,8 +62,8 @@ __device__ __forceinline__ T wave_sum(T v) {
 
 constexpr int NB = 32;    // panel width
 constexpr int TS = 64;    // hemv tile edge
-constexpr int TPR = 8;    // threads per row in the row kernels (they split the panel columns / partial strips)
-constexpr int ROWT = 32;  // rows per block of the row kernels (256 threads)
+constexpr int TPR = 16;   // threads per row in the row kernels (they split the panel columns / partial strips)
+constexpr int ROWT = 16;  // rows per block of the row kernels (256 threads)
 template <class T>
 __device__ __forceinline__ T row_sum(T v) {  // sum over the TPR consecutive lanes of one row, same value in all of them
 #pragma unroll
@@ -355,8 +355,22 @@ __global__ void __launch_bounds__(ROWT * TPR) k_trd_finish(Args<T> a, int S0, in
 #pragma unroll
   for (int k = 0; k < PPT; ++k) vv[k] = ww[k] = make_<T>(0.0, 0.0);
   if (live) {
-    for (int C = S0 + q; C <= (int)(r / TS); C += TPR) y = y + a.ylow[(long)C * n + r];
-    for (int R = (int)(r / RT) + q; R < NS; R += TPR) y = y + a.yup[(long)R * n + r];  // NS: number of RT-row strips
+    // strip partials of the matrix-vector product, four independent chains so that the loads overlap
+    T y1 = make_<T>(0.0, 0.0), y2 = y1, y3 = y1;
+    const int Clast = (int)(r / TS);
+    for (int C = S0 + q; C <= Clast; C += 4 * TPR) {
+      y = y + a.ylow[(long)C * n + r];
+      if (C + TPR <= Clast) y1 = y1 + a.ylow[(long)(C + TPR) * n + r];
+      if (C + 2 * TPR <= Clast) y2 = y2 + a.ylow[(long)(C + 2 * TPR) * n + r];
+      if (C + 3 * TPR <= Clast) y3 = y3 + a.ylow[(long)(C + 3 * TPR) * n + r];
+    }
+    for (int R = (int)(r / RT) + q; R < NS; R += 4 * TPR) {  // NS: number of RT-row strips
+      y = y + a.yup[(long)R * n + r];
+      if (R + TPR < NS) y1 = y1 + a.yup[(long)(R + TPR) * n + r];
+      if (R + 2 * TPR < NS) y2 = y2 + a.yup[(long)(R + 2 * TPR) * n + r];
+      if (R + 3 * TPR < NS) y3 = y3 + a.yup[(long)(R + 3 * TPR) * n + r];
+    }
+    y = (y + y1) + (y2 + y3);
     xr = a.xvec[r];
     t0 = a.A[r + (long)(j + 1) * a.lda];
 #pragma unroll

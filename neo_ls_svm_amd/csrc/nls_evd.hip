@@ -20,6 +20,11 @@ static inline rocblas_status trd_rank2k(rocblas_handle h, int n2, int k, const d
                         (rocblas_int)ldc);
 }
 
+static bool trd_use_rocblas_rank2k() {  // NLS_TRD_RANK2K=rocblas: trailing updates through zher2k / dsyr2k (diagnostic)
+  const char* m = std::getenv("NLS_TRD_RANK2K");
+  return m && std::string(m) == "rocblas";
+}
+
 // A: n x n column-major (lda), lower triangle in, reflectors + (d, e on the diagonals) out; d[n], e[n-1], tau[n-1].
 template <class T>
 static int trd_fused(nls_ctx* ctx, T* A, int n, long lda, double* d, double* e, T* tau) {
@@ -66,7 +71,12 @@ static int trd_fused(nls_ctx* ctx, T* A, int n, long lda, double* d, double* e, 
     const int n2 = n - jend;
     if (n2 > 0) {
       hipLaunchKernelGGL(k_trd_panel_end<T>, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, a, jl);
-      BLASCHK(ctx, trd_rank2k(ctx->blas, n2, jend - j0, A + jend + (long)j0 * lda, lda, a.W + jend, n, A + jend + (long)jend * lda, lda));
+      if (trd_use_rocblas_rank2k()) {
+        BLASCHK(ctx, trd_rank2k(ctx->blas, n2, jend - j0, A + jend + (long)j0 * lda, lda, a.W + jend, n, A + jend + (long)jend * lda, lda));
+      } else {
+        const int ut = (n2 + UT - 1) / UT;
+        hipLaunchKernelGGL(k_trd_rank2k<T>, dim3(ut * (ut + 1) / 2), dim3(256), 0, ctx->stream, A, lda, a.W, (long)n, n, j0, jend - j0, jend);
+      }
     }
     if (jl >= j0)
       hipLaunchKernelGGL(k_trd_restore_subdiag<T>, dim3(1), dim3(64), 0, ctx->stream, A, lda, e, j0, jl - j0 + 1);

@@ -13,6 +13,7 @@ from __future__ import annotations
 import ctypes as C
 
 import numpy as np
+from threadpoolctl import threadpool_limits
 
 from . import _lib
 from ._lib import Context, DeviceArray, DualFitArgs, PrimalFitArgs, default_context
@@ -43,15 +44,18 @@ def gamma_grid(num: int) -> np.ndarray:
 def orf_frequencies(d: int, D: int, random_state=42) -> np.ndarray:
     """Orthogonal random frequencies Z (d x D), host side (P0): ``_feature_maps.py:209-223``.
 
-    O(d^2 D) on a d x D matrix, negligible next to the fit; it stays on the host so that the legacy
-    ``RandomState`` stream (and therefore Z) is bit-identical to the reference's.
+    O(d^2 D) on a d x D matrix; it stays on the host so that the legacy ``RandomState`` stream is the reference's
+    (Z then agrees with the reference's to the rounding of LAPACK's QR, which varies with the BLAS thread count).
     """
     gen = random_state if isinstance(random_state, np.random.RandomState) else np.random.RandomState(random_state)
     Z = gen.randn(d, D)
-    for j in range(0, D, d):
-        block = Z[:, j : j + d]
-        q, _ = np.linalg.qr(block)
-        Z[:, j : j + block.shape[1]] = q[:, : block.shape[1]]
+    # A d x d QR on 64+ BLAS threads spends its time in thread hand-offs (0.20 s per 896 x 896 block on the GPU box's
+    # host against 0.03 s on 8 threads; the rounding pattern depends on the thread count either way).
+    with threadpool_limits(limits=8, user_api="blas"):
+        for j in range(0, D, d):
+            block = Z[:, j : j + d]
+            q, _ = np.linalg.qr(block)
+            Z[:, j : j + block.shape[1]] = q[:, : block.shape[1]]
     Z *= np.sqrt(gen.chisquare(d, size=(1, D)))
     return Z
 

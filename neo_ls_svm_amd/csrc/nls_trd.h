@@ -53,6 +53,11 @@ __device__ __forceinline__ Z sel_(bool c, Z a, Z b) { return {c ? a.re : b.re, c
 __device__ __forceinline__ double sel_(bool c, double a, double b) { return c ? a : b; }
 __device__ __forceinline__ Z shfl_xor_(Z a, int m) { return {__shfl_xor(a.re, m, 64), __shfl_xor(a.im, m, 64)}; }
 __device__ __forceinline__ double shfl_xor_(double a, int m) { return __shfl_xor(a, m, 64); }
+// value of lane `src` (a compile-time or wave-uniform index) as a scalar broadcast: no vector register, no memory
+__device__ __forceinline__ double lane_bcast(double v, int src) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+__device__ __forceinline__ Z lane_bcast(Z v, int src) { return {lane_bcast(v.re, src), lane_bcast(v.im, src)}; }
 template <class T>
 __device__ __forceinline__ T wave_sum(T v) {
 #pragma unroll
@@ -255,7 +260,8 @@ template <class T>
 __global__ void __launch_bounds__(256, 2) k_trd_hemv(Args<T> a, int S0, int ntiles) {
   __shared__ T sh[4][TS];
   const int n = a.n, j = a.j, i = a.j - a.j0;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave index as a scalar: x[c] below becomes scalar loads
   if ((int)blockIdx.x < ntiles) {
     // tile (R, C) of RT x TS = 64 x 64; lane = row, wave w = columns 16 w .. 16 w + 15 (all 16 loads in flight at once)
     int t = blockIdx.x, Rr = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
@@ -271,6 +277,9 @@ __global__ void __launch_bounds__(256, 2) k_trd_hemv(Args<T> a, int S0, int ntil
       av[cc] = make_<T>(0.0, 0.0);
       if (r < n && c < n && r >= c) av[cc] = a.A[r + c * a.lda];
     }
+    // x of the wave's 16 columns: lane l < 16 loads x[c0 + l], every lane then reads it as a scalar broadcast
+    const long cl = (long)C * TS + 2 * GW * w + (lane & 15);
+    const T xcol = cl < n ? a.xvec[cl] : make_<T>(0.0, 0.0);
     T low = make_<T>(0.0, 0.0);
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
@@ -280,7 +289,7 @@ __global__ void __launch_bounds__(256, 2) k_trd_hemv(Args<T> a, int S0, int ntil
         const long c = (long)C * TS + 2 * GW * w + GW * g + cc;
         T v = av[GW * g + cc];
         if (r == c) v = make_<T>(real_(v), 0.0);
-        const T xc = c < n ? a.xvec[c] : make_<T>(0.0, 0.0);
+        const T xc = lane_bcast(xcol, GW * g + cc);
         low = low + v * xc;
         up[cc] = sel_(r > c, conj_(v) * xr, make_<T>(0.0, 0.0));
       }

@@ -285,6 +285,34 @@ class Context:
     def empty(self, shape) -> DeviceArray:
         return DeviceArray(self, shape)
 
+    # ---- one upload per fit ------------------------------------------------------------------------
+    def hold(self, a: np.ndarray):
+        """Context manager: upload the host matrix ``a`` once and let every hot-path call made inside the ``with``
+        block that is handed this very array (same object, or a view of the same memory, shape and strides) use the
+        device copy - the estimator's ``fit`` passes X to the pre-step statistics and to the solver."""
+        ctx = self
+
+        class _Hold:
+            def __enter__(self_inner):
+                arr = np.asarray(a)
+                if arr.dtype == np.float64 and arr.ndim == 2 and arr.flags.c_contiguous and arr.size:
+                    ctx._held = (arr.__array_interface__["data"][0], arr.shape, arr.strides, ctx.to_device(arr))
+                return self_inner
+
+            def __exit__(self_inner, *exc):
+                ctx._held = None
+                return False
+
+        return _Hold()
+
+    def held(self, a):
+        """The device copy made by ``hold`` if ``a`` is that host matrix, else ``a`` itself."""
+        h = getattr(self, "_held", None)
+        if h is not None and isinstance(a, np.ndarray) and a.dtype == np.float64:
+            if (a.__array_interface__["data"][0], a.shape, a.strides) == h[:3]:
+                return h[3]
+        return a
+
     def set_allreduce(self, fn, rank: int, world: int):
         """fn(device_ptr: int, count: int) -> None sums `count` doubles at `device_ptr` over all ranks."""
         if fn is None or world <= 1:

@@ -191,9 +191,10 @@ class NeoLSSVM(BaseEstimator):
                 fm = OrthogonalRandomFourierFeatures(
                     num_features=int(getattr(fm, "num_features", 512)), random_state=getattr(fm, "random_state", 42)
                 )
-            self.primal_feature_map_ = clone(fm).fit(X, y_, sw)
-            shift, scale, B = self.primal_feature_map_.map_params
-            r = hotpath.primal_fit(X, y_, sw, shift, scale, B, is_clf, ctx=ctx)
+            with ctx.hold(X):  # one upload of X serves the pre-step's bin statistics and the solver
+                self.primal_feature_map_ = clone(fm).fit(X, y_, sw)
+                shift, scale, B = self.primal_feature_map_.map_params
+                r = hotpath.primal_fit(X, y_, sw, shift, scale, B, is_clf, ctx=ctx)
             self.β̂_, self.γ_ = r["beta"], r["gamma"]
             self.loo_leverage_ = r["loo_leverage"]
         else:

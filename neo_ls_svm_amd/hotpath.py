@@ -179,7 +179,7 @@ def bin_stats(X, labels, sample_weight=None, ctx: Context | None = None):
     """(centers, spreads), each nbins x d: per class bin the weighted median and weighted mean absolute deviation of
     every input column (``_affine_normalizer.py:72-79``) on the GPU (segmented radix sort + one scan per segment)."""
     ctx = ctx or default_context()
-    X = _f64(X, "X")
+    X = _f64(ctx.held(X), "X")
     n, d = X.shape
     labels = np.asarray(labels)
     lo, hi = int(labels.min()), int(labels.max())
@@ -218,7 +218,7 @@ def primal_fit(
     format, lower=False), residuals, loo_std, lam, timings.
     """
     ctx = ctx or default_context()
-    X = _f64(X, "X")
+    X = _f64(ctx.held(X), "X")
     if len(X.shape) != 2:
         raise ValueError("X must be 2-D")
     n, d = X.shape

@@ -29,6 +29,8 @@ CONFIGS = {
     "c2": dict(n=100_000, d=64, D=1024, G=1024, name="synthetic regression n=1e5 d=64 D=1024 ORF, primal, G=1024"),
     # BASELINE.json configs[4]: gamma x sigma grid (32 x 16); one eigendecomposition per sigma serves all 32 gammas.
     # N > 1 shards the SIGMAS (every rank holds all rows, no collective in the data path) -> "weak"-style replicas.
+    # one eighth of c3: what one rank of an 8-GPU row-sharded c3 fit computes locally (scaling diagnostics)
+    "c3e": dict(n=125_000, d=128, D=4096, G=1024, name="synthetic regression n=1.25e5 d=128 D=4096 ORF, primal, G=1024"),
     "c5": dict(n=1_000_000, d=128, D=4096, G=32, sigmas=16, name="gamma x sigma LOO grid 32 x 16, n=1e6 d=128 D=4096 ORF, primal"),
     # one row chunk of c3 (profiling: same kernels, same D, 1/4 of the rows)
     "c3q": dict(n=262_144, d=128, D=4096, G=1024, name="synthetic regression n=262144 d=128 D=4096 ORF, primal, G=1024"),

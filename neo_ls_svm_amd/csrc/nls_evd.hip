@@ -92,7 +92,10 @@ static bool evd_use_rocsolver() {
 
 // Hermitian: A (n x n complex column-major, lower) is destroyed; eigenvalues ascending in lam, eigenvectors
 // (columns) in *Q, which is either A itself (rocSOLVER path) or the workspace "evd.C".
-static int evd_hermitian(nls_ctx* ctx, double2* A, int n, double* lam, double* e_work, rocblas_int* dinfo, double2** Q) {
+// collective = true (nls_primal_fit, where every rank holds the same all-reduced matrix): the back-transformation of
+// the eigenvectors is split by columns over the ranks and the blocks are exchanged through the all-reduce hook
+// (every rank contributes zeros outside its block, so the sum is an exact all-gather and Q is bit-identical everywhere).
+static int evd_hermitian(nls_ctx* ctx, double2* A, int n, double* lam, double* e_work, rocblas_int* dinfo, double2** Q, bool collective = false) {
   BLASCHK(ctx, rocblas_set_stream(ctx->blas, ctx->stream));
   if (evd_use_rocsolver() || n < 3) {
     BLASCHK(ctx, rocsolver_zheevd(ctx->blas, rocblas_evect_original, rocblas_fill_lower, n, reinterpret_cast<rocblas_double_complex*>(A), n, lam,
@@ -108,9 +111,19 @@ static int evd_hermitian(nls_ctx* ctx, double2* A, int n, double* lam, double* e
   NLSCHK(trd_fused<trd::Z>(ctx, reinterpret_cast<trd::Z*>(A), n, n, lam, e_work, tau));
   BLASCHK(ctx, rocsolver_zstedc(ctx->blas, rocblas_evect_tridiagonal, n, lam, e_work, reinterpret_cast<rocblas_double_complex*>(C), n, dinfo));
   NLSCHK(check_info(ctx, dinfo, "rocsolver_zstedc"));
-  BLASCHK(ctx, rocsolver_zunmtr(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, n, n,
-                                reinterpret_cast<rocblas_double_complex*>(A), n, reinterpret_cast<rocblas_double_complex*>(tau),
-                                reinterpret_cast<rocblas_double_complex*>(C), n));
+  if (collective && ctx->world > 1 && ctx->allreduce && n >= 64) {
+    const long c0 = (long)n * ctx->rank / ctx->world, c1 = (long)n * (ctx->rank + 1) / ctx->world;
+    BLASCHK(ctx, rocsolver_zunmtr(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, n, (rocblas_int)(c1 - c0),
+                                  reinterpret_cast<rocblas_double_complex*>(A), n, reinterpret_cast<rocblas_double_complex*>(tau),
+                                  reinterpret_cast<rocblas_double_complex*>(C + c0 * n), n));
+    HIPCHK(ctx, hipMemsetAsync(C, 0, sizeof(double2) * (size_t)c0 * n, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(C + c1 * n, 0, sizeof(double2) * (size_t)(n - c1) * n, ctx->stream));
+    NLSCHK(do_allreduce(ctx, reinterpret_cast<double*>(C), (size_t)2 * n * n));
+  } else {
+    BLASCHK(ctx, rocsolver_zunmtr(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, n, n,
+                                  reinterpret_cast<rocblas_double_complex*>(A), n, reinterpret_cast<rocblas_double_complex*>(tau),
+                                  reinterpret_cast<rocblas_double_complex*>(C), n));
+  }
   *Q = C;
   return NLS_OK;
 }

@@ -577,7 +577,7 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
     NLSCHK(assemble_A(ctx, st, 1.0, Acm, db));
     NLSCHK(assemble_A(ctx, st, 1.0 / st.c, Qcm, nullptr));
     double2* Qev = nullptr;  // eigenvectors: in Qcm (rocSOLVER path) or in the EVD's own workspace
-    NLSCHK(evd_hermitian(ctx, Qcm, D1, lam, evd_e, dinfo, &Qev));
+    NLSCHK(evd_hermitian(ctx, Qcm, D1, lam, evd_e, dinfo, &Qev, true));
     NLSCHK(build_rot_planes(ctx, mp, Qev, 1L, (long)D1, false, rb));  // column-major Q
     hipLaunchKernelGGL(k_compute_v, dim3((unsigned)Np), dim3(256), 0, ctx->stream, Qev, (long)D1, db, D1, 1.0 / st.c, rb.vr, rb.vi);
     const long tot = (long)Np * Gp;

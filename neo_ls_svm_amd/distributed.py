@@ -1,11 +1,13 @@
 """Row sharding over one process per GPU.
 
 The primal path shards by rows: every rank calls ``primal_fit`` on its own contiguous block
-of X, y, s and the library all-reduces, through the hook registered here, exactly three things:
+of X, y, s and the library all-reduces, through the hook registered here, exactly four things:
 
     1. {sum s, sum s*y, n}                 -> global weight normalisation and c = 1 / (n_total (D+1))
     2. the tile-packed Hermitian block A||b -> identical normal equations (hence EVD, beta, L) on every rank
-    3. the per-gamma error vectors          -> identical argmin on every rank
+    3. the eigenvector matrix Q             -> each rank back-transforms its own column block of the eigenvectors and
+                                               contributes zeros elsewhere: an exact all-gather (bit-identical Q)
+    4. the per-gamma error vectors          -> identical argmin on every rank
     (+ the two scalars of the LOO score)
 
 Per-row outputs (loo_residuals, loo_leverage, loo_std, residuals) stay sharded.  The collective itself is

@@ -1,0 +1,69 @@
+"""Full-size (BASELINE c3: n = 1e6, d = 128, D = 4096, G = 1024) check of the primal fit through size-independent
+identities - the oracle cannot run at this size, the algebra can:
+
+* normal equations of the re-solve:  (gamma* c I + A) beta = b  with A, b from the Gram hook, c = 1 / (n (D + 1));
+* the two routes to the selected column agree: the EVD sweep's LOO residuals and leverages reproduce the Cholesky
+  route's residuals,  e_loo (1 - leverage) = residuals  (regression, no clipping; leverage_i = s_i^2 phi_i M^-1 phi_i^H
+  with the normalised s, ``_neo_ls_svm.py:136-150,169``);
+* residuals = Re(phi beta) - y on sampled rows (feature-map hook), sigma from the stored factor (predict hook) ties
+  loo_std to the leverage:  leverage = s^2 sigma^2,  loo_std^2 = sigma^2 + (s sigma^2)^2 / (1 - leverage)  (``:184-187``);
+* loo_errors[gamma*] = sum_i s_i |e_i|;  eigenvalues positive, ascending, trace(A) / c = sum(lam).
+"""
+from __future__ import annotations
+
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+pytestmark = pytest.mark.gpu
+
+
+def test_c3_identities():
+    import bench
+    import neo_ls_svm_amd as hp
+
+    cfg = bench.CONFIGS["c3"]
+    n, d, D = cfg["n"], cfg["d"], cfg["D"]
+    ctx = hp.default_context()
+    X, y = bench.synth(n, d, 0, n)
+    s = np.ones(n)
+    shift, scale, B = bench.affine_params(d, D)
+    dX = ctx.to_device(X)
+    r = hp.primal_fit(dX, y, s, shift, scale, B, False, ctx=ctx)
+    D1 = D + 1
+    c = 1.0 / (n * D1)
+    sn = s / s.sum()
+    g, lam = r["gamma"], r["lam"]
+    assert r["gammas"].shape == (1024,) and np.all(np.isfinite(r["loo_errors_gammas"]))
+    assert r["opt"] == int(np.argmin(r["loo_errors_gammas"]))
+
+    # eigenvalues and normal equations
+    A, b = hp.gram(dX, y, s, shift, scale, B, ctx=ctx)
+    assert np.all(np.diff(lam) >= 0) and lam[0] > -1e-9 * lam[-1]
+    assert abs(np.trace(A).real / c - lam.sum()) <= 1e-9 * lam.sum()
+    resid = (g * c) * r["beta"] + A @ r["beta"] - b
+    assert np.linalg.norm(resid) <= 1e-9 * np.linalg.norm(b)
+
+    # EVD route vs Cholesky route, every row
+    lev = r["loo_leverage"]
+    assert np.all(lev > 0) and np.all(lev < 1)
+    lhs = r["loo_residuals"] * (1.0 - lev)
+    assert np.max(np.abs(lhs - r["residuals"])) <= 1e-8 * np.max(np.abs(r["residuals"]))
+    assert abs(np.sum(sn * np.abs(r["loo_residuals"])) - r["loo_errors_gammas"][r["opt"]]) <= 1e-10 * r["loo_errors_gammas"][r["opt"]]
+
+    # sampled rows through the inference hooks
+    idx = np.random.default_rng(1).choice(n, size=2048, replace=False)
+    Xs = np.ascontiguousarray(X[idx])
+    yhat, sigma = hp.primal_predict(Xs, shift, scale, B, beta=r["beta"], L=r["L"], ctx=ctx)
+    assert np.max(np.abs((yhat - y[idx]) - r["residuals"][idx])) <= 1e-9 * np.max(np.abs(r["residuals"]))
+    phi = hp.featuremap(Xs[:256], shift, scale, B, ctx=ctx)
+    assert np.max(np.abs((phi @ r["beta"]).real - yhat[:256])) <= 1e-10 * np.max(np.abs(yhat))
+    s2 = sigma**2
+    assert np.max(np.abs(sn[idx] ** 2 * s2 - lev[idx])) <= 1e-8 * np.max(lev)
+    loo_var = s2 + (sn[idx] * s2) ** 2 / (1.0 - lev[idx])
+    assert np.max(np.abs(np.sqrt(loo_var) - r["loo_std"][idx])) <= 1e-8 * np.max(r["loo_std"])

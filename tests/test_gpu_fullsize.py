@@ -67,3 +67,26 @@ def test_c3_identities():
     assert np.max(np.abs(sn[idx] ** 2 * s2 - lev[idx])) <= 1e-8 * np.max(lev)
     loo_var = s2 + (sn[idx] * s2) ** 2 / (1.0 - lev[idx])
     assert np.max(np.abs(np.sqrt(loo_var) - r["loo_std"][idx])) <= 1e-8 * np.max(r["loo_std"])
+
+
+def test_c4_dual_identities():
+    """Dual path at BASELINE c4 (n = 1e4, r = 256): residuals_ = F alpha - y (``_neo_ls_svm.py:313-317``) reproduced by the
+    inference hook on the training rows (k(x_i, X) alpha + sum(alpha) = (F alpha)_i with F = rbf + 1), and the re-solve's
+    normal equations  (gamma* diag(sn^-2) + F) alpha = y  through that same product."""
+    import neo_ls_svm_amd as hp
+
+    n, r_ = 10_000, 256
+    rng = np.random.default_rng(4)
+    Xt = rng.standard_normal((n, r_)) * 0.25
+    w = rng.standard_normal(r_) / np.sqrt(r_)
+    y = np.sin(4 * Xt @ w) + 0.1 * rng.standard_normal(n)
+    s = rng.uniform(0.5, 2.0, n)
+    r = hp.dual_fit(Xt, y, s, False)
+    assert r["opt"] == int(np.argmin(r["loo_errors_gammas"])) and np.all(np.isfinite(r["loo_residuals"]))
+    yhat, sigma = hp.dual_predict(Xt, Xt, alpha=r["alpha"], L=r["L"])
+    assert np.max(np.abs((yhat - y) - r["residuals"])) <= 1e-9 * np.max(np.abs(y))
+    sn = s / s.sum()
+    sn = sn / np.median(np.abs(sn))  # :253-254
+    lhs = r["gamma"] * r["alpha"] / sn**2 + yhat
+    assert np.max(np.abs(lhs - y)) <= 1e-8 * np.max(np.abs(y))
+    assert np.all(np.isfinite(sigma)) and np.all(sigma >= 0)

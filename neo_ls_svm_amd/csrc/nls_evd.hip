@@ -20,6 +20,16 @@ static inline rocblas_status trd_rank2k(rocblas_handle h, int n2, int k, const d
                         (rocblas_int)ldc);
 }
 
+// Two or three kernels per column (nls_trd.h).  Folding the column update into the neighbouring kernels saves a launch
+// (~5 us) per column but every matrix-vector tile then forms x on the fly (two loads + the reduced scalars): a gain
+// while the columns are latency bound (n = 4097: 181 -> 176 ms, n = 1025: 24.2 -> 22.4 ms), a loss once the tiles are
+// bandwidth bound (real n = 10^4: 778 -> 800 ms).  NLS_TRD_KERNELS=2 / 3 overrides the size rule.
+static bool trd_three_kernels(int n) {
+  const char* m = std::getenv("NLS_TRD_KERNELS");
+  if (m && m[0] == '3') return true;
+  if (m && m[0] == '2') return false;
+  return n > 6144;
+}
 static bool trd_use_rocblas_rank2k() {  // NLS_TRD_RANK2K=rocblas: trailing updates through zher2k / dsyr2k (diagnostic)
   const char* m = std::getenv("NLS_TRD_RANK2K");
   return m && std::string(m) == "rocblas";
@@ -51,17 +61,38 @@ static int trd_fused(nls_ctx* ctx, T* A, int n, long lda, double* d, double* e, 
   NLSCHK(ws_get_t(ctx, "trd.pnorm", (size_t)nrb, &a.pnorm));
   HIPCHK(ctx, hipMemsetAsync(a.W, 0, sizeof(T) * (size_t)n * NB, ctx->stream));
   BLASCHK(ctx, rocblas_set_stream(ctx->blas, ctx->stream));
+  const bool two_kernels = !trd_three_kernels(n);
+  T *wt[2] = {a.wtmp, nullptr}, *sp[2] = {a.spart, nullptr};
+  if (two_kernels) {
+    NLSCHK(ws_get_t(ctx, "trd.wtmp2", (size_t)n, &wt[1]));
+    NLSCHK(ws_get_t(ctx, "trd.spart2", (size_t)nrb, &sp[1]));
+    NLSCHK(ws_get_t(ctx, "trd.bvec", (size_t)n, &a.bvec));
+  }
+  int cur = 0;  // buffer that the column being finished writes (two-kernel variant)
   for (int j0 = 0; j0 < n; j0 += NB) {
     const int jend = std::min(j0 + NB, n);
     a.j0 = j0;
     for (int j = j0; j < jend; ++j) {
       a.j = j;
       const int i = j - j0;
+      const int S0 = (j + 1) / TS, K = NSC - S0, ntiles = K * (K + 1) / 2;
+      if (two_kernels) {
+        a.wtmp = wt[cur];
+        a.spart = sp[cur];
+        a.wtmp_prev = wt[cur ^ 1];
+        a.spart_prev = sp[cur ^ 1];
+        a.ndot = (n - j + RD - 1) / RD;  // dot blocks start at row j
+        a.make_base = j + 1 < jend;
+        hipLaunchKernelGGL(k_trd_hemv2<T>, dim3((j < n - 1 ? ntiles : 0) + a.ndot), dim3(256), 0, ctx->stream, a, S0, j < n - 1 ? ntiles : 0);
+        if (j < n - 1) {
+          hipLaunchKernelGGL(k_trd_finish2<T>, dim3(nrb), dim3(ROWT * TPR), 0, ctx->stream, a, S0, NSR);
+          cur ^= 1;
+        }
+        continue;
+      }
       a.ndot = i > 0 ? (n - j - 1 + RD - 1) / RD : 0;
       hipLaunchKernelGGL(k_trd_column<T>, dim3(nrb), dim3(ROWT * TPR), 0, ctx->stream, a);
       if (j < n - 1) {
-        const int S0 = (j + 1) / TS;
-        const int K = NSC - S0, ntiles = K * (K + 1) / 2;
         hipLaunchKernelGGL(k_trd_hemv<T>, dim3(ntiles + a.ndot), dim3(256), 0, ctx->stream, a, S0, ntiles);
         hipLaunchKernelGGL(k_trd_finish<T>, dim3(nrb), dim3(ROWT * TPR), 0, ctx->stream, a, S0, NSR);
       }
@@ -70,7 +101,12 @@ static int trd_fused(nls_ctx* ctx, T* A, int n, long lda, double* d, double* e, 
     const int jl = std::min(jend - 1, n - 2);  // last column of the panel that has a reflector
     const int n2 = n - jend;
     if (n2 > 0) {
-      hipLaunchKernelGGL(k_trd_panel_end<T>, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, a, jl);
+      Args<T> ae = a;
+      if (two_kernels) {  // the last finished column wrote the buffers that are "previous" now
+        ae.wtmp = wt[cur ^ 1];
+        ae.spart = sp[cur ^ 1];
+      }
+      hipLaunchKernelGGL(k_trd_panel_end<T>, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ae, jl);
       if (trd_use_rocblas_rank2k()) {
         BLASCHK(ctx, trd_rank2k(ctx->blas, n2, jend - j0, A + jend + (long)j0 * lda, lda, a.W + jend, n, A + jend + (long)jend * lda, lda));
       } else {

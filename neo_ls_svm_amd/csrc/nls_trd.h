@@ -120,6 +120,11 @@ struct Args {
   T* tau;
   int j0, j;  // panel start, current column
   int nrowblocks, ndot;
+  // two-kernels-per-column variant (k_trd_hemv2 / k_trd_finish2)
+  T* bvec;          // n: column j without the terms that need the previous column's global scalars (see k_trd_finish2)
+  T* wtmp_prev;     // w' of column j - 1 (wtmp holds the one being written)
+  T* spart_prev;    // partials of w'^H v of column j - 1 (spart holds the ones being written)
+  int make_base;    // k_trd_finish2: also prepare bvec for column j + 1 (same panel)
 };
 
 // Sum of cnt per-block partials, computed by the first wave of the block in a fixed order (lane-strided, then a
@@ -429,6 +434,261 @@ __global__ void __launch_bounds__(ROWT * TPR) k_trd_finish(Args<T> a, int S0, in
     }
     a.wtmp[r] = wp;
     a.A[r + (long)j * a.lda] = v;
+    sv = conj_(wp) * v;
+  }
+  if (r == 0 && q == 0) {
+    a.e[j] = h.beta;
+    a.tau[j] = h.tau;
+  }
+  if (q == 0) red[rl] = sv;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const T t = wave_sum(sel_(threadIdx.x < ROWT, red[threadIdx.x % ROWT], make_<T>(0.0, 0.0)));
+    if (threadIdx.x == 0) a.spart[blockIdx.x] = t;
+  }
+}
+
+// ================================================================================================================
+// Two kernels per column.  The column update of column j + 1 is folded into the finish of column j, and what it lacks -
+// the global scalar s = w'^H v of column j - is applied by the matrix-vector kernel of column j + 1 on the fly:
+//   zlatrd's update of column j + 1 subtracts, for the newest reflector, v conj(w[j+1]) + w conj(v[j+1]) with
+//   w = w' + alpha2 v, alpha2 = -tau s / 2, v[j+1] = 1, i.e.  w' + v (conj(w'[j+1]) + 2 Re alpha2).  So
+//       x_{j+1} = base + mu v ,   base = A[:, j+1] - sum_{p < i} (...) - w' ,   mu = Re(tau s) - conj(w'[j+1]) ,
+//   base needs only quantities local to a row (k_trd_finish2 has them in registers already), mu two scalars.
+//   k_trd_hemv2(j)  : x = bvec + mu A[:, j-1] formed on the fly (first column of a panel: x = A[:, j]); tiles as in
+//                     k_trd_hemv; the dot blocks start at row j: they store x, d[j], the |x|^2 partials, finish column
+//                     i - 1 of W (W = w' + alpha2 v) and form W^H x, V^H x.
+//   k_trd_finish2(j): k_trd_finish + bvec for column j + 1.
+// ================================================================================================================
+template <class T>
+struct PrevScalars {
+  T mu, alpha2;
+};
+// mu and alpha2 of the previous column (i > 0), every thread of the block gets them; slot: one T of shared memory
+template <class T>
+__device__ __forceinline__ PrevScalars<T> prev_scalars(const Args<T>& a, T* slot) {
+  const T s = sum_partials(a.spart_prev, a.nrowblocks, slot);
+  const T ts = a.tau[a.j - 1] * s;
+  PrevScalars<T> ps;
+  ps.alpha2 = (-0.5) * ts;
+  ps.mu = make_<T>(real_(ts), 0.0) - conj_(a.wtmp_prev[a.j]);
+  return ps;
+}
+
+template <class T>
+__global__ void __launch_bounds__(256, 2) k_trd_hemv2(Args<T> a, int S0, int ntiles) {
+  __shared__ T sh[4][TS];
+  __shared__ T slot;
+  const int n = a.n, j = a.j, i = a.j - a.j0;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  PrevScalars<T> ps;
+  ps.mu = ps.alpha2 = make_<T>(0.0, 0.0);
+  if (i > 0) ps = prev_scalars(a, &slot);
+  // x[q] of column j for q > j (0 above): first column of a panel straight from A, else base + mu v_{j-1}
+  auto xval = [&](long q) -> T {
+    if (q <= j || q >= n) return make_<T>(0.0, 0.0);
+    return i > 0 ? a.bvec[q] + ps.mu * a.A[q + (long)(j - 1) * a.lda] : a.A[q + (long)j * a.lda];
+  };
+  if ((int)blockIdx.x < ntiles) {
+    int t = blockIdx.x, Rr = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+    while ((Rr + 1) * (Rr + 2) / 2 <= t) ++Rr;
+    while (Rr * (Rr + 1) / 2 > t) --Rr;
+    const int R = S0 + Rr, C = S0 + (t - Rr * (Rr + 1) / 2);
+    const long r = (long)R * RT + lane;
+    T av[2 * GW];
+#pragma unroll
+    for (int cc = 0; cc < 2 * GW; ++cc) {
+      const long c = (long)C * TS + 2 * GW * w + cc;
+      av[cc] = make_<T>(0.0, 0.0);
+      if (r < n && c < n && r >= c) av[cc] = a.A[r + c * a.lda];
+    }
+    const T xr = xval(r);
+    const T xcol = xval((long)C * TS + 2 * GW * w + (lane & 15));
+    T low = make_<T>(0.0, 0.0);
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      T up[GW];
+#pragma unroll
+      for (int cc = 0; cc < GW; ++cc) {
+        const long c = (long)C * TS + 2 * GW * w + GW * g + cc;
+        T v = av[GW * g + cc];
+        if (r == c) v = make_<T>(real_(v), 0.0);
+        const T xc = lane_bcast(xcol, GW * g + cc);
+        low = low + v * xc;
+        up[cc] = sel_(r > c, conj_(v) * xr, make_<T>(0.0, 0.0));
+      }
+      butterfly8(up, lane);
+      if ((lane & 7) == 0) {
+        const long c = (long)C * TS + 2 * GW * w + GW * g + butterfly_col(lane);
+        if (c < n) a.yup[(long)R * n + c] = up[0];
+      }
+    }
+    sh[w][lane] = low;
+    __syncthreads();
+    if (w == 0 && r < n) a.ylow[(long)C * n + r] = ((sh[0][lane] + sh[1][lane]) + sh[2][lane]) + sh[3][lane];
+  } else {
+    // dot block b: rows j + 64 b + lane (row j itself included: it carries d[j]); wave w: panel columns p = w, w + 4, ...
+    const int b = blockIdx.x - ntiles;
+    const long r = (long)j + (long)b * RD + lane;
+    const bool inrange = r < n;
+    T xfull = make_<T>(0.0, 0.0), wt = make_<T>(0.0, 0.0), vprev = make_<T>(0.0, 0.0);
+    if (inrange) {
+      if (i > 0) {
+        vprev = a.A[r + (long)(j - 1) * a.lda];
+        wt = a.wtmp_prev[r];
+        xfull = a.bvec[r] + ps.mu * vprev;
+      } else {
+        xfull = a.A[r + (long)j * a.lda];
+      }
+    }
+    const bool live = inrange && r > j;
+    const T xr = live ? xfull : make_<T>(0.0, 0.0);
+    const T wlast = wt + ps.alpha2 * vprev;  // final W[r][i - 1]
+    T mw[GW], mv[GW];
+#pragma unroll
+    for (int k = 0; k < GW; ++k) {
+      const int p = w + 4 * k;
+      mw[k] = mv[k] = make_<T>(0.0, 0.0);
+      if (live && p < i) {
+        mw[k] = p == i - 1 ? wlast : a.W[r + (long)p * n];
+        mv[k] = a.A[r + (long)(a.j0 + p) * a.lda];
+      }
+    }
+    if (w == 0 && inrange) {
+      if (r == j) {
+        const double dj = real_(xfull);
+        a.d[j] = dj;
+        a.A[r + (long)j * a.lda] = make_<T>(dj, 0.0);
+      } else {
+        a.xvec[r] = xfull;
+      }
+      if (i > 0) a.W[r + (long)(i - 1) * n] = wlast;
+    }
+    if (w == 0) {
+      const double nrm = wave_sum(inrange && r >= j + 2 ? abs2_(xfull) : 0.0);
+      if (lane == 0) a.pnorm[b] = nrm;
+    }
+#pragma unroll
+    for (int k = 0; k < GW; ++k) {
+      mw[k] = conj_(mw[k]) * xr;
+      mv[k] = conj_(mv[k]) * xr;
+    }
+    butterfly8(mw, lane);
+    butterfly8(mv, lane);
+    if ((lane & 7) == 0) {
+      const int p = w + 4 * butterfly_col(lane);
+      a.zpart[(long)b * 2 * NB + p] = sel_(p < i, mw[0], make_<T>(0.0, 0.0));
+      a.zpart[(long)b * 2 * NB + NB + p] = sel_(p < i, mv[0], make_<T>(0.0, 0.0));
+    }
+  }
+}
+
+template <class T>
+__global__ void __launch_bounds__(ROWT * TPR) k_trd_finish2(Args<T> a, int S0, int NS) {
+  __shared__ T zsh[4][2 * NB], zw[NB], zv[NB], wj1[NB], vj1[NB], red[ROWT];
+  __shared__ double dslot;
+  constexpr int PPT = NB / TPR;
+  const int n = a.n, j = a.j, i = a.j - a.j0;
+  const int q = threadIdx.x % TPR, rl = threadIdx.x / TPR;
+  const long r = (long)blockIdx.x * ROWT + rl;
+  const bool live = r < n && r >= j + 1;
+  // ---- loads
+  double pn = 0.0;
+  if (threadIdx.x < 64)
+    for (int b = threadIdx.x; b < a.ndot; b += 64) pn += a.pnorm[b];  // |x[j+2:]|^2 partials of the dot blocks
+  const T alpha = a.xvec[j + 1];
+  T zp = make_<T>(0.0, 0.0);
+  {
+    const int slot = threadIdx.x % (2 * NB), part = threadIdx.x / (2 * NB);
+    if (slot % NB < i)
+      for (int b = part; b < a.ndot; b += 4) zp = zp + a.zpart[(long)b * 2 * NB + slot];
+  }
+  T zrow = make_<T>(0.0, 0.0);  // row j + 1 of W (slots < NB) and of V
+  if (threadIdx.x < 2 * NB && threadIdx.x % NB < i) {
+    const int p = threadIdx.x % NB;
+    zrow = threadIdx.x >= NB ? a.A[(long)(j + 1) + (long)(a.j0 + p) * a.lda] : a.W[(long)(j + 1) + (long)p * n];
+  }
+  T y = make_<T>(0.0, 0.0), xr = make_<T>(0.0, 0.0), t0 = make_<T>(0.0, 0.0), vv[PPT], ww[PPT];
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) vv[k] = ww[k] = make_<T>(0.0, 0.0);
+  if (live) {
+    T y1 = make_<T>(0.0, 0.0), y2 = y1, y3 = y1;
+    const int Clast = (int)(r / TS);
+    for (int C = S0 + q; C <= Clast; C += 4 * TPR) {
+      y = y + a.ylow[(long)C * n + r];
+      if (C + TPR <= Clast) y1 = y1 + a.ylow[(long)(C + TPR) * n + r];
+      if (C + 2 * TPR <= Clast) y2 = y2 + a.ylow[(long)(C + 2 * TPR) * n + r];
+      if (C + 3 * TPR <= Clast) y3 = y3 + a.ylow[(long)(C + 3 * TPR) * n + r];
+    }
+    for (int R = (int)(r / RT) + q; R < NS; R += 4 * TPR) {
+      y = y + a.yup[(long)R * n + r];
+      if (R + TPR < NS) y1 = y1 + a.yup[(long)(R + TPR) * n + r];
+      if (R + 2 * TPR < NS) y2 = y2 + a.yup[(long)(R + 2 * TPR) * n + r];
+      if (R + 3 * TPR < NS) y3 = y3 + a.yup[(long)(R + 3 * TPR) * n + r];
+    }
+    y = (y + y1) + (y2 + y3);
+    xr = a.xvec[r];
+    t0 = a.A[r + (long)(j + 1) * a.lda];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+      const int p = q + TPR * k;
+      if (p < i) {
+        vv[k] = a.A[r + (long)(a.j0 + p) * a.lda];
+        ww[k] = a.W[r + (long)p * n];
+      }
+    }
+  }
+  // ---- reductions of the scalars
+  if (threadIdx.x < 64) {
+    pn = wave_sum(pn);
+    if (threadIdx.x == 0) dslot = pn;
+  }
+  zsh[threadIdx.x / (2 * NB)][threadIdx.x % (2 * NB)] = zp;
+  __syncthreads();
+  const Larfg<T> h = larfg<T>(alpha, dslot);
+  const T beta = make_<T>(h.beta, 0.0);
+  if (threadIdx.x < 2 * NB) {
+    const int p = threadIdx.x % NB;
+    T z = make_<T>(0.0, 0.0);
+    if (p < i && !h.identity)
+      z = ((((zsh[0][threadIdx.x] + zsh[1][threadIdx.x]) + zsh[2][threadIdx.x]) + zsh[3][threadIdx.x]) - beta * conj_(zrow)) * h.scale;
+    if (threadIdx.x >= NB) {
+      zv[p] = z;
+      vj1[p] = conj_(zrow);
+    } else {
+      zw[p] = z;
+      wj1[p] = conj_(zrow);
+    }
+  }
+  __syncthreads();
+  // ---- v, w', and the local part of column j + 1
+  T corr = make_<T>(0.0, 0.0), upd = make_<T>(0.0, 0.0);
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) {
+    const int p = q + TPR * k;
+    if (live && p < i) {
+      corr = corr + vv[k] * zw[p] + ww[k] * zv[p];
+      upd = upd + vv[k] * wj1[p] + ww[k] * vj1[p];
+    }
+  }
+  y = row_sum(y);
+  corr = row_sum(corr);
+  upd = row_sum(upd);
+  T sv = make_<T>(0.0, 0.0);
+  if (live && q == 0) {
+    T v, wp = make_<T>(0.0, 0.0);
+    T t0d = t0;
+    if (r == j + 1) t0d = make_<T>(real_(t0), 0.0);
+    if (h.identity) {
+      v = make_<T>(r == j + 1 ? 1.0 : 0.0, 0.0);
+    } else {
+      v = r == j + 1 ? make_<T>(1.0, 0.0) : xr * h.scale;
+      wp = h.tau * ((y - beta * t0d) * h.scale - corr);
+    }
+    a.wtmp[r] = wp;
+    a.A[r + (long)j * a.lda] = v;
+    if (a.make_base) a.bvec[r] = t0d - upd - wp;
     sv = conj_(wp) * v;
   }
   if (r == 0 && q == 0) {

@@ -4,8 +4,9 @@
 //
 // Why not rocsolver_zhetrd: its panel runs FIVE kernels per column (a 16 us matrix-vector product and four 4-5 us
 // vector kernels, profiles/r01b_c3_kernel_stats_summary.md) - 140 of the 219 ms of zheevd(4097) and 25 of the 28 ms
-// of zheevd(1025).  Here a column is THREE kernels, and the matrix-vector product reads the lower triangle once
-// (it sits in the 256 MB Infinity Cache: 134 MB at n = 4097):
+// of zheevd(1025).  Here a column is THREE kernels - or TWO, see k_trd_hemv2 / k_trd_finish2 below, which fold the first
+// one into its neighbours - and the matrix-vector product reads the lower triangle once (it sits in the 256 MB
+// Infinity Cache: 134 MB at n = 4097):
 //   k_trd_column : x = A[j:, j] - V W[j, :]^H - W V[j, :]^H   (blocked zlatrd update of the column), d[j], |x|^2 partials
 //   k_trd_hemv   : y = A22 x on 64 x 64 tiles of the lower triangle - every tile adds its A x contribution to its
 //                  rows and its A^H x contribution to its columns - plus the short products W^H x, V^H x

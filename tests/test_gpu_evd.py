@@ -95,3 +95,29 @@ def test_argument_errors(hp):
         hp.tridiagonalize(np.zeros((3, 4)))
     with pytest.raises(ValueError):
         hp.eigh(np.zeros((0, 0)))
+
+
+@pytest.mark.parametrize("kernels", ["2", "3"])
+@pytest.mark.parametrize("cplx", [True, False])
+def test_both_panel_variants_match_lapack(kernels, cplx, hp, monkeypatch):
+    """Two kernels per column (default up to n = 6144) and three (above): same reduction, same LAPACK conventions."""
+    monkeypatch.setenv("NLS_TRD_KERNELS", kernels)
+    for n in (33, 200, 517):
+        A = _hermitian(n, cplx, 300 + n)
+        d, e, tau, _ = hp.tridiagonalize(A)
+        f = lapack.zhetrd if cplx else lapack.dsytrd
+        _, d0, e0, tau0, info = f(np.asfortranarray(A), lower=1)
+        scale = np.max(np.abs(A))
+        assert info == 0
+        assert np.max(np.abs(d - d0)) <= 1e-12 * scale * n and np.max(np.abs(e - e0)) <= 1e-12 * scale * n
+        assert np.max(np.abs(tau - tau0)) <= 1e-11 * n
+    lam, Q = hp.eigh(_hermitian(300, cplx, 77, spd=True))
+    assert np.max(np.abs(Q.conj().T @ Q - np.eye(300))) <= 1e-11
+
+
+def test_rank2k_rocblas_knob(hp, monkeypatch):
+    A = _hermitian(260, True, 8)
+    d0, e0, _, _ = hp.tridiagonalize(A)
+    monkeypatch.setenv("NLS_TRD_RANK2K", "rocblas")
+    d1, e1, _, _ = hp.tridiagonalize(A)
+    assert np.max(np.abs(d0 - d1)) <= 1e-12 * 260 and np.max(np.abs(e0 - e1)) <= 1e-12 * 260

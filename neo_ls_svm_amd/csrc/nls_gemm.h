@@ -125,31 +125,6 @@ struct MMajorLoader {  // tile [ROWS][16 k] of a row-major [M][ld] plane, rows r
   static __device__ __forceinline__ void store1(lds_f64* wr, int it, v2d v) { *(lds_v2d*)(wr + it * ROWS_IT * LDM) = v; }
 };
 
-// Guarded m-major loader for the user's X (arbitrary n, d, any alignment) with the affine shift fused:
-// element = X[row][k] - shift[k] inside the matrix, 0 outside.  (K1 only: d / 16 slices, not matrix-pipe bound.)
-template <int NT, int ROWS>
-struct XShiftLoader {
-  const double* X;
-  const double* shift;
-  long n, d;
-  long row0;
-  static constexpr int ROWS_IT = NT / 8;
-  static constexpr int NREG = ROWS / ROWS_IT;
-  __device__ __forceinline__ v2d fetch1(long k0, int it) const {
-    const long row = row0 + (threadIdx.x >> 3) + it * ROWS_IT;
-    const long k = k0 + 2 * (threadIdx.x & 7);
-    v2d v = {0.0, 0.0};
-    if (row < n) {
-      const double* p = X + row * d + k;
-      if (k < d) v.x = p[0] - shift[k];
-      if (k + 1 < d) v.y = p[1] - shift[k + 1];
-    }
-    return v;
-  }
-  static __device__ __forceinline__ int lds_off() { return MMajorLoader<NT, ROWS>::lds_off(); }
-  static __device__ __forceinline__ void store1(lds_f64* wr, int it, v2d v) { MMajorLoader<NT, ROWS>::store1(wr, it, v); }
-};
-
 // ------------------------------------------------------------------------------------------------
 // REAL main loop.  smem must hold 2 x 2 tiles of TILE_DOUBLES doubles.
 //

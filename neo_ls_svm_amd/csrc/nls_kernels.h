@@ -26,6 +26,7 @@ constexpr int LOO_ROWS_PER_BLOCK = 256;
 // ------------------------------------------------------------------------------------------------
 struct FeatureMapParams {
   const double* X;         // rows x d (pointer to the first row of this chunk)
+  const double* Xs;        // rows_pad x dk: (X - shift), zero padded (k_shift_pad) - what the tile loop reads
   const double* shift;     // d
   const double* Bs;        // dk x Kf, B / scale^T zero padded
   const double* rowscale;  // rows (chunk-local) or nullptr (= 1)
@@ -46,7 +47,7 @@ __global__ void __launch_bounds__(Cfg4::NTHREADS, 1) k_featuremap(FeatureMapPara
   v4d acc[C::MT][C::NTL];
   zero_acc(acc);
   if (col0 < p.D) {
-    XShiftLoader<C::NTHREADS, BM> la{p.X, p.shift, p.rows, p.d, row0};
+    MMajorLoader<C::NTHREADS, BM> la{p.Xs, p.dk, row0};
     KMajorLoader<C::NTHREADS, BN> lb{p.Bs, p.Kf, col0};
     mainloop_real<C, false>(acc, la, lb, 0, p.dk / BK, smem);
   }
@@ -78,6 +79,17 @@ __global__ void __launch_bounds__(Cfg4::NTHREADS, 1) k_featuremap(FeatureMapPara
         }
       }
     }
+}
+
+// Xs[r][k] = X[r][k] - shift[k] for r < rows, k < d; zero elsewhere (rows_pad x dk).  One cheap pass (16 n d bytes against the
+// 16 n D the feature map writes) that lets the K1 tile loop use the plain aligned loader: the guarded, shifting loader
+// carried ~30 VALU instructions per slice, and VALU instructions are what the fp64 MFMA pipe pays for (nls_gemm.h).
+__global__ void k_shift_pad(const double* X, const double* shift, long rows, int d, long rows_pad, int dk, double* Xs) {
+  const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (idx >= rows_pad * dk) return;
+  const long r = idx / dk;
+  const int k = (int)(idx % dk);
+  Xs[idx] = (r < rows && k < d) ? X[r * d + k] - shift[k] : 0.0;
 }
 
 // Bs[k][j] = B[k][j] / scale[k] for k < d, j < D; zero elsewhere (dk x Kf).

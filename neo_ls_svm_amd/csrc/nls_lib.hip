@@ -57,6 +57,11 @@ static int launch_featuremap_planes(nls_ctx* ctx, const MapParams& mp, const dou
                                     const double* rowscale, double* Fc, double* Fs) {
   FeatureMapParams p;
   p.X = Xchunk;
+  double* Xs = nullptr;
+  NLSCHK(ws_get_t(ctx, "fm.Xs", (size_t)rows_pad * mp.dk, &Xs));
+  hipLaunchKernelGGL(k_shift_pad, dim3((unsigned)((rows_pad * mp.dk + 255) / 256)), dim3(256), 0, ctx->stream, Xchunk, mp.shift, rows, mp.d,
+                     rows_pad, mp.dk, Xs);
+  p.Xs = Xs;
   p.shift = mp.shift;
   p.Bs = mp.Bs;
   p.rowscale = rowscale;
@@ -242,6 +247,12 @@ extern "C" int nls_featuremap(nls_ctx* ctx, const double* X, int64_t n, int d, c
     const long rows = std::min<long>(rc, n - r0);
     FeatureMapParams p;
     p.X = dX + r0 * d;
+    const long rows_pad = round_up(rows, BM);
+    double* Xs = nullptr;
+    NLSCHK(ws_get_t(ctx, "fm.Xs", (size_t)rows_pad * mp.dk, &Xs));
+    hipLaunchKernelGGL(k_shift_pad, dim3((unsigned)((rows_pad * mp.dk + 255) / 256)), dim3(256), 0, ctx->stream, p.X, mp.shift, rows, mp.d,
+                       rows_pad, mp.dk, Xs);
+    p.Xs = Xs;
     p.shift = mp.shift;
     p.Bs = mp.Bs;
     p.rowscale = nullptr;

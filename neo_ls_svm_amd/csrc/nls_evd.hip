@@ -121,6 +121,61 @@ static int trd_fused(nls_ctx* ctx, T* A, int n, long lda, double* d, double* e, 
   return NLS_OK;
 }
 
+// rocBLAS shims for the blocked back-transformation
+static inline rocblas_status bt_gemm(rocblas_handle h, rocblas_operation ta, rocblas_operation tb, int m, int n, int k, double alpha,
+                                     const trd::Z* A, long lda, const trd::Z* B, long ldb, double beta, trd::Z* C, long ldc) {
+  const rocblas_double_complex al(alpha, 0.0), be(beta, 0.0);
+  return rocblas_zgemm(h, ta, tb, m, n, k, &al, reinterpret_cast<const rocblas_double_complex*>(A), (rocblas_int)lda,
+                       reinterpret_cast<const rocblas_double_complex*>(B), (rocblas_int)ldb, &be, reinterpret_cast<rocblas_double_complex*>(C),
+                       (rocblas_int)ldc);
+}
+static inline rocblas_status bt_gemm(rocblas_handle h, rocblas_operation ta, rocblas_operation tb, int m, int n, int k, double alpha,
+                                     const double* A, long lda, const double* B, long ldb, double beta, double* C, long ldc) {
+  return rocblas_dgemm(h, ta, tb, m, n, k, &alpha, A, (rocblas_int)lda, B, (rocblas_int)ldb, &beta, C, (rocblas_int)ldc);
+}
+static inline rocblas_status bt_trsm(rocblas_handle h, int m, int n, const trd::Z* A, long lda, trd::Z* B, long ldb) {
+  const rocblas_double_complex one(1.0, 0.0);
+  return rocblas_ztrsm(h, rocblas_side_left, rocblas_fill_upper, rocblas_operation_none, rocblas_diagonal_non_unit, m, n, &one,
+                       reinterpret_cast<const rocblas_double_complex*>(A), (rocblas_int)lda, reinterpret_cast<rocblas_double_complex*>(B),
+                       (rocblas_int)ldb);
+}
+static inline rocblas_status bt_trsm(rocblas_handle h, int m, int n, const double* A, long lda, double* B, long ldb) {
+  const double one = 1.0;
+  return rocblas_dtrsm(h, rocblas_side_left, rocblas_fill_upper, rocblas_operation_none, rocblas_diagonal_non_unit, m, n, &one, A,
+                       (rocblas_int)lda, B, (rocblas_int)ldb);
+}
+static inline rocblas_operation bt_op_h(const trd::Z*) { return rocblas_operation_conjugate_transpose; }
+static inline rocblas_operation bt_op_h(const double*) { return rocblas_operation_transpose; }
+
+// C (n x ncols, column-major, ldc) <- Q C with the reflectors of trd_fused in A / tau (nls_trd.h, "back-transformation").
+template <class T>
+static int apply_q_blocked(nls_ctx* ctx, const T* A, long lda, int n, const T* tau, T* C, long ldc, int ncols) {
+  using namespace trd;
+  const int nrefl = n - 1;
+  if (nrefl <= 0 || ncols <= 0) return NLS_OK;
+  T *Vw = nullptr, *S = nullptr, *W = nullptr;
+  NLSCHK(ws_get_t(ctx, "bt.V", (size_t)n * KBQ, &Vw));
+  NLSCHK(ws_get_t(ctx, "bt.S", (size_t)KBQ * KBQ, &S));
+  NLSCHK(ws_get_t(ctx, "bt.W", (size_t)KBQ * ncols, &W));
+  BLASCHK(ctx, rocblas_set_stream(ctx->blas, ctx->stream));
+  for (int j0 = ((nrefl - 1) / KBQ) * KBQ; j0 >= 0; j0 -= KBQ) {
+    const int kb = std::min(KBQ, nrefl - j0), r0 = j0 + 1, m = n - r0;
+    hipLaunchKernelGGL(k_trd_copy_v<T>, dim3((unsigned)(((long)m * kb + 255) / 256)), dim3(256), 0, ctx->stream, A, lda, n, j0, kb, Vw);
+    BLASCHK(ctx, bt_gemm(ctx->blas, bt_op_h(A), rocblas_operation_none, kb, kb, m, 1.0, Vw, m, Vw, m, 0.0, S, kb));
+    hipLaunchKernelGGL(k_trd_tinv<T>, dim3((unsigned)((kb * kb + 255) / 256)), dim3(256), 0, ctx->stream, S, kb, tau, j0);
+    HIPCHK(ctx, hipGetLastError());
+    BLASCHK(ctx, bt_gemm(ctx->blas, bt_op_h(A), rocblas_operation_none, kb, ncols, m, 1.0, Vw, m, C + r0, ldc, 0.0, W, kb));
+    BLASCHK(ctx, bt_trsm(ctx->blas, kb, ncols, S, kb, W, kb));
+    BLASCHK(ctx, bt_gemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, m, ncols, kb, -1.0, Vw, m, W, kb, 1.0, C + r0, ldc));
+  }
+  return NLS_OK;
+}
+
+static bool evd_rocsolver_backtransform() {  // NLS_EVD_UNMTR=rocsolver: zunmtr / dormtr instead of apply_q_blocked (diagnostic)
+  const char* m = std::getenv("NLS_EVD_UNMTR");
+  return m && std::string(m) == "rocsolver";
+}
+
 static bool evd_use_rocsolver() {
   const char* m = std::getenv("NLS_EVD");
   return m && std::string(m) == "rocsolver";
@@ -149,16 +204,22 @@ static int evd_hermitian(nls_ctx* ctx, double2* A, int n, double* lam, double* e
   NLSCHK(check_info(ctx, dinfo, "rocsolver_zstedc"));
   if (collective && ctx->world > 1 && ctx->allreduce && n >= 64) {
     const long c0 = (long)n * ctx->rank / ctx->world, c1 = (long)n * (ctx->rank + 1) / ctx->world;
-    BLASCHK(ctx, rocsolver_zunmtr(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, n, (rocblas_int)(c1 - c0),
-                                  reinterpret_cast<rocblas_double_complex*>(A), n, reinterpret_cast<rocblas_double_complex*>(tau),
-                                  reinterpret_cast<rocblas_double_complex*>(C + c0 * n), n));
+    if (evd_rocsolver_backtransform()) {
+      BLASCHK(ctx, rocsolver_zunmtr(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, n, (rocblas_int)(c1 - c0),
+                                    reinterpret_cast<rocblas_double_complex*>(A), n, reinterpret_cast<rocblas_double_complex*>(tau),
+                                    reinterpret_cast<rocblas_double_complex*>(C + c0 * n), n));
+    } else {
+      NLSCHK(apply_q_blocked<trd::Z>(ctx, reinterpret_cast<trd::Z*>(A), n, n, tau, reinterpret_cast<trd::Z*>(C + c0 * n), n, (int)(c1 - c0)));
+    }
     HIPCHK(ctx, hipMemsetAsync(C, 0, sizeof(double2) * (size_t)c0 * n, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(C + c1 * n, 0, sizeof(double2) * (size_t)(n - c1) * n, ctx->stream));
     NLSCHK(do_allreduce(ctx, reinterpret_cast<double*>(C), (size_t)2 * n * n));
-  } else {
+  } else if (evd_rocsolver_backtransform()) {
     BLASCHK(ctx, rocsolver_zunmtr(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, n, n,
                                   reinterpret_cast<rocblas_double_complex*>(A), n, reinterpret_cast<rocblas_double_complex*>(tau),
                                   reinterpret_cast<rocblas_double_complex*>(C), n));
+  } else {
+    NLSCHK(apply_q_blocked<trd::Z>(ctx, reinterpret_cast<trd::Z*>(A), n, n, tau, reinterpret_cast<trd::Z*>(C), n, n));
   }
   *Q = C;
   return NLS_OK;
@@ -178,7 +239,10 @@ static int evd_symmetric(nls_ctx* ctx, double* A, int n, double* lam, double* e_
   NLSCHK(trd_fused<double>(ctx, A, n, n, lam, e_work, tau));
   BLASCHK(ctx, rocsolver_dstedc(ctx->blas, rocblas_evect_tridiagonal, n, lam, e_work, C, n, dinfo));
   NLSCHK(check_info(ctx, dinfo, "rocsolver_dstedc"));
-  BLASCHK(ctx, rocsolver_dormtr(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, n, n, A, n, tau, C, n));
+  if (evd_rocsolver_backtransform())
+    BLASCHK(ctx, rocsolver_dormtr(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, n, n, A, n, tau, C, n));
+  else
+    NLSCHK(apply_q_blocked<double>(ctx, A, n, n, tau, C, n, n));
   *Q = C;
   return NLS_OK;
 }

@@ -782,5 +782,34 @@ __global__ void k_trd_restore_subdiag(T* A, long lda, const double* e, int j0, i
   if (p < cnt) A[(long)(j0 + p + 1) + (long)(j0 + p) * lda] = make_<T>(e[j0 + p], 0.0);
 }
 
+// ---- back-transformation  C <- Q C,  Q = H_0 H_1 ... H_{n-2}  (zunmtr / dormtr, left, lower, no transpose) --------------
+// In blocks of KBQ reflectors: H_{j0} ... H_{j0+kb-1} = I - V T V^H with T^-1 = striu(V^H V) + diag(1 / tau), so a block is
+// two large GEMMs (W = V^H C, C -= V X) around one kb x kb triangular solve (T^-1 X = W) - no sequential larft, and the
+// first GEMM has 256 rows instead of rocSOLVER's 64 (a quarter of the CUs at n = 4097).
+constexpr int KBQ = 256;
+// Vw[q][p] (column-major m x kb): reflector j0 + p restricted to rows r0 = j0 + 1 .. n-1: 0 above its unit entry
+template <class T>
+__global__ void k_trd_copy_v(const T* A, long lda, int n, int j0, int kb, T* Vw) {
+  const long m = n - (j0 + 1);
+  const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (idx >= m * kb) return;
+  const long q = idx % m;
+  const int p = (int)(idx / m);
+  Vw[idx] = q < p ? make_<T>(0.0, 0.0) : (q == p ? make_<T>(1.0, 0.0) : A[(j0 + 1 + q) + (long)(j0 + p) * lda]);
+}
+// S (kb x kb, = V^H V) -> T^-1 = striu(S) + diag(1 / tau); tau = 0 (H = I) gets a huge diagonal, i.e. a zero row of X
+template <class T>
+__global__ void k_trd_tinv(T* S, int kb, const T* tau, int j0) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= kb * kb) return;
+  const int r = idx % kb, c = idx / kb;
+  if (r > c) {
+    S[idx] = make_<T>(0.0, 0.0);
+  } else if (r == c) {
+    const T t = tau[j0 + r];
+    S[idx] = abs2_(t) == 0.0 ? make_<T>(1e300, 0.0) : inv_(t);
+  }
+}
+
 }  // namespace trd
 }  // namespace nls

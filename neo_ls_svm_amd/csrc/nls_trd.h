@@ -785,8 +785,8 @@ __global__ void k_trd_restore_subdiag(T* A, long lda, const double* e, int j0, i
 // ---- back-transformation  C <- Q C,  Q = H_0 H_1 ... H_{n-2}  (zunmtr / dormtr, left, lower, no transpose) --------------
 // In blocks of KBQ reflectors: H_{j0} ... H_{j0+kb-1} = I - V T V^H with T^-1 = striu(V^H V) + diag(1 / tau), so a block is
 // two large GEMMs (W = V^H C, C -= V X) around one kb x kb triangular solve (T^-1 X = W) - no sequential larft, and the
-// first GEMM has 256 rows instead of rocSOLVER's 64 (a quarter of the CUs at n = 4097).
-constexpr int KBQ = 256;
+// first GEMM has 512 rows instead of rocSOLVER's 64 (65 workgroups = a quarter of the CUs at n = 4097).
+constexpr int KBQ = 512;  // 256: 146.8 ms, 512: 143.9 ms, 1024: 143.7 ms per EVD at n = 4097
 // Vw[q][p] (column-major m x kb): reflector j0 + p restricted to rows r0 = j0 + 1 .. n-1: 0 above its unit entry
 template <class T>
 __global__ void k_trd_copy_v(const T* A, long lda, int n, int j0, int kb, T* Vw) {

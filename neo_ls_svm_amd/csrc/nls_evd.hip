@@ -1,7 +1,7 @@
 // Eigendecomposition of the path's Hermitian / real symmetric matrices (P4: _neo_ls_svm.py:120, D2: :265):
-// tridiagonalisation by the three-kernels-per-column panel of nls_trd.h, then rocSOLVER's divide-and-conquer
-// (stedc) on the tridiagonal matrix and its back-transformation (unmtr / ormtr).  NLS_EVD=rocsolver selects the
-// all-rocSOLVER zheevd / dsyevd instead.
+// tridiagonalisation by the panel of nls_trd.h (two or three kernels per column), rocSOLVER's divide-and-conquer
+// (stedc) on the tridiagonal matrix, and a blocked back-transformation built from rocBLAS GEMMs (apply_q_blocked).
+// NLS_EVD=rocsolver selects the all-rocSOLVER zheevd / dsyevd instead.
 #include "nls_host.h"
 #include "nls_trd.h"
 

@@ -30,6 +30,13 @@ static bool trd_three_kernels(int n) {
   if (m && m[0] == '2') return false;
   return n > 6144;
 }
+static int trd_dotgroups(int n) {  // 64-row groups per dot block (NLS_TRD_DOTGROUPS overrides the size rule; test hook)
+  if (const char* m = std::getenv("NLS_TRD_DOTGROUPS")) {
+    const int g = std::atoi(m);
+    if (g >= 1 && g <= 16) return g;
+  }
+  return n > 6144 ? 4 : 1;
+}
 static bool trd_use_rocblas_rank2k() {  // NLS_TRD_RANK2K=rocblas: trailing updates through zher2k / dsyr2k (diagnostic)
   const char* m = std::getenv("NLS_TRD_RANK2K");
   return m && std::string(m) == "rocblas";
@@ -90,7 +97,8 @@ static int trd_fused(nls_ctx* ctx, T* A, int n, long lda, double* d, double* e, 
         }
         continue;
       }
-      a.ndot = i > 0 ? (n - j - 1 + RD - 1) / RD : 0;
+      a.dotgroups = trd_dotgroups(n);
+      a.ndot = i > 0 ? (n - j - 1 + RD * a.dotgroups - 1) / (RD * a.dotgroups) : 0;
       hipLaunchKernelGGL(k_trd_column<T>, dim3(nrb), dim3(ROWT * TPR), 0, ctx->stream, a);
       if (j < n - 1) {
         hipLaunchKernelGGL(k_trd_hemv<T>, dim3(ntiles + a.ndot), dim3(256), 0, ctx->stream, a, S0, ntiles);

@@ -121,6 +121,7 @@ struct Args {
   T* tau;
   int j0, j;  // panel start, current column
   int nrowblocks, ndot;
+  int dotgroups;  // 64-row groups per dot block of k_trd_hemv
   // two-kernels-per-column variant (k_trd_hemv2 / k_trd_finish2)
   T* bvec;          // n: column j without the terms that need the previous column's global scalars (see k_trd_finish2)
   T* wtmp_prev;     // w' of column j - 1 (wtmp holds the one being written)
@@ -309,25 +310,31 @@ __global__ void __launch_bounds__(256, 2) k_trd_hemv(Args<T> a, int S0, int ntil
     __syncthreads();
     if (w == 0 && r < n) a.ylow[(long)C * n + r] = ((sh[0][lane] + sh[1][lane]) + sh[2][lane]) + sh[3][lane];
   } else {
-    // dot block: RD = 64 rows (lane = row); wave w takes the panel columns p = w, w + 4, ... of W and of V, all loads first
+    // dot block: a.dotgroups groups of RD = 64 rows (lane = row; one group when the columns are latency bound, four for
+    // large n so that k_trd_finish has few partials to add); wave w takes the panel columns p = w, w + 4, ... of W and V
     const int b = blockIdx.x - ntiles;
-    const long r = (long)j + 1 + (long)b * RD + lane;
-    const bool live = r < n;
-    const T xr = live ? a.xvec[r] : make_<T>(0.0, 0.0);
     T mw[GW], mv[GW];
 #pragma unroll
-    for (int k = 0; k < GW; ++k) {
-      const int p = w + 4 * k;
-      mw[k] = mv[k] = make_<T>(0.0, 0.0);
-      if (live && p < i) {
-        mw[k] = a.W[r + (long)p * n];
-        mv[k] = a.A[r + (long)(a.j0 + p) * a.lda];
-      }
-    }
+    for (int k = 0; k < GW; ++k) mw[k] = mv[k] = make_<T>(0.0, 0.0);
+    for (int gq = 0; gq < a.dotgroups; ++gq) {
+      const long r = (long)j + 1 + ((long)b * a.dotgroups + gq) * RD + lane;
+      const bool live = r < n;
+      const T xr = live ? a.xvec[r] : make_<T>(0.0, 0.0);
+      T lw[GW], lv[GW];
 #pragma unroll
-    for (int k = 0; k < GW; ++k) {
-      mw[k] = conj_(mw[k]) * xr;
-      mv[k] = conj_(mv[k]) * xr;
+      for (int k = 0; k < GW; ++k) {
+        const int p = w + 4 * k;
+        lw[k] = lv[k] = make_<T>(0.0, 0.0);
+        if (live && p < i) {
+          lw[k] = a.W[r + (long)p * n];
+          lv[k] = a.A[r + (long)(a.j0 + p) * a.lda];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < GW; ++k) {
+        mw[k] = mw[k] + conj_(lw[k]) * xr;
+        mv[k] = mv[k] + conj_(lv[k]) * xr;
+      }
     }
     butterfly8(mw, lane);
     butterfly8(mv, lane);

@@ -115,6 +115,19 @@ def test_both_panel_variants_match_lapack(kernels, cplx, hp, monkeypatch):
     assert np.max(np.abs(Q.conj().T @ Q - np.eye(300))) <= 1e-11
 
 
+def test_large_n_configuration_on_a_small_matrix(hp, monkeypatch):
+    """Above n = 6144 the panel runs three kernels per column with four row groups per dot block; force that here."""
+    monkeypatch.setenv("NLS_TRD_KERNELS", "3")
+    monkeypatch.setenv("NLS_TRD_DOTGROUPS", "4")
+    for cplx in (True, False):
+        A = _hermitian(517, cplx, 41)
+        d, e, tau, _ = hp.tridiagonalize(A)
+        f = lapack.zhetrd if cplx else lapack.dsytrd
+        _, d0, e0, tau0, _ = f(np.asfortranarray(A), lower=1)
+        assert np.max(np.abs(d - d0)) <= 1e-12 * 517 * np.max(np.abs(A)) and np.max(np.abs(e - e0)) <= 1e-12 * 517 * np.max(np.abs(A))
+        assert np.max(np.abs(tau - tau0)) <= 1e-11 * 517
+
+
 def test_rank2k_rocblas_knob(hp, monkeypatch):
     A = _hermitian(260, True, 8)
     d0, e0, _, _ = hp.tridiagonalize(A)

@@ -172,7 +172,9 @@ int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* args);
 
 /* ---- primal inference -------------------------------------------------------------------------
  * yhat[i] = Re(phi(x_i) . beta); sigma[i] = sqrt(Re phi_i (U^H U)^-1 phi_i^H).  Either output may be
- * NULL; L (format as nls_primal_fit's output) is only read when sigma != NULL. */
+ * NULL; L (format as nls_primal_fit's output) is only read when sigma != NULL.  The context keeps the inverse
+ * factor of the last host L it was given (recognised by address, size and a checksum of its diagonal and of one entry
+ * per row): L is fitted state and must not be edited in place between calls. */
 int nls_primal_predict(nls_ctx* ctx, const double* X, int64_t m, int d, const double* shift,
                        const double* scale, const double* B, int D, const double* beta,
                        const double* L, double* yhat, double* sigma);

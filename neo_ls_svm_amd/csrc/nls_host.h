@@ -40,6 +40,11 @@ struct nls_ctx {
   // XCD patch shape of k_rotate3 (NLS_ROT_PATCH=RxC; 0x0 = plain order, the default: patches raise the L2 hit rate
   // from 0.57 to 0.78 and halve the fabric traffic but run 1-4 % slower, profiles/r01_pmc_summary.md)
   int rot_pr = 0, rot_pc = 0;
+  // nls_primal_predict keeps the inverse-factor planes of the last L it was given (fingerprint: host address, size,
+  // a checksum of the diagonal and of one entry per row), so repeated predict_std calls skip the 268 MB upload and ztrtri
+  const void* pred_L = nullptr;
+  int pred_D1 = 0;
+  double pred_hash = 0.0;
   bool no_resident = false;  // NLS_NO_RESIDENT_PLANES=1: recompute the feature planes per phase even when they would fit
   // stage timing
   struct Span {

@@ -209,3 +209,20 @@ def test_argument_errors_raise_like_the_reference(hp):
         hp.primal_fit(X, y, np.zeros(50), np.zeros(3), np.ones(3), B, False)
     with pytest.raises(ValueError):
         hp.featuremap(X, np.zeros(3), np.ones(3), rng.standard_normal((4, 8)))
+
+
+def test_predict_std_reuses_and_refreshes_the_cached_factor(golden_loader, hp):
+    """nls_primal_predict keeps the inverse of the last L; a different L (other address or other content) replaces it."""
+    g = golden_loader("primal_reg_n3000_d20_D256")
+    y = signed_targets(g)
+    r = hp.primal_fit(g["X"], y, g["s"], g["shift"], g["scale"], g["B"], False)
+    L = np.ascontiguousarray(r["L"])
+    _, s1 = hp.primal_predict(g["Xq"], g["shift"], g["scale"], g["B"], L=L)
+    _, s2 = hp.primal_predict(g["Xq"][:100], g["shift"], g["scale"], g["B"], L=L)  # cached factor
+    assert np.array_equal(s1[:100], s2) and relerr(s1, g["predict_std"]) < TOL
+    L2 = L * 2.0  # U -> 2 U: sigma halves; new array, new content
+    _, s3 = hp.primal_predict(g["Xq"], g["shift"], g["scale"], g["B"], L=L2)
+    assert relerr(s3, s1 / 2) < 1e-12
+    L *= 2.0  # same address, edited diagonal: the checksum notices
+    _, s4 = hp.primal_predict(g["Xq"], g["shift"], g["scale"], g["B"], L=L)
+    assert relerr(s4, s1 / 2) < 1e-12

@@ -1,13 +1,15 @@
 """Headline benchmark: primal fits/s with the full gamma sweep on synthetic n x d data (BASELINE.json).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c2] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c2|c5|...] [--no-cpu-baseline]
 
-One step = one ``nls_primal_fit`` call (P1-P9: feature map, Hermitian Gram, EVD, rotation, gamma sweep
-over G = 1024, selection, Cholesky re-solve, residuals, LOO sigma) with X, y, s already resident in HBM.
-N = 1 runs torch-free (ctypes + the HIP library).  N > 1 is launched by ``torch.distributed.run`` with one
-rank per GPU; the n rows are sharded over the ranks (strong scaling at fixed n) and the library's three
-exchange points (weight sums, the Hermitian block A||b, the per-gamma error vectors) are all-reduced over
-RCCL through ``torch.distributed``.  Rank 0 prints ONE JSON line.
+One step = one ``nls_primal_fit`` call (P1-P9: feature map, Hermitian Gram, EVD, rotation, gamma sweep over G = 1024,
+selection, Cholesky re-solve, residuals, LOO sigma) with X, y, s already resident in HBM.  Everything is ctypes + the
+HIP library; there is no PyTorch anywhere.  N > 1: one process per GPU - either launched by a launcher that sets
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT (``python -m torch.distributed.run ... bench.py --gpus N``; only its
+environment variables are used) or, with no such environment, spawned by this script itself before any GPU call.
+The n rows are sharded over the ranks (strong scaling at fixed n) and the library's exchange points run as RCCL
+collectives on its own stream (``nls_comm_init_rank``; the 128-byte communicator id travels through a file in /tmp).
+Rank 0 prints ONE JSON line.
 """
 
 from __future__ import annotations
@@ -15,6 +17,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -27,10 +30,10 @@ CONFIGS = {
     "c3": dict(n=1_000_000, d=128, D=4096, G=1024, name="synthetic regression n=1e6 d=128 D=4096 ORF, primal, G=1024"),
     # BASELINE.json configs[1]
     "c2": dict(n=100_000, d=64, D=1024, G=1024, name="synthetic regression n=1e5 d=64 D=1024 ORF, primal, G=1024"),
-    # BASELINE.json configs[4]: gamma x sigma grid (32 x 16); one eigendecomposition per sigma serves all 32 gammas.
-    # N > 1 shards the SIGMAS (every rank holds all rows, no collective in the data path) -> "weak"-style replicas.
     # one eighth of c3: what one rank of an 8-GPU row-sharded c3 fit computes locally (scaling diagnostics)
     "c3e": dict(n=125_000, d=128, D=4096, G=1024, name="synthetic regression n=1.25e5 d=128 D=4096 ORF, primal, G=1024"),
+    # BASELINE.json configs[4]: gamma x sigma grid (32 x 16); one eigendecomposition per sigma serves all 32 gammas.
+    # N > 1 shards the SIGMAS (every rank holds all rows, no collective in the data path) -> "weak"-style replicas.
     "c5": dict(n=1_000_000, d=128, D=4096, G=32, sigmas=16, name="gamma x sigma LOO grid 32 x 16, n=1e6 d=128 D=4096 ORF, primal"),
     # one row chunk of c3 (profiling: same kernels, same D, 1/4 of the rows)
     "c3q": dict(n=262_144, d=128, D=4096, G=1024, name="synthetic regression n=262144 d=128 D=4096 ORF, primal, G=1024"),
@@ -38,6 +41,8 @@ CONFIGS = {
     "c0": dict(n=20_000, d=32, D=512, G=1024, name="synthetic regression n=2e4 d=32 D=512 ORF, primal, G=1024"),
 }
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X dense fp64 matrix peak; measured issue rate 78.0 (profiles/r01_probe_mfma.log)
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E (MI355X_MICROARCH.md); a plain 16-byte copy reaches 4.6 TB/s (profiles/r01_probe_hw.log)
+PRESTEP_PREFIX = 200_000  # for n = 1e6 the affine pre-step is fitted on a fixed 2e5-row prefix
 
 
 def synth(n, d, lo, hi):
@@ -59,46 +64,116 @@ def synth(n, d, lo, hi):
     return np.ascontiguousarray(np.vstack(Xs)), np.concatenate(ys)
 
 
-def affine_params(d, D):
-    """Standardising shift/scale of N(0,1) columns and B = ORF Z (RandomState(42)) scaled to unit bandwidth."""
-    import numpy as np
+def affine_params(n, d, D, ctx=None):
+    """(shift, scale, B) as SURVEY.md 8(d) prescribes: the package's own supervised pre-step (AffineSeparator + ORF
+    frequencies, RandomState(42)) fitted on the first min(n, 2e5) rows of the workload.  Deterministic: every rank
+    computes the same parameters."""
+    from neo_ls_svm_amd import OrthogonalRandomFourierFeatures
 
-    from neo_ls_svm_amd import orf_frequencies
+    p = min(n, PRESTEP_PREFIX)
+    Xp, yp = synth(n, d, 0, p)
+    fm = OrthogonalRandomFourierFeatures(num_features=D).fit(Xp, yp, None, ctx=ctx)
+    shift, scale, B = fm.map_params
+    return shift.copy(), scale.copy(), B.copy()
 
-    return np.zeros(d), np.ones(d), orf_frequencies(d, D, 42) / np.sqrt(d)
 
-
-def cpu_baseline(cfg, shift, scale, B, gammas):
-    """Oracle (NumPy port) timed on a bounded row sample of the same workload; see oracle docstring."""
-    import numpy as np
-
-    sys.path.insert(0, str(ROOT / "oracle"))
-    import neolssvm_oracle as orc
-
+def _blas_info():
     try:
         from threadpoolctl import threadpool_info
 
         infos = [i for i in threadpool_info() if i.get("user_api") == "blas"]
-        threads = max([i.get("num_threads", 1) for i in infos] or [1])
-        blas = ",".join(sorted({str(i.get("internal_api")) for i in infos})) or "unknown"
+        return max([i.get("num_threads", 1) for i in infos] or [1]), ",".join(sorted({str(i.get("internal_api")) for i in infos})) or "unknown"
     except Exception:
-        threads, blas = os.cpu_count(), "unknown"
-    n_s = 4096 if cfg["D"] >= 2048 else 16384
-    n_s = min(n_s, cfg["n"])
-    X, y = synth(cfg["n"], cfg["d"], 0, n_s)
-    t = orc.time_primal_row_stages(X, y, np.ones(n_s), shift, scale, B, gammas, row_tile=2048)
-    est = t["seconds"] * cfg["n"] / n_s
-    return {
-        "value": 1.0 / est,
-        "unit": "fits/s",
-        "cores": int(threads),
-        "host_cpus": os.cpu_count(),
-        "blas": blas,
-        "kind": "port",
-        "sample": f"n-proportional stages (feature map x2, Gram, rotation, sweep, LOO) on the first {n_s} of "
-        f"{cfg['n']} rows at full d, D, G: {t['seconds']:.2f} s, scaled x{cfg['n'] / n_s:.1f}; EVD + Cholesky excluded",
-        "stage_seconds": {k: round(v, 3) for k, v in t["stages"].items()},
-    }
+        return os.cpu_count(), "unknown"
+
+
+def cpu_baseline(cfg, shift, scale, B, gammas):
+    """The oracle (NumPy restatement of the reference's algorithm, ``kind: port``) timed on this box's host cores.
+
+    * Mode S ("simplified, row-streamed schedule" = what the HIP library implements) on a bounded row sample of the
+      workload at full d, D, G, scaled to n rows, PLUS the n-independent ``eigh`` / ``cho_factor`` measured at full size.
+    * Where the reference's own schedule fits host RAM (n (D+1) 16 B of phi and its five zgemm-class products: c2),
+      Mode R (``primal_fit_faithful``, the schedule of ``_neo_ls_svm.py:112-187``) and Mode S are both run at FULL size.
+    BLAS threads are pinned with threadpoolctl and stated.
+    """
+    import numpy as np
+    import scipy.linalg as sla
+    from threadpoolctl import threadpool_limits
+
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import neolssvm_oracle as orc
+
+    threads, blas = _blas_info()
+    n, d, D = cfg["n"], cfg["d"], cfg["D"]
+    D1 = D + 1
+    out = {"unit": "fits/s", "cores": int(threads), "host_cpus": os.cpu_count(), "blas": blas, "kind": "port"}
+    with threadpool_limits(limits=int(threads), user_api="blas"):
+        full_fits_ram = n * D1 <= 2e8  # phi, S phi, h, phi beta(.) of the faithful schedule: 4 x 16 B per entry (c2: 6.6 GB)
+        if full_fits_ram:
+            X, y = synth(n, d, 0, n)
+            s = np.ones(n)
+            t0 = time.perf_counter()
+            rS = orc.primal_fit_streamed(X, y, s, shift, scale, B, False, gammas=gammas)
+            tS = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            phi = orc.feature_map(X, shift, scale, B)
+            rR = orc.primal_fit_faithful(phi, y, s, False, gammas=gammas)
+            tR = time.perf_counter() - t0
+            del phi
+            out.update(
+                value=1.0 / tR,
+                mode="R (reference-faithful schedule, materialised phi, transform included), full size",
+                seconds_mode_R=tR,
+                seconds_mode_S=tS,
+                value_mode_S=1.0 / tS,
+                sample=f"all {n} rows, both schedules at full size; argmin R/S {rR['opt']}/{rS['opt']}",
+            )
+            return out
+        n_s = min(n, 65_536)
+        X, y = synth(n, d, 0, n_s)
+        t = orc.time_primal_row_stages(X, y, np.ones(n_s), shift, scale, B, gammas, row_tile=8192)
+        # n-independent serial section at full size: eigh of a (D+1)^2 Hermitian matrix and one Cholesky factorisation
+        rng = np.random.default_rng(1)
+        M = rng.standard_normal((D1, 2 * D1)) + 1j * rng.standard_normal((D1, 2 * D1))
+        A = M @ M.conj().T / (2 * D1)
+        t0 = time.perf_counter()
+        sla.eigh(A)
+        t_evd = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        sla.cho_factor(A)
+        t_chol = time.perf_counter() - t0
+        est = t["seconds"] * n / n_s + t_evd + t_chol
+        out.update(
+            value=1.0 / est,
+            mode="S (simplified row-streamed schedule), row sample scaled to n + eigh / cho_factor measured at full (D+1)",
+            sample=f"n-proportional stages (feature map x2, Gram, rotation, sweep, LOO) on the first {n_s} of {n} rows at full d, D, G: "
+            f"{t['seconds']:.2f} s, scaled x{n / n_s:.2f}; eigh({D1}) {t_evd:.2f} s + cho_factor {t_chol:.2f} s added unscaled",
+            seconds_estimated=est,
+            stage_seconds={**{k: round(v, 3) for k, v in t["stages"].items()}, "eigh_full": round(t_evd, 3), "cho_factor_full": round(t_chol, 3)},
+            note="the reference itself cannot run this size (phi alone is 65.5 GB); Mode R at the largest size it can run "
+            "(c2) is in profiles/ (bench.py --config c2)",
+        )
+    return out
+
+
+def spawn_ranks(args) -> int:
+    """``python bench.py --gpus N`` without a launcher: start N copies of this script, one per GPU, before anything here
+    has touched the GPU; relay rank 0's JSON line."""
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for rank in range(args.gpus):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))  # fmt: skip
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL, text=True))  # fmt: skip
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0)
+    return max(abs(c) for c in codes)
 
 
 def main():
@@ -110,69 +185,53 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-        args.gpus = world
-
-    dist = torch = None
-    if world > 1 or os.environ.get("NLS_BENCH_FORCE_DIST") == "1":
-        # torch (and its bundled ROCm) must be loaded BEFORE the HIP library so that both share one runtime.
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        import torch
-        import torch.distributed as dist
-
-        torch.cuda.set_device(local_rank)
-        if world == 1:  # debugging aid: exercise the torch + RCCL plumbing on a single GPU
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    args.gpus = world
 
     import numpy as np
 
     import neo_ls_svm_amd as hp
-
-    ctx = hp.Context(local_rank)
-    if dist is not None:
-        from neo_ls_svm_amd.distributed import attach
-
-        attach(ctx, dist)  # RCCL all-reduce (zero-copy on the library's device buffers) at the three exchange points
+    from neo_ls_svm_amd.distributed import init_from_env
 
     n, d, D, G = cfg["n"], cfg["d"], cfg["D"], cfg["G"]
     grid_mode = "sigmas" in cfg
+    ctx = hp.Context(local_rank)
+    # Row sharding: the fitting context itself joins the communicator.  Sigma sharding (c5): every rank fits all rows on
+    # its own, so the communicator lives on a second context that only serves the barrier / the merge of the small tables.
+    use_comm = world > 1 or os.environ.get("NLS_BENCH_FORCE_COMM") == "1"
+    cctx = None
+    if use_comm:
+        cctx = hp.Context(local_rank) if grid_mode else ctx
+        init_from_env(cctx)
+
     lo, hi = (0, n) if grid_mode else ((n * rank) // world, (n * (rank + 1)) // world)
+    shift, scale, B = affine_params(n, d, D, ctx=ctx)
     X, y = synth(n, d, lo, hi)
     s = np.ones(hi - lo)
-    shift, scale, B = affine_params(d, D)
     gammas = hp.gamma_grid(1024)[::33] if grid_mode else hp.gamma_grid(G)
-    if grid_mode and dist is not None:
-        ctx.set_allreduce(None, 0, 1)  # sigma sharding: every rank fits all rows on its own
     dX, dy, ds = ctx.to_device(X), ctx.to_device(y), ctx.to_device(s)
-    del X
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
         ctx.synchronize()
+        if cctx is not None:
+            cctx.comm_barrier()
 
-    def allgather(obj):
-        out = [None] * world
-        dist.all_gather_object(out, obj)
-        return out
+    def allreduce_sum(a):
+        flat = np.ascontiguousarray(a, dtype=np.float64).ravel()
+        return cctx.comm_allreduce(flat, "sum").reshape(np.shape(a))
 
-    def step():
+    def step(X_=dX, y_=dy, s_=ds):
         if grid_mode:
             sig = np.logspace(np.log10(0.25), np.log10(4.0), cfg["sigmas"])
-            g = hp.primal_fit_sigma_grid(dX, dy, ds, shift, scale, B, False, sig, gammas=gammas, ctx=ctx, rank=rank, world=world,
-                                         allgather=allgather if dist is not None else None)  # fmt: skip
-            r = g["best"] or hp.primal_fit(dX, dy, ds, shift, scale, B / g["sigma"], False, gammas=gammas, ctx=ctx, want_L=False)
-            r = dict(r, grid=g)
-            return r
-        return hp.primal_fit(dX, dy, ds, shift, scale, B, False, gammas=gammas, ctx=ctx)
+            g = hp.primal_fit_sigma_grid(X_, y_, s_, shift, scale, B, False, sig, gammas=gammas, ctx=ctx, rank=rank, world=world,
+                                         allreduce_sum=allreduce_sum if world > 1 else None)  # fmt: skip
+            best = g["best"] or {}
+            return {"opt": g["gamma_index"], "sigma_index": g["sigma_index"], "loo_score": best.get("loo_score"), "timings": g["timings"]}
+        return hp.primal_fit(X_, y_, s_, shift, scale, B, False, gammas=gammas, ctx=ctx)
 
     for _ in range(args.warmup):
         step()
@@ -185,26 +244,41 @@ def main():
             stage[k] = stage.get(k, 0.0) + v
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    if cctx is not None:
+        elapsed = float(cctx.comm_allreduce([elapsed], "max")[0])
+
+    pcie = None
+    if world == 1 and not grid_mode:  # the same step with host-resident inputs: one pageable H2D copy of X inside the call
+        tp = time.perf_counter()
+        step(X, y, s)
+        ctx.synchronize()
+        pcie = time.perf_counter() - tp
 
     if rank == 0:
-        # Dominant kernel: k_rotate (P = phi Q, 8 n D1^2 algorithmic flops per fit, fp64 MFMA bound).  Its
-        # launches are timed with HIP events on the library's stream inside the timed region.
-        launches = max(stage["rotate_launches"], 1.0)
-        rot_tflops = stage["rotate_flops"] / max(stage["rotate"], 1e-12) / 1e12
-        # HBM-side traffic of the dominant kernel comes from a separate rocprofv3 PMC pass (it cannot be read live);
-        # scaled per row because every launch streams (rows x panels) with the same reuse pattern.
-        traffic = None
-        try:
-            pmc = json.loads((ROOT / "profiles" / "r01b_pmc_summary.json").read_text())["k_rotate3"]
-            if pmc["D"] == D and pmc["d"] == d:
-                rows_per_launch = stage["rotate_flops"] / launches / (8.0 * (D + 1) ** 2)
-                traffic = (pmc["fetch_bytes_x2"] + pmc["write_bytes"]) * rows_per_launch / pmc["rows_per_launch"]
-        except Exception:
-            pass
+        Kf, Np = -(-D // 128) * 128, -(-(D + 1) // 64) * 64
+        rot_launches = max(stage["rotate_launches"], 1.0)
+        rot_rows = stage["rotate_flops"] / (8.0 * (D + 1) ** 2)  # rows through K4 over the timed steps
+        rot_exec_tflops = 6.0 * rot_rows * Kf * Np / max(stage["rotate"], 1e-12) / 1e12
+        rot_alg_tflops = stage["rotate_flops"] / max(stage["rotate"], 1e-12) / 1e12
+        # Traffic past L2 comes from separate rocprofv3 PMC passes (it cannot be read live); per row because every launch
+        # streams (rows x panels) with the same reuse pattern.
+        traffic = k1_traffic = None
+        for name in ("r02_pmc_summary.json", "r01b_pmc_summary.json"):
+            try:
+                pmc = json.loads((ROOT / "profiles" / name).read_text())
+                pr = pmc["k_rotate3"]
+                if traffic is None and pr["D"] == D and pr["d"] == d:
+                    traffic = (pr["fetch_bytes_x2"] + pr["write_bytes"]) * (rot_rows / rot_launches) / pr["rows_per_launch"]
+                pk = pmc.get("k_featuremap")
+                if k1_traffic is None and pk and pk["D"] == D and pk["d"] == d:
+                    k1_traffic = pk["hbm_bytes_per_row"]
+            except Exception:
+                pass
+        fm_launches = max(stage["featuremap_launches"], 1.0)
+        fm_rows = stage["featuremap_flops"] / (2.0 * d * D)
+        fm_bytes = fm_rows * (8.0 * d + 16.0 * (D + 1))  # 8 n d + 16 n (D+1) algorithmic bytes
+        fm_gbs = fm_bytes / max(stage["featuremap"], 1e-12) / 1e9
+        whole_alg = (stage["rotate_flops"] + stage["gram_flops"] + stage["sweep_flops"] + stage["featuremap_flops"]) / elapsed / 1e12
         out = {
             "metric": "fits/sec (full gamma-sweep), n=1e6 d=128 D=4096" if args.config == "c3"
             else ("gamma x sigma grids/sec (16 sigma x 32 gamma), n=1e6 d=128 D=4096" if grid_mode else f"fits/sec (full gamma-sweep), {args.config}"),
@@ -220,47 +294,59 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
+            "value_pcie_inclusive": None if pcie is None else 1.0 / pcie,
             "config": {
                 "workload": cfg["name"],
                 "n": n, "d": d, "D": D, "G": G,
                 "rows_per_gpu": hi - lo,
-                "parallelism": (f"sigma-shard x{world}, rows replicated" if grid_mode else f"row-shard x{world}, all-reduce of A||b") if world > 1 else "single GPU",
-                "affine": "identity shift/scale, B = ORF Z(RandomState 42)/sqrt(d)",
+                "parallelism": (f"sigma-shard x{world}, rows replicated" if grid_mode else f"row-shard x{world}, RCCL all-reduce of A||b") if world > 1 else "single GPU",
+                "affine": f"package pre-step (AffineSeparator + ORF RandomState 42) fitted on the first {min(n, PRESTEP_PREFIX)} rows (SURVEY 8d)",
                 "gamma_index": r["opt"],
                 "loo_score": r["loo_score"],
             },
             "roofline": {
                 "kernel": "k_rotate3",
                 "bound": "mfma",
-                "achieved": rot_tflops,
+                "achieved": rot_exec_tflops,
                 "peak": FP64_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
-                "frac": rot_tflops / FP64_MFMA_PEAK_TFLOPS,
+                "frac": rot_exec_tflops / FP64_MFMA_PEAK_TFLOPS,
                 "traffic": traffic,
-                "traffic_unit": "bytes/launch beyond L2 (2 x FETCH_SIZE + WRITE_SIZE, Infinity-Cache hits included), profiles/r01b_pmc_summary.md",
-                "note": "achieved counts the ALGORITHMIC 8 n (D+1)^2 flops of the four-product complex GEMM; the kernel executes "
-                "the 3M form (6 n Kf Np flops, Kf = ceil(D/128)*128, Np = ceil((D+1)/64)*64), so frac can exceed 1; executed_frac is the matrix-pipe utilisation",
-                "executed_frac": 6.0 * (stage["rotate_flops"] / (8.0 * (D + 1) ** 2)) * (-(-D // 128) * 128) * (-(-(D + 1) // 64) * 64)
-                / max(stage["rotate"], 1e-12) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
-                "avg_launch_ms": 1e3 * stage["rotate"] / launches,
-                "flops_per_launch": stage["rotate_flops"] / launches,
-                "whole_fit_tflops": (stage["rotate_flops"] + stage["gram_flops"] + stage["sweep_flops"] + stage["featuremap_flops"])
-                / elapsed / 1e12,
+                "traffic_unit": "bytes/launch beyond L2 (2 x FETCH_SIZE + WRITE_SIZE, Infinity-Cache hits included), profiles/*_pmc_summary.md",
+                "note": "achieved = EXECUTED MFMA flops (3M complex product: 6 rows Kf Np, Kf = ceil(D/128)*128, Np = ceil((D+1)/64)*64) / kernel "
+                "time, so frac is the matrix-pipe utilisation; the algorithmic 8 rows (D+1)^2 of the four-product form is reported beside it",
+                "algorithmic_tflops": rot_alg_tflops,
+                "algorithmic_gain": rot_alg_tflops / rot_exec_tflops,
+                "avg_launch_ms": 1e3 * stage["rotate"] / rot_launches,
+                "executed_flops_per_launch": 6.0 * rot_rows * Kf * Np / rot_launches,
+                "whole_fit_algorithmic_tflops": whole_alg,
+            },
+            "roofline_k1": {
+                "kernel": "k_featuremap (+ k_shift_pad)",
+                "bound": "hbm",
+                "achieved": fm_gbs,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": fm_gbs / HBM_PEAK_GBS,
+                "traffic": None if k1_traffic is None else k1_traffic * fm_rows / fm_launches,
+                "avg_launch_ms": 1e3 * stage["featuremap"] / fm_launches,
+                "algorithmic_bytes_per_launch": fm_bytes / fm_launches,
             },
             "stage_ms_per_step": {
-                k: round(1e3 * stage[k] / args.steps, 3)
+                k: round(1e3 * stage.get(k, 0.0) / args.steps, 3)
                 for k in ("upload", "featuremap", "gram", "allreduce", "evd", "rotate", "sweep", "loo", "cholesky", "residuals", "download", "total")
             },
         }
         if not args.no_cpu_baseline and world == 1:
+            ctx.release_workspace()
             out["cpu_baseline"] = cpu_baseline(cfg, shift, scale, B, gammas)
-            out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+            out["cpu_baseline"]["gpu_over_cpu"] = out["value"] * (cfg.get("sigmas", 1)) / out["cpu_baseline"]["value"]
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    if cctx is not None and cctx is not ctx:
+        cctx.close()
     ctx.close()
-    if dist is not None:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

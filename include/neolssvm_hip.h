@@ -17,6 +17,8 @@
  *   nls_dual_fit            NeoLSSVM._optimize_alpha_gamma(X, y, s)      _neo_ls_svm.py:191-325
  *   nls_bin_stats           per-bin weighted medians / deviations        _affine_normalizer.py:72-79
  *   nls_dual_predict        decision_function / predict_std (dual)       _neo_ls_svm.py:666-671, 470-477
+ *   nls_factor_create       cho_solve(self.L_, .) state of predict_std   _neo_ls_svm.py:464-469 (the factor kept on the device)
+ *   nls_comm_*              (no counterpart: the reference is single-process)
  *
  * Conventions
  *   - Every call returns 0 on success, non-zero on failure; nls_last_error() gives the message.
@@ -31,10 +33,13 @@
  *     staged with one H2D copy.  Small parameter arrays (shift, scale, B, gammas, beta, L, alpha) and
  *     all outputs are host pointers.  Nothing is retained after a call returns.
  *   - Calls are blocking; one host thread per context.  The library never uses a CPU fallback.
- *   - Multi-GPU: one process and one context per GPU, rows sharded by the caller.  The library calls
- *     the registered all-reduce hook (sum over ranks, in place, on a DEVICE buffer of doubles) at the
- *     three points where the path exchanges data: {sum s, sum s*y, n}, the Hermitian block A||b, and
- *     the per-gamma error vectors.  Without a hook the context is single-rank.
+ *   - Multi-GPU: one process and one context per GPU, rows sharded by the caller.  The path exchanges data at
+ *     four points: {sum s, sum s*y, n}, the Hermitian block A||b (sum all-reduce), the eigenvectors (rank 0 runs the
+ *     tridiagonal eigensolver and broadcasts; every rank back-transforms one column block; all-gather) and the
+ *     per-gamma error vectors (sum all-reduce).  The collectives are RCCL calls on the library's own stream once
+ *     nls_comm_init_rank has joined the context to a communicator (librccl is loaded on first use; no PyTorch
+ *     anywhere); alternatively a caller-supplied all-reduce hook (nls_set_allreduce: CPU tests over gloo, several
+ *     ranks sharing one GPU).  Without either the context is single-rank.
  */
 #ifndef NEOLSSVM_HIP_H
 #define NEOLSSVM_HIP_H
@@ -52,7 +57,7 @@ extern "C" {
 #define NLS_ERR_LINALG 3
 #define NLS_ERR_COMM 4
 
-#define NLS_ABI_VERSION 1
+#define NLS_ABI_VERSION 2
 #define NLS_NUM_TIMINGS 24
 
 typedef struct nls_ctx nls_ctx;
@@ -70,8 +75,26 @@ void nls_ctx_destroy(nls_ctx* ctx);
 const char* nls_last_error(const nls_ctx* ctx);
 /* Register the collective hook; world == 1 or fn == NULL resets to single-rank. */
 int nls_set_allreduce(nls_ctx* ctx, nls_allreduce_fn fn, void* user, int rank, int world);
-/* Upper bound, in bytes, on the device workspace the context may hold (0 = default: 60% of HBM). */
+/* Upper bound, in bytes, on the device workspace the context may hold (0 = default: 60% of HBM).  Row chunks are
+ * planned against it; a workspace request that would take the total past an explicitly set limit (the n x n
+ * buffers of the eigendecomposition / dual path cannot be chunked) fails with NLS_ERR_ARG instead of allocating. */
 int nls_set_workspace_limit(nls_ctx* ctx, size_t bytes);
+/* Free the context's workspace buffers of at least min_bytes each (0 = all of them) and return the bytes still held.
+ * The workspace is a grow-only arena between calls (no hipMalloc in steady state); this is the trim. */
+int nls_ws_release(nls_ctx* ctx, size_t min_bytes, size_t* still_held);
+
+/* ---- multi-GPU: native RCCL communicator (one process per GPU) ----------------------------------------------
+ * Rank 0 calls nls_comm_get_unique_id and hands the NLS_COMM_ID_BYTES bytes to the other ranks by any means (file,
+ * socket, environment); every rank then calls nls_comm_init_rank on its own context (collective, blocks until all
+ * ranks arrive).  From then on nls_primal_fit treats X, y, s as this rank's row block.  nls_comm_allreduce is the
+ * small utility collective a driver needs around the library (barrier, max of a timing): count doubles at a HOST
+ * address (at most NLS_COMM_UTIL_MAX), op 0 = sum, 1 = max. */
+#define NLS_COMM_ID_BYTES 128
+#define NLS_COMM_UTIL_MAX 8192
+int nls_comm_get_unique_id(void* id);
+int nls_comm_init_rank(nls_ctx* ctx, const void* id, int rank, int world);
+int nls_comm_destroy(nls_ctx* ctx);
+int nls_comm_allreduce(nls_ctx* ctx, double* host_values, size_t count, int op);
 
 /* ---- device memory plumbing (so a host without a GPU array library can keep inputs resident) -- */
 int nls_device_malloc(nls_ctx* ctx, size_t bytes, void** dptr);
@@ -129,6 +152,12 @@ typedef struct nls_primal_fit_args {
   int32_t d, D, G;
   int32_t is_classifier;  /* 0 regressor, 1 classifier (residual clipping + hinge selection)  */
   int32_t gamma_index_in; /* >= 0 forces the selected grid index, -1 = argmin as the reference */
+  int32_t flags;          /* NLS_FIT_* bits                                                    */
+  const double* Cmat;     /* complexity matrix C of the penalty gamma beta^H C beta: NULL = identity (the reference's */
+                          /* fast diagonal approximation, _feature_maps.py:129-135), else (D+1) x (D+1) real      */
+                          /* symmetric positive definite, row-major, host: the generalised-EVD branch            */
+                          /* eigh(A, b=C) of _neo_ls_svm.py:122-124,131,139                                      */
+  double finish_below;    /* NLS_FIT_FINISH_IF_BELOW: threshold on the selected objective         */
   /* outputs (host; any may be NULL) */
   double* beta;          /* 2 (D+1)   fitted weights, complex128                              */
   double* L;             /* 2 (D+1)^2 cho_factor(gamma* C + A) as scipy returns it: upper     */
@@ -142,8 +171,14 @@ typedef struct nls_primal_fit_args {
   double* residuals;     /* n         Re(phi beta) - y after the Cholesky re-solve            */
   double* loo_score;     /* 1         weighted accuracy / R^2 of the LOO predictions          */
   int32_t* gamma_index;  /* 1         selected grid index                                     */
+  int32_t* finished;     /* 1         1 when P8 / P9 ran (beta, L, residuals, row outputs written), else 0 */
   double* timings;       /* NLS_NUM_TIMINGS seconds per stage, see NLS_T_* (HIP events)       */
 } nls_primal_fit_args;
+
+/* flags */
+#define NLS_FIT_SWEEP_ONLY 1      /* stop after the gamma selection (P1-P7): no Cholesky re-solve, no residuals / L / beta */
+#define NLS_FIT_FINISH_IF_BELOW 2 /* run P8 / P9 only when objective[selected] < finish_below: a gamma x sigma grid    */
+                                  /* finishes only the sigmas that beat the incumbent (the others need the curve only) */
 
 /* indices into timings[] */
 #define NLS_T_TOTAL 0
@@ -171,13 +206,19 @@ typedef struct nls_primal_fit_args {
 int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* args);
 
 /* ---- primal inference -------------------------------------------------------------------------
- * yhat[i] = Re(phi(x_i) . beta); sigma[i] = sqrt(Re phi_i (U^H U)^-1 phi_i^H).  Either output may be
- * NULL; L (format as nls_primal_fit's output) is only read when sigma != NULL.  The context keeps the inverse
- * factor of the last host L it was given (recognised by address, size and a checksum of its diagonal and of one entry
- * per row): L is fitted state and must not be edited in place between calls. */
+ * A factor handle keeps U^-1 of one fitted Cholesky factor on the device (as the B-operand planes of the rotation
+ * kernel), so that repeated predict_std calls skip the (D+1)^2 upload and the triangular inversion.  The handle is
+ * explicit state owned by the caller: create it from L_ after a fit, destroy it (or the context) when done.
+ * L: (D+1) x (D+1) complex128, scipy cho_factor(lower=False) layout as returned by nls_primal_fit, host or device. */
+typedef struct nls_factor nls_factor;
+int nls_factor_create(nls_ctx* ctx, const double* L, int D, nls_factor** factor);
+int nls_factor_destroy(nls_ctx* ctx, nls_factor* factor);
+
+/* yhat[i] = Re(phi(x_i) . beta); sigma[i] = sqrt(Re phi_i (U^H U)^-1 phi_i^H).  Either output may be NULL.
+ * sigma needs the factor: a handle (preferred), or L itself (inverted on the fly, nothing kept). */
 int nls_primal_predict(nls_ctx* ctx, const double* X, int64_t m, int d, const double* shift,
                        const double* scale, const double* B, int D, const double* beta,
-                       const double* L, double* yhat, double* sigma);
+                       const double* L, const nls_factor* factor, double* yhat, double* sigma);
 
 /* ---- supervised normaliser statistics (next row after the hot path) ------------
  * Per class bin b and input column j: the weighted median of X[bin b, j] (weighted_quantile(.., 0.5), the average of

@@ -4,11 +4,12 @@ Host code is Python + NumPy marshalling over a ctypes C ABI (``include/neolssvm_
 hand-written HIP kernels for gfx950 plus rocSOLVER for the dense EVD / Cholesky.  No CPU fallback.
 """
 
-from ._lib import Context, DeviceArray, NlsError, default_context, load_library  # noqa: F401
+from ._lib import Context, DeviceArray, Factor, NlsError, default_context, load_library  # noqa: F401
 from .hotpath import (  # noqa: F401
     dual_fit,
     dual_predict,
     eigh,
+    exact_complexity_matrix,
     featuremap,
     gamma_grid,
     gram,
@@ -28,6 +29,7 @@ __all__ = [
     "AffineSeparator",
     "Context",
     "DeviceArray",
+    "Factor",
     "NlsError",
     "default_context",
     "load_library",
@@ -40,6 +42,7 @@ __all__ = [
     "dual_predict",
     "gamma_grid",
     "orf_frequencies",
+    "exact_complexity_matrix",
     "eigh",
     "tridiagonalize",
 ]

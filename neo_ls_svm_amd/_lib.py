@@ -17,6 +17,9 @@ _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("NEOLSSVM_HIP_LIB", _HERE / "libneolssvm_hip.so"))
 
 NLS_OK, NLS_ERR_ARG, NLS_ERR_HIP, NLS_ERR_LINALG, NLS_ERR_COMM = 0, 1, 2, 3, 4
+ABI_VERSION = 2
+FIT_SWEEP_ONLY, FIT_FINISH_IF_BELOW = 1, 2
+COMM_ID_BYTES = 128
 NUM_TIMINGS = 24
 TIMING_NAMES = {
     "total": 0,
@@ -64,6 +67,9 @@ class PrimalFitArgs(C.Structure):
         ("G", C.c_int32),
         ("is_classifier", C.c_int32),
         ("gamma_index_in", C.c_int32),
+        ("flags", C.c_int32),
+        ("Cmat", C.c_void_p),
+        ("finish_below", C.c_double),
         ("beta", C.c_void_p),
         ("L", C.c_void_p),
         ("lam", C.c_void_p),
@@ -75,6 +81,7 @@ class PrimalFitArgs(C.Structure):
         ("residuals", C.c_void_p),
         ("loo_score", C.c_void_p),
         ("gamma_index", C.c_void_p),
+        ("finished", C.c_void_p),
         ("timings", C.c_void_p),
     ]
 
@@ -114,6 +121,13 @@ SIGNATURES = {
     "nls_last_error": (C.c_char_p, [C.c_void_p]),
     "nls_set_allreduce": (C.c_int, [C.c_void_p, ALLREDUCE_FN, C.c_void_p, C.c_int, C.c_int]),
     "nls_set_workspace_limit": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "nls_ws_release": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "nls_comm_get_unique_id": (C.c_int, [C.c_void_p]),
+    "nls_comm_init_rank": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "nls_comm_destroy": (C.c_int, [C.c_void_p]),
+    "nls_comm_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
+    "nls_factor_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "nls_factor_destroy": (C.c_int, [C.c_void_p, C.c_void_p]),
     "nls_device_malloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "nls_device_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "nls_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
@@ -140,7 +154,7 @@ SIGNATURES = {
     "nls_primal_predict": (
         C.c_int,
         [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
-        + [C.c_void_p, C.c_void_p],
+        + [C.c_void_p, C.c_void_p, C.c_void_p],
     ),
     "nls_bin_stats": (
         C.c_int,
@@ -167,11 +181,13 @@ def load_library() -> C.CDLL:
             "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C neo_ls_svm_amd/csrc`). "
             "neo_ls_svm_amd has no CPU fallback."
         )
-    lib = C.CDLL(str(LIB_PATH), mode=C.RTLD_GLOBAL)
+    lib = C.CDLL(str(LIB_PATH))
     for name, (restype, argtypes) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the export is missing
         fn.restype = restype
         fn.argtypes = argtypes
+    if lib.nls_abi_version() != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH} has ABI version {lib.nls_abi_version()}, this package needs {ABI_VERSION}: rebuild the library")
     _lib = lib
     return lib
 
@@ -239,6 +255,32 @@ def _ptr(a):
     return a.ctypes.data
 
 
+class Factor:
+    """Device-resident inverse of one fitted Cholesky factor ``L_`` (``nls_factor_create``): what repeated
+    ``predict_std`` calls reuse instead of uploading and inverting (D+1)^2 complex numbers every time.  Explicit state:
+    it belongs to the estimator that fitted ``L`` and is dropped (``close``) on refit; nothing is keyed on addresses."""
+
+    def __init__(self, ctx: "Context", L: np.ndarray):
+        L = np.ascontiguousarray(L, dtype=np.complex128)
+        if L.ndim != 2 or L.shape[0] != L.shape[1] or L.shape[0] < 2:
+            raise ValueError("L must be a (D+1) x (D+1) complex matrix")
+        self.ctx, self.D = ctx, L.shape[0] - 1
+        h = C.c_void_p()
+        ctx._check(ctx.lib.nls_factor_create(ctx.handle, L.ctypes.data, self.D, C.byref(h)))
+        self.handle = h
+
+    def close(self):
+        if getattr(self, "handle", None) and getattr(self.ctx, "handle", None):
+            self.ctx.lib.nls_factor_destroy(self.ctx.handle, self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Context:
     """One context per process and GPU: stream, rocBLAS/rocSOLVER handles, grow-only workspace."""
 
@@ -271,6 +313,42 @@ class Context:
 
     def synchronize(self):
         self._check(self.lib.nls_synchronize(self.handle))
+
+    def release_workspace(self, min_bytes: int = 0) -> int:
+        """Free the workspace buffers of at least ``min_bytes`` each (0: all); returns the bytes still held.  The arena
+        only grows between calls (a c3-size fit leaves ~100 GB allocated for the next one); this is the trim."""
+        held = C.c_size_t()
+        self._check(self.lib.nls_ws_release(self.handle, int(min_bytes), C.byref(held)))
+        return int(held.value)
+
+    # ---- native RCCL communicator (one process per GPU; no torch) -----------------------------------
+    def comm_unique_id(self) -> bytes:
+        """Rank 0: a fresh communicator id (128 bytes) to hand to the other ranks (file, socket, env ...)."""
+        buf = C.create_string_buffer(COMM_ID_BYTES)
+        rc = self.lib.nls_comm_get_unique_id(buf)
+        if rc != NLS_OK:
+            msg = self.lib.nls_last_error(None)
+            raise NlsError(f"nls_comm_get_unique_id failed: {msg.decode() if msg else rc}")
+        return bytes(buf.raw)
+
+    def comm_init(self, unique_id: bytes, rank: int, world: int):
+        """Join the communicator (collective over all ranks); from now on ``primal_fit`` treats its rows as this
+        rank's block of a row-sharded problem."""
+        if len(unique_id) != COMM_ID_BYTES:
+            raise ValueError(f"unique_id must be {COMM_ID_BYTES} bytes")
+        self._check(self.lib.nls_comm_init_rank(self.handle, C.c_char_p(unique_id), int(rank), int(world)))
+
+    def comm_destroy(self):
+        self._check(self.lib.nls_comm_destroy(self.handle))
+
+    def comm_allreduce(self, values, op: str = "sum") -> np.ndarray:
+        """Sum / max of a few host doubles over the ranks (driver utility: barrier, timing)."""
+        v = np.ascontiguousarray(np.atleast_1d(values), dtype=np.float64).copy()
+        self._check(self.lib.nls_comm_allreduce(self.handle, v.ctypes.data, v.size, {"sum": 0, "max": 1}[op]))
+        return v
+
+    def comm_barrier(self):
+        self.comm_allreduce([0.0])
 
     def device_info(self) -> dict:
         name = C.create_string_buffer(256)

@@ -60,6 +60,7 @@ extern "C" int nls_dual_fit(nls_ctx* ctx, const nls_dual_fit_args* a) {
   if (!a) return fail(ctx, NLS_ERR_ARG, "args is NULL");
   if (!a->Xt || !a->y || !a->s || !a->gammas) return fail(ctx, NLS_ERR_ARG, "Xt, y, s and gammas must not be NULL");
   if (a->n < 2 || a->r < 1 || a->G < 1) return fail(ctx, NLS_ERR_ARG, "need n >= 2, r >= 1, G >= 1");
+  if (a->n > 65535 - BM) return fail(ctx, NLS_ERR_ARG, "dual path: n = %ld exceeds 65407 rows (n x n kernel matrices); use the primal path", (long)a->n);
   if (a->gamma_index_in >= a->G) return fail(ctx, NLS_ERR_ARG, "gamma_index_in out of range");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   const double t_start = wall();
@@ -290,6 +291,7 @@ extern "C" int nls_dual_predict(nls_ctx* ctx, const double* Xq, int64_t m, const
   NLSCHK(resident(ctx, "in.Xq", Xq, (size_t)m * r, &dXq));
   // Query rows per chunk: K block of at most ~2 GiB.
   long mc = std::max<long>(BM, (long)(((size_t)2 << 30) / ((size_t)n_pad * 8)) / BM * BM);
+  mc = std::min<long>(mc, 65535 / BM * BM);  // the row index of the padding kernels is gridDim.y (HIP limit 65535)
   mc = std::min<long>(mc, round_up(m, BM));
   double *XtT = nullptr, *xx = nullptr, *Qp = nullptr, *qq = nullptr, *K = nullptr, *dalpha = nullptr, *dL = nullptr, *dy = nullptr,
          *dsig = nullptr, *asum = nullptr;

@@ -189,12 +189,68 @@ static bool evd_use_rocsolver() {
   return m && std::string(m) == "rocsolver";
 }
 
+// LAPACK's zheev / dsyev scale the matrix when its largest entry leaves [rmin, rmax] = [sqrt(safmin / eps), 1 / rmin]; the
+// panel's larfg (nls_trd.h) has no safmin rescaling loop of its own, so a general-purpose nls_eigh_only relies on this:
+// inside the safe range sums of squares of entries neither overflow nor lose more than entries already negligible
+// against the matrix norm.  Returns the factor applied (1 = none); eigenvalues are divided by it afterwards.
+__global__ void k_absmax_lower(const double* A, long lda_d, int n, int comps, unsigned long long* out) {
+  // A viewed as doubles; comps = 2 for complex.  One block per column.
+  const int c = blockIdx.x;
+  double m = 0.0;
+  for (long r = c + threadIdx.x; r < n; r += blockDim.x)
+    for (int k = 0; k < comps; ++k) {
+      const double v = fabs(A[(long)c * lda_d + r * comps + k]);
+      m = (v > m || v != v) ? v : m;  // NaN propagates
+    }
+  for (int o = 32; o > 0; o >>= 1) {
+    const double t = __shfl_xor(m, o, 64);
+    m = (t > m || t != t) ? t : m;
+  }
+  if ((threadIdx.x & 63) == 0) atomicMax(out, (unsigned long long)__double_as_longlong(m));  // non-negative doubles order like integers
+}
+__global__ void k_scale_lower(double* A, long lda_d, int n, int comps, double f) {
+  const int c = blockIdx.x;
+  for (long r = c + threadIdx.x; r < n; r += blockDim.x)
+    for (int k = 0; k < comps; ++k) A[(long)c * lda_d + r * comps + k] *= f;
+}
+static int evd_prescale(nls_ctx* ctx, void* A, int n, int comps, double* factor) {
+  unsigned long long* slot = nullptr;
+  NLSCHK(ws_get_t(ctx, "evd.absmax", 1, &slot));
+  HIPCHK(ctx, hipMemsetAsync(slot, 0, sizeof(*slot), ctx->stream));
+  hipLaunchKernelGGL(k_absmax_lower, dim3((unsigned)n), dim3(256), 0, ctx->stream, static_cast<const double*>(A), (long)n * comps, n, comps, slot);
+  HIPCHK(ctx, hipGetLastError());
+  unsigned long long bits = 0;
+  HIPCHK(ctx, hipMemcpyAsync(&bits, slot, sizeof(bits), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  double anrm;
+  std::memcpy(&anrm, &bits, sizeof(anrm));
+  if (!std::isfinite(anrm)) return fail(ctx, NLS_ERR_LINALG, "eigendecomposition: the matrix contains NaN or Inf");
+  const double rmin = std::sqrt(2.2250738585072014e-308 / 1.1102230246251565e-16), rmax = 1.0 / rmin;
+  *factor = 1.0;
+  if (anrm > 0.0 && anrm < rmin) *factor = rmin / anrm;
+  if (anrm > rmax) *factor = rmax / anrm;
+  if (*factor != 1.0) {
+    hipLaunchKernelGGL(k_scale_lower, dim3((unsigned)n), dim3(256), 0, ctx->stream, static_cast<double*>(A), (long)n * comps, n, comps, *factor);
+    HIPCHK(ctx, hipGetLastError());
+  }
+  return NLS_OK;
+}
+__global__ void k_vec_scale(double* v, int n, double f) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v[i] *= f;
+}
+static int evd_unscale(nls_ctx* ctx, double* lam, int n, double factor) {
+  if (factor == 1.0) return NLS_OK;
+  hipLaunchKernelGGL(k_vec_scale, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, lam, n, 1.0 / factor);
+  HIPCHK(ctx, hipGetLastError());
+  return NLS_OK;
+}
+
 // Hermitian: A (n x n complex column-major, lower) is destroyed; eigenvalues ascending in lam, eigenvectors
 // (columns) in *Q, which is either A itself (rocSOLVER path) or the workspace "evd.C".
-// collective = true (nls_primal_fit, where every rank holds the same all-reduced matrix): the back-transformation of
-// the eigenvectors is split by columns over the ranks and the blocks are exchanged through the all-reduce hook
-// (every rank contributes zeros outside its block, so the sum is an exact all-gather and Q is bit-identical everywhere).
-static int evd_hermitian(nls_ctx* ctx, double2* A, int n, double* lam, double* e_work, rocblas_int* dinfo, double2** Q, bool collective = false) {
+// collective = true (nls_primal_fit, where every rank holds the same all-reduced matrix): stedc on rank 0 + broadcast,
+// back-transformation split by columns over the ranks, blocks all-gathered (Q bit-identical everywhere).
+static int evd_hermitian_core(nls_ctx* ctx, double2* A, int n, double* lam, double* e_work, rocblas_int* dinfo, double2** Q, bool collective) {
   BLASCHK(ctx, rocblas_set_stream(ctx->blas, ctx->stream));
   if (evd_use_rocsolver() || n < 3) {
     BLASCHK(ctx, rocsolver_zheevd(ctx->blas, rocblas_evect_original, rocblas_fill_lower, n, reinterpret_cast<rocblas_double_complex*>(A), n, lam,
@@ -208,9 +264,29 @@ static int evd_hermitian(nls_ctx* ctx, double2* A, int n, double* lam, double* e
   NLSCHK(ws_get_t(ctx, "evd.tau", (size_t)n, &tau));
   NLSCHK(ws_get_t(ctx, "evd.C", (size_t)n * n, &C));
   NLSCHK(trd_fused<trd::Z>(ctx, reinterpret_cast<trd::Z*>(A), n, n, lam, e_work, tau));
-  BLASCHK(ctx, rocsolver_zstedc(ctx->blas, rocblas_evect_tridiagonal, n, lam, e_work, reinterpret_cast<rocblas_double_complex*>(C), n, dinfo));
-  NLSCHK(check_info(ctx, dinfo, "rocsolver_zstedc"));
-  if (collective && ctx->world > 1 && ctx->allreduce && n >= 64) {
+  if (collective && multi_rank(ctx) && n >= 64) {
+    // Every rank holds the same all-reduced matrix and the tridiagonalisation is bit-reproducible, so the reflectors are
+    // replicated.  The tridiagonal eigensolver runs on rank 0 ONLY and (lam, C) are broadcast: all ranks then pair the
+    // same eigenvalues with the same basis whatever rocSOLVER's stedc does on clustered spectra.  The back-transformation
+    // is split by columns over the ranks and the blocks are all-gathered.
+    double* flag = e_work;  // e is dead once stedc has run
+    double hflag = 0.0;
+    if (ctx->rank == 0) {
+      BLASCHK(ctx, rocsolver_zstedc(ctx->blas, rocblas_evect_tridiagonal, n, lam, e_work, reinterpret_cast<rocblas_double_complex*>(C), n, dinfo));
+      rocblas_int info = 0;
+      HIPCHK(ctx, hipMemcpyAsync(&info, dinfo, sizeof(info), hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      hflag = (double)info;
+    }
+    HIPCHK(ctx, hipMemcpyAsync(flag, &hflag, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    NLSCHK(do_broadcast(ctx, flag, 1, 0));
+    HIPCHK(ctx, hipMemcpyAsync(&hflag, flag, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (hflag != 0.0) return fail(ctx, NLS_ERR_LINALG, "rocsolver_zstedc (rank 0): info = %d (no convergence)", (int)hflag);
+    NLSCHK(do_broadcast(ctx, lam, (size_t)n, 0));
+    NLSCHK(do_broadcast(ctx, reinterpret_cast<double*>(C), (size_t)2 * n * n, 0));
+    std::vector<size_t> offs((size_t)ctx->world + 1);
+    for (int r = 0; r <= ctx->world; ++r) offs[r] = (size_t)2 * n * (size_t)((long)n * r / ctx->world);
     const long c0 = (long)n * ctx->rank / ctx->world, c1 = (long)n * (ctx->rank + 1) / ctx->world;
     if (evd_rocsolver_backtransform()) {
       BLASCHK(ctx, rocsolver_zunmtr(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, n, (rocblas_int)(c1 - c0),
@@ -219,10 +295,13 @@ static int evd_hermitian(nls_ctx* ctx, double2* A, int n, double* lam, double* e
     } else {
       NLSCHK(apply_q_blocked<trd::Z>(ctx, reinterpret_cast<trd::Z*>(A), n, n, tau, reinterpret_cast<trd::Z*>(C + c0 * n), n, (int)(c1 - c0)));
     }
-    HIPCHK(ctx, hipMemsetAsync(C, 0, sizeof(double2) * (size_t)c0 * n, ctx->stream));
-    HIPCHK(ctx, hipMemsetAsync(C + c1 * n, 0, sizeof(double2) * (size_t)(n - c1) * n, ctx->stream));
-    NLSCHK(do_allreduce(ctx, reinterpret_cast<double*>(C), (size_t)2 * n * n));
-  } else if (evd_rocsolver_backtransform()) {
+    NLSCHK(do_allgather_blocks(ctx, reinterpret_cast<double*>(C), offs));
+    *Q = C;
+    return NLS_OK;
+  }
+  BLASCHK(ctx, rocsolver_zstedc(ctx->blas, rocblas_evect_tridiagonal, n, lam, e_work, reinterpret_cast<rocblas_double_complex*>(C), n, dinfo));
+  NLSCHK(check_info(ctx, dinfo, "rocsolver_zstedc"));
+  if (evd_rocsolver_backtransform()) {
     BLASCHK(ctx, rocsolver_zunmtr(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, n, n,
                                   reinterpret_cast<rocblas_double_complex*>(A), n, reinterpret_cast<rocblas_double_complex*>(tau),
                                   reinterpret_cast<rocblas_double_complex*>(C), n));
@@ -233,7 +312,7 @@ static int evd_hermitian(nls_ctx* ctx, double2* A, int n, double* lam, double* e
   return NLS_OK;
 }
 
-static int evd_symmetric(nls_ctx* ctx, double* A, int n, double* lam, double* e_work, rocblas_int* dinfo, double** Q) {
+static int evd_symmetric_core(nls_ctx* ctx, double* A, int n, double* lam, double* e_work, rocblas_int* dinfo, double** Q) {
   BLASCHK(ctx, rocblas_set_stream(ctx->blas, ctx->stream));
   if (evd_use_rocsolver() || n < 3) {
     BLASCHK(ctx, rocsolver_dsyevd(ctx->blas, rocblas_evect_original, rocblas_fill_lower, n, A, n, lam, e_work, dinfo));
@@ -253,6 +332,19 @@ static int evd_symmetric(nls_ctx* ctx, double* A, int n, double* lam, double* e_
     NLSCHK(apply_q_blocked<double>(ctx, A, n, n, tau, C, n, n));
   *Q = C;
   return NLS_OK;
+}
+
+static int evd_hermitian(nls_ctx* ctx, double2* A, int n, double* lam, double* e_work, rocblas_int* dinfo, double2** Q, bool collective = false) {
+  double f = 1.0;
+  NLSCHK(evd_prescale(ctx, A, n, 2, &f));
+  NLSCHK(evd_hermitian_core(ctx, A, n, lam, e_work, dinfo, Q, collective));
+  return evd_unscale(ctx, lam, n, f);
+}
+static int evd_symmetric(nls_ctx* ctx, double* A, int n, double* lam, double* e_work, rocblas_int* dinfo, double** Q) {
+  double f = 1.0;
+  NLSCHK(evd_prescale(ctx, A, n, 1, &f));
+  NLSCHK(evd_symmetric_core(ctx, A, n, lam, e_work, dinfo, Q));
+  return evd_unscale(ctx, lam, n, f);
 }
 
 }  // namespace nls

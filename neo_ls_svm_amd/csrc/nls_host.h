@@ -2,6 +2,7 @@
 // reporting, grow-only workspace, pointer classification, stage timing, collective hook.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>  // types only: librccl is loaded with dlopen on first use (nls_comm.hip)
 #include <rocblas/rocblas.h>
 #include <rocsolver/rocsolver.h>
 
@@ -25,6 +26,26 @@ struct DevBuf {
   size_t bytes = 0;
 };
 
+// Entry points of librccl resolved at run time (nls_comm.hip): a single-GPU process never loads the library.
+struct RcclApi {
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclBroadcast) Broadcast = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+const RcclApi* rccl_api(std::string* why);
+
+// Device-resident inverse Cholesky factor for predict_std (nls_factor_create): the B-operand planes of U^-1.
+struct nls_factor {
+  nls_ctx* owner = nullptr;
+  int D = 0;
+  double *Mr = nullptr, *Mi = nullptr, *mbr = nullptr, *mbi = nullptr, *zero = nullptr;
+};
+
 struct nls_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -37,14 +58,13 @@ struct nls_ctx {
   nls_allreduce_fn allreduce = nullptr;
   void* allreduce_user = nullptr;
   int rank = 0, world = 1;
+  ncclComm_t comm = nullptr;  // native RCCL communicator (nls_comm_init_rank); takes precedence over the hook
+  double* comm_scratch = nullptr;  // a few doubles on the device for nls_comm_allreduce
+  size_t ws_bytes = 0;        // bytes currently held by the workspace arena
+  std::vector<nls_factor*> factors;
   // XCD patch shape of k_rotate3 (NLS_ROT_PATCH=RxC; 0x0 = plain order, the default: patches raise the L2 hit rate
   // from 0.57 to 0.78 and halve the fabric traffic but run 1-4 % slower, profiles/r01_pmc_summary.md)
   int rot_pr = 0, rot_pc = 0;
-  // nls_primal_predict keeps the inverse-factor planes of the last L it was given (fingerprint: host address, size,
-  // a checksum of the diagonal and of one entry per row), so repeated predict_std calls skip the 268 MB upload and ztrtri
-  const void* pred_L = nullptr;
-  int pred_D1 = 0;
-  double pred_hash = 0.0;
   bool no_resident = false;  // NLS_NO_RESIDENT_PLANES=1: recompute the feature planes per phase even when they would fit
   // stage timing
   struct Span {
@@ -97,12 +117,18 @@ static int ws_get(nls_ctx* ctx, const char* name, size_t bytes, void** out) {
   DevBuf& b = ctx->ws[name];
   if (b.bytes < bytes) {
     if (b.p) HIPCHK(ctx, hipFree(b.p));
+    ctx->ws_bytes -= b.bytes;
     b.p = nullptr;
     b.bytes = 0;
+    // An explicitly set limit is a hard bound (with 10 % slack for the small buffers the chunk planner does not count).
+    if (ctx->ws_limit && (double)(ctx->ws_bytes + bytes) > 1.1 * (double)ctx->ws_limit + (double)(64u << 20))
+      return fail(ctx, NLS_ERR_ARG, "workspace '%s' (%zu bytes) would take the context to %zu bytes, past the limit of %zu set with "
+                  "nls_set_workspace_limit", name, bytes, ctx->ws_bytes + bytes, ctx->ws_limit);
     hipError_t e = hipMalloc(&b.p, bytes);
     if (e != hipSuccess)
       return fail(ctx, NLS_ERR_HIP, "hipMalloc(%zu bytes) for workspace '%s' failed: %s", bytes, name, hipGetErrorString(e));
     b.bytes = bytes;
+    ctx->ws_bytes += bytes;
   }
   *out = b.p;
   return NLS_OK;
@@ -182,12 +208,61 @@ struct SpanGuard {  // RAII so early returns still close the span
   }
 };
 
+// ------------------------------------------------------------------------------------------------
+// Collectives of the row-sharded primal fit.  With a native communicator they are RCCL calls enqueued on the
+// library's stream (stream-ordered, no host synchronisation); with only the caller's all-reduce hook the broadcast
+// and the all-gather are expressed as sums (zeros outside the owned part), which is exact.
+// ------------------------------------------------------------------------------------------------
+#define RCCLCHK(ctx, api, call)                                                                              \
+  do {                                                                                                       \
+    ncclResult_t r__ = (call);                                                                               \
+    if (r__ != ncclSuccess)                                                                                  \
+      return fail(ctx, NLS_ERR_COMM, "%s failed: %s (%s:%d)", #call, (api)->GetErrorString(r__), __FILE__, __LINE__); \
+  } while (0)
+
+static inline bool multi_rank(const nls_ctx* ctx) { return ctx->world > 1 && (ctx->comm || ctx->allreduce); }
+
 static int do_allreduce(nls_ctx* ctx, double* dbuf, size_t count) {
-  if (ctx->world <= 1 || !ctx->allreduce) return NLS_OK;
+  if (!multi_rank(ctx)) return NLS_OK;
+  if (ctx->comm) {
+    const RcclApi* api = rccl_api(nullptr);
+    RCCLCHK(ctx, api, api->AllReduce(dbuf, dbuf, count, ncclDouble, ncclSum, ctx->comm, ctx->stream));
+    return NLS_OK;
+  }
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   int rc = ctx->allreduce(dbuf, count, ctx->allreduce_user);
   if (rc != 0) return fail(ctx, NLS_ERR_COMM, "all-reduce hook returned %d", rc);
   return NLS_OK;
+}
+
+// dbuf[0:count] of rank `root` to every rank.
+static int do_broadcast(nls_ctx* ctx, double* dbuf, size_t count, int root) {
+  if (!multi_rank(ctx)) return NLS_OK;
+  if (ctx->comm) {
+    const RcclApi* api = rccl_api(nullptr);
+    RCCLCHK(ctx, api, api->Broadcast(dbuf, dbuf, count, ncclDouble, root, ctx->comm, ctx->stream));
+    return NLS_OK;
+  }
+  if (ctx->rank != root) HIPCHK(ctx, hipMemsetAsync(dbuf, 0, count * sizeof(double), ctx->stream));
+  return do_allreduce(ctx, dbuf, count);
+}
+
+// Rank r owns dbuf[offs[r] : offs[r + 1]) (offs has world + 1 entries, in doubles); afterwards every rank holds all blocks.
+static int do_allgather_blocks(nls_ctx* ctx, double* dbuf, const std::vector<size_t>& offs) {
+  if (!multi_rank(ctx)) return NLS_OK;
+  if (ctx->comm) {
+    const RcclApi* api = rccl_api(nullptr);
+    RCCLCHK(ctx, api, api->GroupStart());
+    for (int r = 0; r < ctx->world; ++r)
+      if (offs[r + 1] > offs[r])
+        RCCLCHK(ctx, api, api->Broadcast(dbuf + offs[r], dbuf + offs[r], offs[r + 1] - offs[r], ncclDouble, r, ctx->comm, ctx->stream));
+    RCCLCHK(ctx, api, api->GroupEnd());
+    return NLS_OK;
+  }
+  const size_t lo = offs[ctx->rank], hi = offs[ctx->rank + 1], tot = offs[ctx->world];
+  if (lo > 0) HIPCHK(ctx, hipMemsetAsync(dbuf, 0, lo * sizeof(double), ctx->stream));
+  if (tot > hi) HIPCHK(ctx, hipMemsetAsync(dbuf + hi, 0, (tot - hi) * sizeof(double), ctx->stream));
+  return do_allreduce(ctx, dbuf, tot);
 }
 
 static double wall() {

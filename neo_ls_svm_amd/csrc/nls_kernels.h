@@ -577,6 +577,15 @@ __global__ void k_add_diag(double2* Acm, long lda, int D1, double v) {
   if (i < D1) Acm[(long)i * lda + i].x += v;
 }
 
+// y += alpha x (complex arrays, real alpha)
+__global__ void k_axpy_z(const double2* x, double alpha, long n, double2* y) {
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i < n) {
+    y[i].x += alpha * x[i].x;
+    y[i].y += alpha * x[i].y;
+  }
+}
+
 __global__ void k_conj_inplace(double2* a, long n) {
   const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
   if (i < n) a[i].y = -a[i].y;
@@ -592,9 +601,10 @@ __global__ void k_split_vec(const double2* v, int len, int n_out, double* vr, do
 
 // out[i][j] = in[i][j] for j < cols (ld_in -> cols contiguous)
 __global__ void k_compact_rows(const double* in, long ld_in, long rows, int cols, double* out) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  const long i = blockIdx.y;
-  if (j < cols && i < rows) out[i * cols + j] = in[i * ld_in + j];
+  const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (idx >= rows * cols) return;
+  const long i = idx / cols;
+  out[idx] = in[i * ld_in + (idx - i * cols)];
 }
 
 }  // namespace nls

@@ -157,10 +157,19 @@ extern "C" int nls_ctx_create(int device, nls_ctx** out) {
   return NLS_OK;
 }
 
+static void factor_free(nls_factor* f) {
+  for (double* p : {f->Mr, f->Mi, f->mbr, f->mbi, f->zero})
+    if (p) (void)hipFree(p);
+  delete f;
+}
+
 extern "C" void nls_ctx_destroy(nls_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  (void)nls_comm_destroy(ctx);
+  if (ctx->comm_scratch) (void)hipFree(ctx->comm_scratch);
+  for (nls_factor* f : ctx->factors) factor_free(f);
   for (auto& kv : ctx->ws)
     if (kv.second.p) (void)hipFree(kv.second.p);
   for (auto ev : ctx->event_pool) (void)hipEventDestroy(ev);
@@ -174,9 +183,10 @@ extern "C" const char* nls_last_error(const nls_ctx* ctx) { return ctx ? ctx->er
 extern "C" int nls_set_allreduce(nls_ctx* ctx, nls_allreduce_fn fn, void* user, int rank, int world) {
   if (!ctx) return NLS_ERR_ARG;
   if (world < 1 || rank < 0 || rank >= world) return fail(ctx, NLS_ERR_ARG, "bad rank/world %d/%d", rank, world);
+  if (ctx->comm) return fail(ctx, NLS_ERR_ARG, "the context already has a native communicator (nls_comm_destroy first)");
   ctx->allreduce = (world > 1) ? fn : nullptr;
   ctx->allreduce_user = user;
-  ctx->rank = rank;
+  ctx->rank = (fn && world > 1) ? rank : 0;
   ctx->world = (fn && world > 1) ? world : 1;
   return NLS_OK;
 }
@@ -184,6 +194,23 @@ extern "C" int nls_set_allreduce(nls_ctx* ctx, nls_allreduce_fn fn, void* user, 
 extern "C" int nls_set_workspace_limit(nls_ctx* ctx, size_t bytes) {
   if (!ctx) return NLS_ERR_ARG;
   ctx->ws_limit = bytes;
+  return NLS_OK;
+}
+
+extern "C" int nls_ws_release(nls_ctx* ctx, size_t min_bytes, size_t* still_held) {
+  if (!ctx) return NLS_ERR_ARG;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  for (auto it = ctx->ws.begin(); it != ctx->ws.end();) {
+    if (it->second.p && it->second.bytes >= min_bytes) {
+      HIPCHK(ctx, hipFree(it->second.p));
+      ctx->ws_bytes -= it->second.bytes;
+      it = ctx->ws.erase(it);
+    } else {
+      ++it;
+    }
+  }
+  if (still_held) *still_held = ctx->ws_bytes;
   return NLS_OK;
 }
 
@@ -529,8 +556,8 @@ extern "C" int nls_rotate_only(nls_ctx* ctx, const double* X, int64_t n, int d, 
     for (int which = 0; which < 2; ++which) {
       double* dst = which ? Gmout : Uout;
       if (!dst) continue;
-      hipLaunchKernelGGL(k_compact_rows, dim3((unsigned)((D1 + 255) / 256), (unsigned)rows), dim3(256), 0, ctx->stream, which ? Gm : U,
-                         (long)Np, rows, D1, cmp);
+      hipLaunchKernelGGL(k_compact_rows, dim3((unsigned)((rows * D1 + 255) / 256)), dim3(256), 0, ctx->stream, which ? Gm : U, (long)Np,
+                         rows, D1, cmp);
       HIPCHK(ctx, hipGetLastError());
       HIPCHK(ctx, hipMemcpyAsync(dst + r0 * D1, cmp, sizeof(double) * (size_t)rows * D1, hipMemcpyDeviceToHost, ctx->stream));
       HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -546,6 +573,7 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
   if (!a->X || !a->y || !a->s || !a->gammas) return fail(ctx, NLS_ERR_ARG, "X, y, s and gammas must not be NULL");
   if (a->n < 1 || a->G < 1) return fail(ctx, NLS_ERR_ARG, "n and G must be >= 1 (n=%ld, G=%d)", (long)a->n, a->G);
   if (a->gamma_index_in >= a->G) return fail(ctx, NLS_ERR_ARG, "gamma_index_in out of range");
+  if (a->flags & ~(NLS_FIT_SWEEP_ONLY | NLS_FIT_FINISH_IF_BELOW)) return fail(ctx, NLS_ERR_ARG, "unknown flag bits 0x%x", (unsigned)a->flags);
   HIPCHK(ctx, hipSetDevice(ctx->device));
   const double t_start = wall();
   double tm[NLS_NUM_TIMINGS];
@@ -583,14 +611,50 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
   NLSCHK(ws_get_t(ctx, "sweep.gammas", (size_t)G, &dgam));
   NLSCHK(ws_get_t(ctx, "sweep.R", (size_t)Np * Gp, &R));
   HIPCHK(ctx, hipMemcpyAsync(dgam, a->gammas, sizeof(double) * G, hipMemcpyHostToDevice, ctx->stream));
+  // Identity complexity matrix (the only one the reference reaches): A / c = Q Lam Q^H with c = 1 / (n (D+1)), Q unitary,
+  // leverage s^2 |phi Q|^2 / c.  General C (8(f) #4): C <- C / mean|diag C| / (n (D+1)) (_neo_ls_svm.py:117), C = Lc Lc^H,
+  // Lc^-1 A Lc^-H = W Lam W^H, Q = Lc^-H W, which is what eigh(A, b=C) returns (Q^H C Q = I, so lu_solve(C Q, x) = Q^H x):
+  // the same rotation with the 1 / c factors replaced by 1.
+  const bool general_C = a->Cmat != nullptr;
+  const double inv_c = general_C ? 1.0 : 1.0 / st.c;
+  double2 *Cn = nullptr, *Lc = nullptr;
   {
     SpanGuard g(ctx, NLS_T_EVD);
     NLSCHK(assemble_A(ctx, st, 1.0, Acm, db));
-    NLSCHK(assemble_A(ctx, st, 1.0 / st.c, Qcm, nullptr));
+    NLSCHK(assemble_A(ctx, st, inv_c, Qcm, nullptr));
+    if (general_C) {
+      NLSCHK(ws_get_t(ctx, "gevd.C", (size_t)D1 * D1, &Cn));
+      NLSCHK(ws_get_t(ctx, "gevd.L", (size_t)D1 * D1, &Lc));
+      double dsum = 0.0;
+      for (int k = 0; k < D1; ++k) dsum += std::fabs(a->Cmat[(size_t)k * D1 + k]);
+      if (!(dsum > 0.0) || !std::isfinite(dsum)) return fail(ctx, NLS_ERR_ARG, "complexity matrix has a zero or non-finite diagonal");
+      const double cscale = 1.0 / (dsum / D1) / (st.n_total * (double)D1);
+      std::vector<double2> hC((size_t)D1 * D1);
+      for (size_t k = 0; k < hC.size(); ++k) hC[k] = make_double2(a->Cmat[k] * cscale, 0.0);  // symmetric: row-major == column-major
+      HIPCHK(ctx, hipMemcpyAsync(Cn, hC.data(), sizeof(double2) * hC.size(), hipMemcpyHostToDevice, ctx->stream));
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      HIPCHK(ctx, hipMemcpyAsync(Lc, Cn, sizeof(double2) * (size_t)D1 * D1, hipMemcpyDeviceToDevice, ctx->stream));
+      BLASCHK(ctx, rocblas_set_stream(ctx->blas, ctx->stream));
+      BLASCHK(ctx, rocsolver_zpotrf(ctx->blas, rocblas_fill_lower, D1, reinterpret_cast<rocblas_double_complex*>(Lc), D1, dinfo));
+      NLSCHK(check_info(ctx, dinfo, "rocsolver_zpotrf(complexity matrix)"));
+      const rocblas_double_complex one(1.0, 0.0);
+      auto* zL = reinterpret_cast<const rocblas_double_complex*>(Lc);
+      auto* zA = reinterpret_cast<rocblas_double_complex*>(Qcm);
+      BLASCHK(ctx, rocblas_ztrsm(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, D1, D1,
+                                 &one, zL, D1, zA, D1));
+      BLASCHK(ctx, rocblas_ztrsm(ctx->blas, rocblas_side_right, rocblas_fill_lower, rocblas_operation_conjugate_transpose,
+                                 rocblas_diagonal_non_unit, D1, D1, &one, zL, D1, zA, D1));
+    }
     double2* Qev = nullptr;  // eigenvectors: in Qcm (rocSOLVER path) or in the EVD's own workspace
     NLSCHK(evd_hermitian(ctx, Qcm, D1, lam, evd_e, dinfo, &Qev, true));
+    if (general_C) {
+      const rocblas_double_complex one(1.0, 0.0);
+      BLASCHK(ctx, rocblas_ztrsm(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_conjugate_transpose,
+                                 rocblas_diagonal_non_unit, D1, D1, &one, reinterpret_cast<const rocblas_double_complex*>(Lc), D1,
+                                 reinterpret_cast<rocblas_double_complex*>(Qev), D1));
+    }
     NLSCHK(build_rot_planes(ctx, mp, Qev, 1L, (long)D1, false, rb));  // column-major Q
-    hipLaunchKernelGGL(k_compute_v, dim3((unsigned)Np), dim3(256), 0, ctx->stream, Qev, (long)D1, db, D1, 1.0 / st.c, rb.vr, rb.vi);
+    hipLaunchKernelGGL(k_compute_v, dim3((unsigned)Np), dim3(256), 0, ctx->stream, Qev, (long)D1, db, D1, inv_c, rb.vr, rb.vi);
     const long tot = (long)Np * Gp;
     hipLaunchKernelGGL(k_rgrid, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, lam, dgam, D1, G, Np, Gp, R);
     HIPCHK(ctx, hipGetLastError());
@@ -621,7 +685,7 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
     {
       SpanGuard g(ctx, NLS_T_SWEEP);
       hipLaunchKernelGGL(k_sweep, dim3((unsigned)(Gp / BN), (unsigned)(rows_pad / BM), 2), dim3(Cfg4::NTHREADS), SMEM_REAL, ctx->stream, U,
-                         Gm, Np, R, Gp, 1.0 / st.c, num, hs, r0);
+                         Gm, Np, R, Gp, inv_c, num, hs, r0);
       HIPCHK(ctx, hipGetLastError());
       tm[NLS_T_SWEEP_LAUNCHES] += 1;
       tm[NLS_T_SWEEP_FLOPS] += 4.0 * rows * (double)D1 * G;
@@ -662,6 +726,18 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
     }
   }
   const double gamma_opt = a->gammas[opt];
+  const bool finish = !(a->flags & NLS_FIT_SWEEP_ONLY) && !((a->flags & NLS_FIT_FINISH_IF_BELOW) && !(hobj[opt] < a->finish_below));
+  if (a->finished) *a->finished = finish ? 1 : 0;
+  if (!finish) {  // a non-winning sigma of a gamma x sigma grid: the error curve is all that is needed
+    NLSCHK(spans_collect(ctx, tm));
+    if (a->lam) HIPCHK(ctx, hipMemcpy(a->lam, lam, sizeof(double) * D1, hipMemcpyDeviceToHost));
+    if (a->loo_errors) std::memcpy(a->loo_errors, herrs.data(), sizeof(double) * G);
+    if (a->objective) std::memcpy(a->objective, hobj.data(), sizeof(double) * G);
+    if (a->gamma_index) *a->gamma_index = opt;
+    tm[NLS_T_TOTAL] = wall() - t_start;
+    if (a->timings) std::memcpy(a->timings, tm, sizeof(tm));
+    return NLS_OK;
+  }
 
   // ---- column of the selected gamma (P7 outputs, P9 sigma) -------------------------------------
   double *loo_res = nullptr, *loo_lev = nullptr, *loo_std = nullptr, *res = nullptr, *cpart = nullptr, *csum = nullptr;
@@ -695,7 +771,12 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
   NLSCHK(ws_get_t(ctx, "chol.bi", (size_t)Kf, &bi));
   {
     SpanGuard g(ctx, NLS_T_CHOLESKY);
-    hipLaunchKernelGGL(k_add_diag, dim3((unsigned)((D1 + 255) / 256)), dim3(256), 0, ctx->stream, Acm, (long)D1, D1, gamma_opt * st.c);
+    if (general_C) {  // gamma* C + A (_neo_ls_svm.py:177)
+      const long tot = (long)D1 * D1;
+      hipLaunchKernelGGL(k_axpy_z, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, Cn, gamma_opt, tot, Acm);
+    } else {
+      hipLaunchKernelGGL(k_add_diag, dim3((unsigned)((D1 + 255) / 256)), dim3(256), 0, ctx->stream, Acm, (long)D1, D1, gamma_opt * st.c);
+    }
     HIPCHK(ctx, hipGetLastError());
     BLASCHK(ctx, rocsolver_zpotrf(ctx->blas, rocblas_fill_lower, D1, reinterpret_cast<rocblas_double_complex*>(Acm), D1, dinfo));
     NLSCHK(check_info(ctx, dinfo, "rocsolver_zpotrf"));
@@ -762,12 +843,92 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
 // ------------------------------------------------------------------------------------------------
 // Primal inference (P10, P11)
 // ------------------------------------------------------------------------------------------------
+// W = phi U^-1, sigma^2 = sum_j |W_ij|^2.  The row-major upper U read as column-major is the lower triangular U^T;
+// ztrtri(lower) inverts it in place, which read back row-major is U^-1 (upper): the B operand of the rotation kernel.
+static int build_inverse_factor_planes(nls_ctx* ctx, const MapParams& mp, const double* L, const RotBuffers& rb) {
+  const int D1 = mp.D1;
+  double2* Urm = nullptr;
+  rocblas_int* dinfo = nullptr;
+  NLSCHK(ws_get_t(ctx, "evd.A", (size_t)D1 * D1, &Urm));
+  NLSCHK(ws_get_t(ctx, "evd.info", 4, &dinfo));
+  HIPCHK(ctx, hipMemcpyAsync(Urm, L, sizeof(double2) * (size_t)D1 * D1, is_device_ptr(L) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                             ctx->stream));
+  BLASCHK(ctx, rocblas_set_stream(ctx->blas, ctx->stream));
+  BLASCHK(ctx, rocsolver_ztrtri(ctx->blas, rocblas_fill_lower, rocblas_diagonal_non_unit, D1, reinterpret_cast<rocblas_double_complex*>(Urm),
+                                D1, dinfo));
+  NLSCHK(check_info(ctx, dinfo, "rocsolver_ztrtri"));
+  NLSCHK(build_rot_planes(ctx, mp, Urm, (long)D1, 1L, true, rb));
+  return NLS_OK;
+}
+
+static void map_sizes(int D, MapParams* mp) {
+  mp->D = D;
+  mp->D1 = D + 1;
+  mp->Kf = (int)round_up(D, BN);
+  mp->Np = (int)round_up(D + 1, m3::BN3);
+}
+
+extern "C" int nls_factor_create(nls_ctx* ctx, const double* L, int D, nls_factor** out) {
+  if (!ctx) return NLS_ERR_ARG;
+  if (!L || !out || D < 1) return fail(ctx, NLS_ERR_ARG, "nls_factor_create: L / factor NULL or D < 1");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  MapParams mp;
+  map_sizes(D, &mp);
+  nls_factor* f = new nls_factor();
+  f->owner = ctx;
+  f->D = D;
+  auto alloc = [&](double** p, size_t count) { return hipMalloc(reinterpret_cast<void**>(p), count * sizeof(double)); };
+  hipError_t e = alloc(&f->Mr, (size_t)mp.Kf * mp.Np);
+  if (e == hipSuccess) e = alloc(&f->Mi, (size_t)mp.Kf * mp.Np);
+  if (e == hipSuccess) e = alloc(&f->mbr, (size_t)mp.Np);
+  if (e == hipSuccess) e = alloc(&f->mbi, (size_t)mp.Np);
+  if (e == hipSuccess) e = alloc(&f->zero, (size_t)mp.Np);
+  if (e == hipSuccess) e = hipMemsetAsync(f->zero, 0, sizeof(double) * mp.Np, ctx->stream);
+  int rc = NLS_OK;
+  if (e != hipSuccess) {
+    rc = fail(ctx, NLS_ERR_HIP, "nls_factor_create: device allocation failed: %s", hipGetErrorString(e));
+  } else {
+    RotBuffers rb;
+    rb.Mr = f->Mr;
+    rb.Mi = f->Mi;
+    rb.mbr = f->mbr;
+    rb.mbi = f->mbi;
+    rc = build_inverse_factor_planes(ctx, mp, L, rb);
+    if (rc == NLS_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, NLS_ERR_HIP, "nls_factor_create: stream failed");
+  }
+  if (rc != NLS_OK) {
+    factor_free(f);
+    return rc;
+  }
+  ctx->factors.push_back(f);
+  *out = f;
+  return NLS_OK;
+}
+
+extern "C" int nls_factor_destroy(nls_ctx* ctx, nls_factor* f) {
+  if (!ctx) return NLS_ERR_ARG;
+  if (!f) return NLS_OK;
+  auto it = std::find(ctx->factors.begin(), ctx->factors.end(), f);
+  if (it == ctx->factors.end()) return fail(ctx, NLS_ERR_ARG, "nls_factor_destroy: not a live factor of this context");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->factors.erase(it);
+  factor_free(f);
+  return NLS_OK;
+}
+
 extern "C" int nls_primal_predict(nls_ctx* ctx, const double* X, int64_t m, int d, const double* shift, const double* scale,
-                                  const double* B, int D, const double* beta, const double* L, double* yhat, double* sigma) {
+                                  const double* B, int D, const double* beta, const double* L, const nls_factor* factor, double* yhat,
+                                  double* sigma) {
   if (!ctx) return NLS_ERR_ARG;
   if (!X || m < 0) return fail(ctx, NLS_ERR_ARG, "X NULL or m < 0");
   if (yhat && !beta) return fail(ctx, NLS_ERR_ARG, "beta is required for yhat");
-  if (sigma && !L) return fail(ctx, NLS_ERR_ARG, "L is required for sigma");
+  if (sigma && !L && !factor) return fail(ctx, NLS_ERR_ARG, "L or a factor handle is required for sigma");
+  if (sigma && factor) {
+    if (std::find(ctx->factors.begin(), ctx->factors.end(), factor) == ctx->factors.end())
+      return fail(ctx, NLS_ERR_ARG, "factor is not a live handle of this context");
+    if (factor->D != D) return fail(ctx, NLS_ERR_ARG, "factor was created for D = %d, called with D = %d", factor->D, D);
+  }
   HIPCHK(ctx, hipSetDevice(ctx->device));
   if (m == 0 || (!yhat && !sigma)) return NLS_OK;
   MapParams mp;
@@ -794,44 +955,19 @@ extern "C" int nls_primal_predict(nls_ctx* ctx, const double* X, int64_t m, int 
   RotBuffers rb;
   double *U = nullptr, *Gm = nullptr;
   if (sigma) {
-    // W = phi U^-1, sigma^2 = sum_j |W_ij|^2.  The row-major upper U read as column-major is the lower
-    // triangular U^T; ztrtri(lower) inverts it in place, which read back row-major is U^-1 (upper).
-    double2* Urm = nullptr;
-    rocblas_int* dinfo = nullptr;
     NLSCHK(ws_get_t(ctx, "chunk.U", (size_t)rc * Np, &U));
     NLSCHK(ws_get_t(ctx, "chunk.Gm", (size_t)rc * Np, &Gm));
-    // planes of U^-1 in buffers of their own, kept between calls (see nls_ctx::pred_L)
-    const size_t before = ctx->ws.count("pred.Mr") ? ctx->ws["pred.Mr"].bytes : 0;
-    NLSCHK(ws_get_t(ctx, "pred.Mr", (size_t)Kf * Np, &rb.Mr));
-    NLSCHK(ws_get_t(ctx, "pred.Mi", (size_t)Kf * Np, &rb.Mi));
-    NLSCHK(ws_get_t(ctx, "pred.mbr", (size_t)Np, &rb.mbr));
-    NLSCHK(ws_get_t(ctx, "pred.mbi", (size_t)Np, &rb.mbi));
-    NLSCHK(ws_get_t(ctx, "pred.vr", (size_t)Np, &rb.vr));
-    NLSCHK(ws_get_t(ctx, "pred.vi", (size_t)Np, &rb.vi));
-    double hash = 0.0;
-    const bool host_L = !is_device_ptr(L);
-    if (host_L)
-      for (long k = 0; k < D1; ++k) {
-        const double* row = L + 2 * k * (long)D1;
-        hash += (double)(k + 1) * row[2 * k] + 0.5 * row[2 * k + 1] + row[2 * ((k * 7919L) % D1)];
-      }
-    const bool cached = host_L && ctx->pred_L == L && ctx->pred_D1 == D1 && ctx->pred_hash == hash && before == ctx->ws["pred.Mr"].bytes && before > 0;
-    if (!cached) {
-      ctx->pred_L = nullptr;
-      NLSCHK(ws_get_t(ctx, "evd.A", (size_t)D1 * D1, &Urm));
-      NLSCHK(ws_get_t(ctx, "evd.info", 4, &dinfo));
-      HIPCHK(ctx, hipMemcpyAsync(Urm, L, sizeof(double2) * (size_t)D1 * D1, host_L ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, ctx->stream));
-      BLASCHK(ctx, rocsolver_ztrtri(ctx->blas, rocblas_fill_lower, rocblas_diagonal_non_unit, D1,
-                                    reinterpret_cast<rocblas_double_complex*>(Urm), D1, dinfo));
-      NLSCHK(check_info(ctx, dinfo, "rocsolver_ztrtri"));
-      NLSCHK(build_rot_planes(ctx, mp, Urm, (long)D1, 1L, true, rb));
+    if (factor) {
+      rb.Mr = factor->Mr;
+      rb.Mi = factor->Mi;
+      rb.mbr = factor->mbr;
+      rb.mbi = factor->mbi;
+      rb.vr = rb.vi = factor->zero;
+    } else {
+      NLSCHK(rot_buffers(ctx, mp, &rb));
+      NLSCHK(build_inverse_factor_planes(ctx, mp, L, rb));
       HIPCHK(ctx, hipMemsetAsync(rb.vr, 0, sizeof(double) * Np, ctx->stream));
       HIPCHK(ctx, hipMemsetAsync(rb.vi, 0, sizeof(double) * Np, ctx->stream));
-      if (host_L) {
-        ctx->pred_L = L;
-        ctx->pred_D1 = D1;
-        ctx->pred_hash = hash;
-      }
     }
   }
   for (long r0 = 0; r0 < m; r0 += rc) {

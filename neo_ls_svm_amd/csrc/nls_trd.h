@@ -16,7 +16,8 @@
 // is still being reduced.  The last step of zlatrd, w = w' - tau/2 (w'^H v) v, needs a global scalar and is applied
 // by the NEXT column's k_trd_column.  All reductions go through per-block partials summed in a fixed order: results
 // are bit-reproducible.  After nb = 32 columns the trailing matrix gets the rank-2nb update (rocBLAS her2k / syr2k).
-// Not done: LAPACK's rescaling loop for |beta| < safmin (the matrices of this path are O(1)).
+// LAPACK's rescaling loop for |beta| < safmin is replaced by the driver-level scaling of the whole matrix into
+// [sqrt(safmin / eps), sqrt(eps / safmin)] (evd_prescale in nls_evd.hip, as zheev / dsyev do).
 #pragma once
 #include <hip/hip_runtime.h>
 

@@ -1,31 +1,30 @@
-"""Row sharding over one process per GPU.
+"""Row sharding over one process per GPU, collectives by RCCL inside the HIP library (no PyTorch).
 
-The primal path shards by rows: every rank calls ``primal_fit`` on its own contiguous block
-of X, y, s and the library all-reduces, through the hook registered here, exactly four things:
+The primal path shards by rows: every rank calls ``primal_fit`` on its own contiguous block of
+X, y, s and the library exchanges, on its own stream, exactly four things:
 
-    1. {sum s, sum s*y, n}                 -> global weight normalisation and c = 1 / (n_total (D+1))
-    2. the tile-packed Hermitian block A||b -> identical normal equations (hence EVD, beta, L) on every rank
-    3. the eigenvector matrix Q             -> each rank back-transforms its own column block of the eigenvectors and
-                                               contributes zeros elsewhere: an exact all-gather (bit-identical Q)
-    4. the per-gamma error vectors          -> identical argmin on every rank
-    (+ the two scalars of the LOO score)
+    1. {sum s, sum s*y, n}                  all-reduce   global weight normalisation, c = 1 / (n_total (D+1))
+    2. the tile-packed Hermitian block A||b all-reduce   identical normal equations on every rank (139 MB at D = 4096)
+    3. the eigen-decomposition              rank 0 runs the tridiagonal eigensolver and broadcasts (lam, C); every rank
+                                            back-transforms its own column block of the eigenvectors; all-gather
+    4. the per-gamma error vectors          all-reduce   identical argmin everywhere (+ two score scalars)
 
-Per-row outputs (loo_residuals, loo_leverage, loo_std, residuals) stay sharded.  The collective itself is
-``torch.distributed`` - backend ``nccl`` is RCCL over xGMI on the GPU box (zero-copy on the library's device
-buffer), ``gloo`` is staged through host memory (CPU tests, or several ranks sharing one GPU).
+Per-row outputs (loo_residuals, loo_leverage, loo_std, residuals) stay sharded.
 
-IMPORTANT: import ``torch`` BEFORE the HIP library is loaded (i.e. before the first ``Context``), so that
-both use one copy of the ROCm runtime; ``attach`` checks this.
+Joining the ranks: rank 0 draws a communicator id (``Context.comm_unique_id``) and the others need its 128 bytes.
+``exchange_unique_id`` passes them through a file in a directory all ranks see (one node: ``/tmp``); the file name is
+keyed on the launcher's process id and the rendezvous port so concurrent or consecutive launches never meet.
+``init_from_env`` does the whole thing from the environment a launcher such as ``torch.distributed.run`` (or
+``bench.py``'s own spawner) sets: RANK, WORLD_SIZE, LOCAL_RANK, MASTER_PORT.
 """
 
 from __future__ import annotations
 
-import ctypes
-import sys
+import os
+import time
+from pathlib import Path
 
-import numpy as np
-
-__all__ = ["row_shard", "make_allreduce", "attach"]
+__all__ = ["row_shard", "exchange_unique_id", "init_from_env"]
 
 
 def row_shard(n: int, rank: int, world: int) -> tuple[int, int]:
@@ -35,47 +34,46 @@ def row_shard(n: int, rank: int, world: int) -> tuple[int, int]:
     return (n * rank) // world, (n * (rank + 1)) // world
 
 
-class _DeviceView:
-    """Zero-copy view of ``count`` doubles at a raw device address for ``torch.as_tensor``."""
-
-    def __init__(self, ptr: int, count: int):
-        self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr, False), "version": 2}
-
-
-def make_allreduce(ctx, dist=None, group=None):
-    """Return ``fn(device_ptr, count)`` that sums ``count`` doubles over the ranks of ``group`` in place."""
-    import torch
-
-    dist = dist or torch.distributed
-    backend = dist.get_backend(group)
-
-    if backend == "nccl":
-        device = torch.device("cuda", ctx.device)
-
-        def fn(ptr: int, count: int) -> None:
-            t = torch.as_tensor(_DeviceView(ptr, count), device=device)
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-            torch.cuda.synchronize(device)
-
-        return fn
-
-    def fn_staged(ptr: int, count: int) -> None:
-        host = np.empty(count, dtype=np.float64)
-        ctx._check(ctx.lib.nls_memcpy_d2h(ctx.handle, host.ctypes.data, ctypes.c_void_p(ptr), host.nbytes))
-        t = torch.from_numpy(host)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-        ctx._check(ctx.lib.nls_memcpy_h2d(ctx.handle, ctypes.c_void_p(ptr), host.ctypes.data, host.nbytes))
-
-    return fn_staged
+def _rendezvous_file(key: str | None) -> Path:
+    if key is None:
+        # all ranks of one launch are children of one launcher process; the port separates launches of one parent
+        key = f"{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}"
+    base = Path(os.environ.get("NLS_RENDEZVOUS_DIR", "/tmp"))
+    return base / f"nls_rccl_id_{key}"
 
 
-def attach(ctx, dist=None, group=None) -> tuple[int, int]:
-    """Register the collective hook on ``ctx`` for the initialised process group; returns (rank, world)."""
-    if "torch" not in sys.modules:
-        raise RuntimeError("import torch (and init the process group) before creating the neo_ls_svm_amd Context")
-    import torch
+def exchange_unique_id(ctx, rank: int, world: int, key: str | None = None, timeout: float = 300.0) -> bytes:
+    """Rank 0 creates the communicator id and publishes it (atomic rename); the other ranks wait for the file."""
+    path = _rendezvous_file(key)
+    if rank == 0:
+        uid = ctx.comm_unique_id()
+        tmp = path.with_suffix(f".tmp{os.getpid()}")
+        tmp.write_bytes(uid)
+        os.replace(tmp, path)
+        return uid
+    t0 = time.monotonic()
+    while True:
+        try:
+            uid = path.read_bytes()
+            if len(uid) == 128:
+                return uid
+        except FileNotFoundError:
+            pass
+        if time.monotonic() - t0 > timeout:
+            raise TimeoutError(f"rank {rank}: no communicator id at {path} after {timeout:.0f} s")
+        time.sleep(0.02)
 
-    dist = dist or torch.distributed
-    rank, world = dist.get_rank(group), dist.get_world_size(group)
-    ctx.set_allreduce(make_allreduce(ctx, dist, group) if world > 1 else None, rank, world)
+
+def init_from_env(ctx, key: str | None = None) -> tuple[int, int]:
+    """Join ``ctx`` to the RCCL communicator of the launch described by RANK / WORLD_SIZE; returns (rank, world).
+    World size 1 also goes through RCCL (a one-rank communicator), so the collective code path is the one that runs."""
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    uid = exchange_unique_id(ctx, rank, world, key)
+    ctx.comm_init(uid, rank, world)
+    ctx.comm_barrier()
+    if rank == 0:  # everyone has read the id once the barrier returns
+        try:
+            _rendezvous_file(key).unlink()
+        except OSError:
+            pass
     return rank, world

@@ -42,9 +42,11 @@ class AffineSeparator(BaseEstimator):
         self.random_state = random_state
         self.device = device
 
-    def fit(self, X, y, sample_weight=None):
+    def fit(self, X, y, sample_weight=None, ctx=None):
+        """``ctx``: the context (hence GPU) that runs the bin statistics; default: the context of ``self.device``.
+        ``NeoLSSVM.fit`` hands its own context down so that X is uploaded once, to the estimator's device."""
         X, y = check_X_y(X, y, dtype=np.float64)
-        ctx = default_context(int(self.device))
+        ctx = ctx or default_context(int(self.device))
 
         def normalizer(Xa, ya, swa):  # per-bin weighted medians / deviations on the GPU (nls_bin_stats)
             return _prestep.fit_affine_normalizer(Xa, ya, swa, stats=lambda A, lab, w: hotpath.bin_stats(A, lab, w, ctx=ctx))
@@ -76,14 +78,18 @@ class OrthogonalRandomFourierFeatures(BaseEstimator):
     map on the GPU (``nls_featuremap``).
     """
 
-    def __init__(self, affine_feature_map=None, num_features=512, random_state=42):
+    def __init__(self, affine_feature_map=None, num_features=512, random_state=42, exact_complexity=False):
         self.affine_feature_map = affine_feature_map
         self.num_features = num_features
         self.random_state = random_state
+        self.exact_complexity = exact_complexity
 
-    def fit(self, X, y=None, sample_weight=None):
+    def fit(self, X, y=None, sample_weight=None, ctx=None):
         self.affine_feature_map_ = clone(self.affine_feature_map) if self.affine_feature_map is not None else AffineSeparator()
-        self.affine_feature_map_.fit(X, y, sample_weight)
+        if isinstance(self.affine_feature_map_, AffineSeparator):
+            self.affine_feature_map_.fit(X, y, sample_weight, ctx=ctx)
+        else:
+            self.affine_feature_map_.fit(X, y, sample_weight)
         A = self.affine_feature_map_.A_
         d_in = A.shape[1] if A is not None else np.asarray(X).shape[1]
         self.Z_ = hotpath.orf_frequencies(d_in, self.num_features, self.random_state)
@@ -97,7 +103,11 @@ class OrthogonalRandomFourierFeatures(BaseEstimator):
 
     @property
     def complexity_matrix(self):
-        """Identity: the reference's fast diagonal approximation (``_feature_maps.py:129-135``)."""
+        """Identity - the reference's fast diagonal approximation, the only one it reaches (``_feature_maps.py:129-135``) -
+        or, with ``exact_complexity=True``, the exact matrix of ``_ztz_prod_sinc_zmz``'s slow branch (``:46-55``), which
+        sends the solver down the generalised-EVD branch (``_neo_ls_svm.py:122-124``)."""
+        if self.exact_complexity:
+            return hotpath.exact_complexity_matrix(self.Z_)
         return np.eye(self.num_features + 1)
 
     def transform(self, X, ctx=None):
@@ -127,6 +137,7 @@ class NeoLSSVM(BaseEstimator):
         estimator_type="auto",
         random_state=42,
         device=0,
+        release_workspace=True,
     ):
         self.primal_feature_map = primal_feature_map
         self.dual_feature_map = dual_feature_map
@@ -134,6 +145,7 @@ class NeoLSSVM(BaseEstimator):
         self.random_state = random_state
         self.estimator_type = estimator_type
         self.device = device
+        self.release_workspace = release_workspace
 
     # ---- sklearn plumbing -------------------------------------------------------------------
     def __sklearn_tags__(self):
@@ -154,6 +166,26 @@ class NeoLSSVM(BaseEstimator):
 
     def _ctx(self):
         return default_context(int(self.device))
+
+    # The inverse Cholesky factor predict_std needs lives on the device between calls as an explicit handle owned by
+    # this estimator: created on the first predict_std after a fit, dropped on refit, never pickled.
+    def _drop_factor(self):
+        f = self.__dict__.pop("_factor", None)
+        if f is not None:
+            f.close()
+
+    def _factor_for(self, ctx):
+        f = self.__dict__.get("_factor")
+        if f is None or f.ctx is not ctx or not f.handle:
+            self._drop_factor()
+            f = self.__dict__["_factor"] = hotpath.Factor(ctx, self.L_[0])
+        return f
+
+    def __getstate__(self):
+        state = super().__getstate__() if hasattr(super(), "__getstate__") else self.__dict__.copy()
+        state = dict(state)
+        state.pop("_factor", None)
+        return state
 
     # ---- fit --------------------------------------------------------------------------------
     def fit(self, X, y, sample_weight=None):
@@ -182,6 +214,7 @@ class NeoLSSVM(BaseEstimator):
         else:
             raise ValueError("Target type not supported")
         is_clf = self._estimator_type == "classifier"
+        self._drop_factor()  # the device copy of a previous fit's inverse factor
         self.dual_ = bool(X.shape[0] <= 1024 if self.dual == "auto" else self.dual)  # noqa: PLR2004
         self.primal_ = not self.dual_
         ctx = self._ctx()
@@ -192,9 +225,10 @@ class NeoLSSVM(BaseEstimator):
                     num_features=int(getattr(fm, "num_features", 512)), random_state=getattr(fm, "random_state", 42)
                 )
             with ctx.hold(X):  # one upload of X serves the pre-step's bin statistics and the solver
-                self.primal_feature_map_ = clone(fm).fit(X, y_, sw)
+                self.primal_feature_map_ = clone(fm).fit(X, y_, sw, ctx=ctx)
                 shift, scale, B = self.primal_feature_map_.map_params
-                r = hotpath.primal_fit(X, y_, sw, shift, scale, B, is_clf, ctx=ctx)
+                Cm = self.primal_feature_map_.complexity_matrix if self.primal_feature_map_.exact_complexity else None
+                r = hotpath.primal_fit(X, y_, sw, shift, scale, B, is_clf, ctx=ctx, complexity_matrix=Cm)
             self.β̂_, self.γ_ = r["beta"], r["gamma"]
             self.loo_leverage_ = r["loo_leverage"]
         else:
@@ -203,7 +237,7 @@ class NeoLSSVM(BaseEstimator):
             sep = AffineSeparator() if isinstance(self.dual_feature_map, str) else self.dual_feature_map
             if not isinstance(sep, AffineSeparator):
                 sep = AffineSeparator()
-            self.dual_feature_map_ = clone(sep).fit(X, y_, sw)
+            self.dual_feature_map_ = clone(sep).fit(X, y_, sw, ctx=ctx)
             self.X_ = np.ascontiguousarray(self.dual_feature_map_.transform(X))
             r = hotpath.dual_fit(self.X_, y_, sw, is_clf, ctx=ctx)
             self.α̂_, self.γ_ = r["alpha"], r["gamma"]
@@ -218,6 +252,10 @@ class NeoLSSVM(BaseEstimator):
         self.residuals_ = r["residuals"]
         self.loo_std_ = r["loo_std"]
         self.fit_timings_ = r["timings"]
+        # The context's workspace only grows between calls; give the large fit-only buffers (feature planes, sweep
+        # tables: ~100 GB after a c3-size fit) back so that other users of the GPU in this process are not starved.
+        if self.release_workspace:
+            ctx.release_workspace(min_bytes=256 << 20)
         # Isotonic probability calibration on the LOO predictions (:406-412).
         if is_clf:
             self.predict_proba_calibrator_ = IsotonicRegression(out_of_bounds="clip", y_min=0, y_max=1, increasing=True)
@@ -284,7 +322,8 @@ class NeoLSSVM(BaseEstimator):
         Xa = self._check_X(X)
         if self.primal_:
             shift, scale, B = self.primal_feature_map_.map_params
-            _, sigma = hotpath.primal_predict(Xa, shift, scale, B, L=self.L_[0], ctx=self._ctx())
+            ctx = self._ctx()
+            _, sigma = hotpath.primal_predict(Xa, shift, scale, B, ctx=ctx, factor=self._factor_for(ctx))
         else:
             Xq = np.ascontiguousarray(self.dual_feature_map_.transform(Xa))
             _, sigma = hotpath.dual_predict(Xq, self.X_, L=self.L_[0], ctx=self._ctx())
@@ -294,7 +333,8 @@ class NeoLSSVM(BaseEstimator):
         """decision_function and predict_std from ONE pass over X (one feature-map evaluation)."""
         if self.primal_:
             shift, scale, B = self.primal_feature_map_.map_params
-            return hotpath.primal_predict(Xa, shift, scale, B, beta=self.β̂_, L=self.L_[0], ctx=self._ctx())
+            ctx = self._ctx()
+            return hotpath.primal_predict(Xa, shift, scale, B, beta=self.β̂_, ctx=ctx, factor=self._factor_for(ctx))
         Xq = np.ascontiguousarray(self.dual_feature_map_.transform(Xa))
         return hotpath.dual_predict(Xq, self.X_, alpha=self.α̂_, L=self.L_[0], ctx=self._ctx())
 

@@ -16,11 +16,12 @@ import numpy as np
 from threadpoolctl import threadpool_limits
 
 from . import _lib
-from ._lib import Context, DeviceArray, DualFitArgs, PrimalFitArgs, default_context
+from ._lib import Context, DeviceArray, DualFitArgs, Factor, PrimalFitArgs, default_context
 
 __all__ = [
     "gamma_grid",
     "orf_frequencies",
+    "exact_complexity_matrix",
     "featuremap",
     "gram",
     "rotate",
@@ -58,6 +59,26 @@ def orf_frequencies(d: int, D: int, random_state=42) -> np.ndarray:
             Z[:, j : j + block.shape[1]] = q[:, : block.shape[1]]
     Z *= np.sqrt(gen.chisquare(d, size=(1, D)))
     return Z
+
+
+def exact_complexity_matrix(Z) -> np.ndarray:
+    """The exact complexity matrix of a random-Fourier map with frequencies Z (d' x D): the slow branch of
+    ``_ztz_prod_sinc_zmz`` (``_feature_maps.py:40-55``) embedded as ``complexity_matrix`` does (``:129-135``):
+    C[:D, :D] = (Z'Z o prod_k sinc(Z_ki - Z_kj)) / d' (plain sin(x)/x, 1 where |x| <= eps), C[D, D] = 1.
+    The reference never reaches it (``fast_approx=True`` is hard-wired); passing it to ``primal_fit`` as
+    ``complexity_matrix`` runs the generalised-EVD branch (``_neo_ls_svm.py:122-124``).  Host NumPy, O(d' D^2)."""
+    Z = np.asarray(Z, dtype=np.float64)
+    dp, D = Z.shape
+    Cm = Z.T @ Z
+    eps = np.finfo(np.float64).eps
+    for k in range(dp):
+        dz = Z[k][:, None] - Z[k][None, :]
+        with np.errstate(invalid="ignore", divide="ignore"):
+            Cm *= np.where(np.abs(dz) > eps, np.sin(dz) / dz, 1.0)
+    Cm = (np.tril(Cm) + np.tril(Cm, -1).T) / dp
+    out = np.eye(D + 1)
+    out[:D, :D] = Cm
+    return out
 
 
 def _f64(a, name, shape=None):
@@ -209,6 +230,9 @@ def primal_fit(
     ctx: Context | None = None,
     want_L: bool = True,
     want_rows: bool = True,
+    sweep_only: bool = False,
+    finish_below: float | None = None,
+    complexity_matrix=None,
 ) -> dict:
     """Primal LS-SVM fit with the full gamma sweep (P1-P9).
 
@@ -216,6 +240,11 @@ def primal_fit(
     a dict with the reference's attribute names (ASCII): beta, gamma, gammas, opt, loo_errors_gammas,
     loo_residuals, loo_yhat (host input y only), loo_leverage, loo_error, loo_score, L (scipy ``cho_factor``
     format, lower=False), residuals, loo_std, lam, timings.
+
+    ``sweep_only`` stops after the gamma selection (P1-P7); ``finish_below=t`` runs the Cholesky re-solve and the row
+    outputs only when the selected objective is below t (``out["finished"]`` says which) - how a gamma x sigma grid
+    avoids finishing sigmas that cannot win.  ``complexity_matrix``: None = identity (the reference's only reachable
+    case), else a (D+1) x (D+1) symmetric positive definite matrix -> generalised-EVD branch (``_neo_ls_svm.py:122-124``).
     """
     ctx = ctx or default_context()
     X = _f64(ctx.held(X), "X")
@@ -248,6 +277,16 @@ def primal_fit(
     a.n, a.d, a.D, a.G = n, d, D, G
     a.is_classifier = 1 if is_classifier else 0
     a.gamma_index_in = -1 if gamma_index is None else int(gamma_index)
+    a.flags = (_lib.FIT_SWEEP_ONLY if sweep_only else 0) | (_lib.FIT_FINISH_IF_BELOW if finish_below is not None else 0)
+    a.finish_below = float(finish_below) if finish_below is not None else 0.0
+    Cm = None
+    if complexity_matrix is not None:
+        Cm = np.ascontiguousarray(complexity_matrix, dtype=np.float64)
+        if Cm.shape != (D1, D1) or not np.allclose(Cm, Cm.T, rtol=1e-12, atol=0):
+            raise ValueError(f"complexity_matrix must be a symmetric ({D1}, {D1}) matrix")
+        a.Cmat = Cm.ctypes.data
+    finished = C.c_int32(1)
+    a.finished = C.addressof(finished)
     a.beta, a.lam = out["beta"].ctypes.data, out["lam"].ctypes.data
     a.L = out["L"].ctypes.data if want_L else None
     a.loo_errors, a.objective = out["loo_errors_gammas"].ctypes.data, out["objective"].ctypes.data
@@ -262,11 +301,16 @@ def primal_fit(
     out["opt"] = int(opt.value)
     out["gamma"] = float(gammas[opt.value])
     out["loo_error"] = float(out["loo_errors_gammas"][opt.value])
+    out["finished"] = bool(finished.value)
+    out["timings"] = timings_dict(tm)
+    if not out["finished"]:  # the curve only: drop the buffers P8 / P9 would have filled
+        for k in ("beta", "L", "loo_residuals", "loo_leverage", "loo_std", "residuals"):
+            out.pop(k, None)
+        return out
     out["loo_score"] = float(score.value)
     out["L_lower"] = False
     if want_rows and not isinstance(y, DeviceArray):
         out["loo_yhat"] = y + out["loo_residuals"]
-    out["timings"] = timings_dict(tm)
     return out
 
 
@@ -283,42 +327,47 @@ def primal_fit_sigma_grid(
     ctx: Context | None = None,
     rank: int = 0,
     world: int = 1,
-    allgather=None,
+    allreduce_sum=None,
 ) -> dict:
     """gamma x sigma leave-one-out grid (BASELINE config 5).
 
     The reference fixes the kernel bandwidth in closed form (``_affine_separator.py:200-209``); this driver extends the
     search with multipliers sigma_k that divide B (T / sigma_k).  For every sigma one ``primal_fit`` runs P2-P7 on the
     gamma grid - ONE eigendecomposition per sigma is the factorisation all gammas reuse - and the (sigma, gamma) pair
-    with the smallest selection objective wins; that fit's full result is returned under ``"best"``.
+    with the smallest selection objective wins.  Only a sigma that beats the incumbent runs P8 / P9 (Cholesky re-solve,
+    residuals, download of L); the winner's full result is returned under ``"best"`` (on the rank that owns it).
 
     Default gammas: the 32-point grid ``gamma_grid(1024)[::33]`` (exactly a sub-grid of the reference's 1024 points).
     Multi-GPU: sigmas are dealt round-robin over ``world`` ranks, every rank holding all rows (no collective in the
-    data path); ``allgather(obj) -> list`` (e.g. ``torch.distributed.all_gather_object``) merges the small tables.
+    data path); ``allreduce_sum(array) -> array`` (e.g. ``Context.comm_allreduce`` on a communicator context) merges the
+    small tables - every sigma is owned by one rank, the others contribute zeros.
     """
     sigmas = np.asarray(sigmas, dtype=np.float64)
     gammas = gamma_grid(1024)[::33] if gammas is None else np.ascontiguousarray(gammas, dtype=np.float64)
     B = np.ascontiguousarray(B, dtype=np.float64)
-    mine = list(range(rank, sigmas.size, world))
-    rows = {}
+    S, G = sigmas.size, gammas.size
+    table, objective, seconds = np.zeros((S, G)), np.zeros((S, G)), np.zeros(S)
+    timings: dict = {}
     best = None
-    for k in mine:
-        r = primal_fit(X, y, s, shift, scale, B / sigmas[k], is_classifier, gammas=gammas, ctx=ctx)
-        rows[k] = (r["loo_errors_gammas"], r["objective"], r["timings"]["total"])
+    for k in range(rank, S, world):
+        r = primal_fit(X, y, s, shift, scale, B / sigmas[k], is_classifier, gammas=gammas, ctx=ctx,
+                       finish_below=None if best is None else best[0])  # fmt: skip
+        table[k], objective[k], seconds[k] = r["loo_errors_gammas"], r["objective"], r["timings"]["total"]
+        for name, v in r["timings"].items():
+            timings[name] = timings.get(name, 0.0) + v
         score = r["objective"][r["opt"]]
-        if best is None or score < best[0]:
+        if r["finished"] and (best is None or score < best[0]):
             best = (score, k, r)
-    parts = allgather((rows, None if best is None else (best[0], best[1]))) if (allgather and world > 1) else [(rows, best and best[:2])]
-    table = np.full((sigmas.size, gammas.size), np.nan)
-    objective = np.full((sigmas.size, gammas.size), np.nan)
-    seconds = np.zeros(sigmas.size)
-    winner = None
-    for prt_rows, prt_best in parts:
-        for k, (errs, obj, sec) in prt_rows.items():
-            table[k], objective[k], seconds[k] = errs, obj, sec
-        if prt_best is not None and (winner is None or prt_best[0] < winner[0] or (prt_best[0] == winner[0] and prt_best[1] < winner[1])):
-            winner = tuple(prt_best)
-    k_opt = int(winner[1])
+    if allreduce_sum is not None and world > 1:
+        merged = allreduce_sum(np.concatenate([table.ravel(), objective.ravel(), seconds]))
+        table, objective, seconds = merged[: S * G].reshape(S, G), merged[S * G : 2 * S * G].reshape(S, G), merged[2 * S * G :]
+        owned = np.ones(S, dtype=bool)
+    else:
+        owned = np.zeros(S, dtype=bool)
+        owned[rank::world] = True
+        table[~owned], objective[~owned] = np.nan, np.nan
+    col_min = np.where(owned, np.nanmin(np.where(owned[:, None], objective, np.inf), axis=1), np.inf)
+    k_opt = int(np.argmin(col_min))  # first minimum: ties go to the smaller sigma index
     g_opt = int(np.argmin(objective[k_opt]))
     return {
         "sigmas": sigmas,
@@ -330,14 +379,16 @@ def primal_fit_sigma_grid(
         "sigma": float(sigmas[k_opt]),
         "gamma": float(gammas[g_opt]),
         "seconds_per_sigma": seconds,
+        "timings": timings,
         "best": best[2] if (best is not None and best[1] == k_opt) else None,
     }
 
 
-def primal_predict(X, shift, scale, B, beta=None, L=None, ctx: Context | None = None):
+def primal_predict(X, shift, scale, B, beta=None, L=None, ctx: Context | None = None, factor: Factor | None = None):
     """(yhat, sigma): ``decision_function`` ``_neo_ls_svm.py:661-665`` and ``predict_std`` ``:464-469,477``.
 
-    Pass ``beta`` for yhat and/or ``L`` (upper factor as returned by ``primal_fit``) for sigma.
+    Pass ``beta`` for yhat and/or, for sigma, ``L`` (upper factor as returned by ``primal_fit``; uploaded and inverted on
+    every call) or ``factor`` (``Factor(ctx, L)``: the inverse kept on the device across calls).
     """
     ctx = ctx or default_context()
     X = _f64(X, "X")
@@ -350,7 +401,12 @@ def primal_predict(X, shift, scale, B, beta=None, L=None, ctx: Context | None = 
         if beta.shape != (D + 1,):
             raise ValueError(f"beta must have shape ({D + 1},)")
         yhat = np.empty(m)
-    if L is not None:
+    if factor is not None:
+        if factor.ctx is not ctx or factor.D != D or not factor.handle:
+            raise ValueError("factor belongs to another context / feature count, or is closed")
+        L = None
+        sigma = np.empty(m)
+    elif L is not None:
         L = np.ascontiguousarray(L, dtype=np.complex128)
         if L.shape != (D + 1, D + 1):
             raise ValueError(f"L must have shape ({D + 1}, {D + 1})")
@@ -358,7 +414,7 @@ def primal_predict(X, shift, scale, B, beta=None, L=None, ctx: Context | None = 
     ctx._check(
         ctx.lib.nls_primal_predict(
             ctx.handle, _lib._ptr(X), m, d, shift.ctypes.data, scale.ctypes.data, B.ctypes.data, D,
-            _lib._ptr(beta), _lib._ptr(L), _lib._ptr(yhat), _lib._ptr(sigma),
+            _lib._ptr(beta), _lib._ptr(L), factor.handle if factor is not None else None, _lib._ptr(yhat), _lib._ptr(sigma),
         )
     )  # fmt: skip
     return yhat, sigma

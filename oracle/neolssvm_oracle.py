@@ -35,6 +35,7 @@ __all__ = [
     "fold_projection",
     "affine_project",
     "feature_map",
+    "exact_complexity_matrix",
     "primal_gram",
     "primal_fit_faithful",
     "primal_fit_streamed",
@@ -164,23 +165,54 @@ def primal_gram(phi: np.ndarray, y: np.ndarray, s: np.ndarray):
     return A, b, sn
 
 
-def primal_fit_faithful(phi: np.ndarray, y: np.ndarray, s: np.ndarray, is_clf: bool, gammas=None) -> dict:
-    """The reference's own schedule of ``_optimize_beta_gamma`` for C = I.
+def exact_complexity_matrix(Z: np.ndarray) -> np.ndarray:
+    """The exact complexity matrix: the slow branch of ``_ztz_prod_sinc_zmz`` (``_feature_maps.py:46-55``,
+    ``fast_approx=False``) embedded the way ``complexity_matrix`` embeds it (``:131-134``: identity of size D + 1 with
+    the D x D block replaced).  C_ij = (1/d) (Z'Z)_ij prod_k sin(Z_ki - Z_kj) / (Z_ki - Z_kj), factors with
+    |Z_ki - Z_kj| <= eps skipped; only the lower triangle is multiplied and then mirrored (``:54``)."""
+    dp, D = Z.shape
+    Cm = Z.T @ Z
+    eps = np.finfo(Z.dtype).eps
+    il = np.tril_indices(D, -1)
+    for k in range(dp):
+        dz = Z[k, il[0]] - Z[k, il[1]]
+        f = np.ones_like(dz)
+        m = np.abs(dz) > eps
+        f[m] = np.sin(dz[m]) / dz[m]
+        Cm[il] *= f
+    Cm = (np.tril(Cm) + np.tril(Cm, -1).T) / dp
+    out = np.eye(D + 1, dtype=Z.dtype)
+    out[:-1, :-1] = Cm
+    return out
 
-    ``_neo_ls_svm.py:110-187``.  C = I_{D+1} is what ``complexity_matrix`` returns for RFF/ORF
-    (``_feature_maps.py:133-134``), so only the diagonal-C branch (``:119-121``) is restated; its
-    normalised diagonal is the scalar c = 1 / phi.size (``:117-118``).
+
+def primal_fit_faithful(phi: np.ndarray, y: np.ndarray, s: np.ndarray, is_clf: bool, gammas=None, C=None) -> dict:
+    """The reference's own schedule of ``_optimize_beta_gamma``.
+
+    ``_neo_ls_svm.py:110-187``.  C = None stands for I_{D+1}, what ``complexity_matrix`` returns for RFF/ORF
+    (``_feature_maps.py:133-134``): the diagonal-C branch (``:119-121``) with the normalised diagonal
+    c = 1 / phi.size (``:117-118``).  A non-diagonal C takes the generalised branch (``:122-124,131,139``):
+    ``eigh(a=A, b=C)`` and an LU solve with C Q (the branch is unreachable upstream).
     """
     n, D1 = phi.shape
     gammas = gamma_grid(1024, y.dtype) if gammas is None else np.asarray(gammas, dtype=np.float64)
     A, b, sn = primal_gram(phi, y, s)
     F = sn[:, None] * phi
     c = 1.0 / phi.size
-    lam, Q = sla.eigh(A / c)  # :120
-    QHc = Q.conj().T / c  # :121
-    modes = Q * (QHc @ b)[None, :]  # :128-129  beta as a function of gamma is modes @ r(gamma)
+    if C is None:
+        Cn = c * np.eye(D1)
+        lam, Q = sla.eigh(A / c)  # :120
+        QHc = Q.conj().T / c  # :121
+        modes = Q * (QHc @ b)[None, :]  # :128-129  beta as a function of gamma is modes @ r(gamma)
+        h = np.ascontiguousarray(np.real((F @ Q) * (QHc @ F.conj().T).T))  # :136-137,143
+    else:
+        cd = np.diag(C)
+        Cn = C / np.mean(np.abs(cd)) / phi.size  # :117
+        lam, Q = sla.eigh(a=A, b=Cn)  # :123
+        lu = sla.lu_factor(Cn @ Q)  # :124
+        modes = Q * sla.lu_solve(lu, b)[None, :]  # :131
+        h = np.ascontiguousarray(np.real((F @ Q) * sla.lu_solve(lu, F.conj().T).T))  # :139
     phib = np.ascontiguousarray(np.real(phi @ modes))  # :134,142
-    h = np.ascontiguousarray(np.real((F @ Q) * (QHc @ F.conj().T).T))  # :136-137,143
     r = 1.0 / (gammas[None, :] + lam[:, None])  # :147
     with np.errstate(divide="ignore", invalid="ignore"):
         e = (phib @ r - y[:, None]) / (1 - h @ r)  # :149
@@ -203,7 +235,7 @@ def primal_fit_faithful(phi: np.ndarray, y: np.ndarray, s: np.ndarray, is_clf: b
         "loo_error": float(errs[opt]),
         "loo_score": weighted_scores(y, yloo[:, opt], sn, is_clf),
     }
-    M = gammas[opt] * c * np.eye(D1) + A  # :177 (C normalised to c I)
+    M = gammas[opt] * Cn + A  # :177 (C normalised: c I for the identity)
     L = sla.cho_factor(M)
     beta = sla.cho_solve(L, b)  # :178
     res = np.real(phi @ beta) - y  # :179

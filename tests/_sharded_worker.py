@@ -1,8 +1,10 @@
 """Worker of the world_size-2 tests (launched by the test files with RANK / WORLD_SIZE / MASTER_* set).
 
-mode "cpu": no GPU.  Exercises the product's row_shard + staged all-reduce hook over gloo, and replays the
-            library's three exchange points with the oracle standing in for the HIP stages (test infrastructure).
-mode "gpu": both ranks share GPU 0; the real library runs its sharded path, collectives over gloo.
+mode "cpu": no GPU.  Exercises the product's row_shard and a staged all-reduce over gloo, and replays the
+            library's exchange points with the oracle standing in for the HIP stages (test infrastructure).
+mode "gpu": both ranks share GPU 0 (RCCL refuses two ranks on one device, so the collectives go through the library's
+            caller-supplied all-reduce hook, staged over gloo); the real library runs its sharded path.
+torch is test infrastructure here (gloo rendezvous); the product itself is torch-free.
 Prints "OK <rank>" on success.
 """
 
@@ -16,7 +18,7 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 sys.path[:0] = [str(ROOT), str(ROOT / "oracle"), str(ROOT / "tests")]
 
-import torch  # noqa: E402  (must precede the HIP library)
+import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 import numpy as np  # noqa: E402
@@ -44,6 +46,19 @@ class FakeCtx:
         assert rc == 0
 
 
+def make_allreduce(ctx):
+    """fn(device_ptr, count): sum over the gloo ranks, staged through host memory (nls_memcpy_d2h / h2d)."""
+
+    def fn(ptr: int, count: int) -> None:
+        host = np.empty(count, dtype=np.float64)
+        ctx._check(ctx.lib.nls_memcpy_d2h(ctx.handle, host.ctypes.data, ctypes.c_void_p(ptr), host.nbytes))
+        t = torch.from_numpy(host)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        ctx._check(ctx.lib.nls_memcpy_h2d(ctx.handle, ctypes.c_void_p(ptr), host.ctypes.data, host.nbytes))
+
+    return fn
+
+
 def problem(n=1800, d=9, D=64, clf=False):
     rng = np.random.default_rng(123)
     X = rng.standard_normal((n, d))
@@ -59,9 +74,9 @@ def problem(n=1800, d=9, D=64, clf=False):
 def run_cpu(rank, world):
     import neolssvm_oracle as orc
 
-    from neo_ls_svm_amd.distributed import make_allreduce, row_shard
+    from neo_ls_svm_amd.distributed import row_shard
 
-    hook = make_allreduce(FakeCtx(), dist)
+    hook = make_allreduce(FakeCtx())
 
     def allreduce(a):  # in place on a float64 (or complex128 viewed as float64) host array
         v = a.view(np.float64).reshape(-1)
@@ -116,10 +131,10 @@ def run_cpu(rank, world):
 
 def run_gpu(rank, world):
     import neo_ls_svm_amd as hp
-    from neo_ls_svm_amd.distributed import attach, row_shard
+    from neo_ls_svm_amd.distributed import row_shard
 
     ctx = hp.Context(0)
-    attach(ctx, dist)
+    ctx.set_allreduce(make_allreduce(ctx), rank, world)
     for clf in (False, True):
         X, y, s, shift, scale, B = problem(n=5000, d=12, D=200, clf=clf)
         lo, hi = row_shard(X.shape[0], rank, world)

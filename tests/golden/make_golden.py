@@ -178,6 +178,99 @@ def dual_case(name, n, d, task, wkind, seed, nq=129):
     print(name, "gamma", m.γ_, "opt", out["opt"], "loo_score", m.loo_score_, "r", m.X_.shape)
 
 
+def ames_like(n=2930, seed=8):
+    """An ames_housing-shaped table (BASELINE config 1; the real one needs ``fetch_openml``): ~40 numeric columns of
+    mixed scale (areas, years, counts, skewed and zero-inflated ones), ~260 one-hot columns from 43 categoricals with
+    unbalanced levels (some rare enough to be all-zero in a class bin), one constant column; log-price-like target."""
+    rng = np.random.default_rng(seed)
+    z = rng.standard_normal((n, 6))  # latent factors
+    num = []
+    for j in range(40):
+        load = rng.standard_normal(6) * (rng.random(6) < 0.5)
+        v = z @ load + rng.standard_normal(n)
+        kind = j % 5
+        if kind == 0:
+            v = np.exp(0.5 * v) * 1500.0  # areas
+        elif kind == 1:
+            v = np.round(1970 + 20 * v)  # years
+        elif kind == 2:
+            v = np.clip(np.round(2 + v), 0, None)  # counts
+        elif kind == 3:
+            v = np.where(rng.random(n) < 0.7, 0.0, np.exp(v) * 100.0)  # zero-inflated
+        num.append(v)
+    cats = []
+    ncols = 0
+    while ncols < 260:
+        levels = int(rng.integers(2, 13))
+        levels = min(levels, 260 - ncols) if 260 - ncols >= 2 else 260 - ncols
+        p = rng.dirichlet(np.full(levels, 0.4))
+        c = rng.choice(levels, size=n, p=p)
+        cats.append(np.eye(levels)[c])
+        ncols += levels
+    X = np.column_stack(num + cats + [np.full(n, 3.0)])
+    price = 12.0 + 0.25 * z[:, 0] - 0.15 * z[:, 1] + 0.1 * np.tanh(z[:, 2] * z[:, 3]) + 0.05 * (cats[0] @ rng.standard_normal(cats[0].shape[1]))
+    y = np.exp(price + 0.1 * rng.standard_normal(n))
+    return rng, np.ascontiguousarray(X), y
+
+
+def ames_case(name, nq=129):
+    """Default ``NeoLSSVM()`` (n > 1024 -> primal, D = 512) on the ames-shaped table: the plumbing configuration."""
+    rng, X, y = ames_like()
+    n = X.shape[0]
+    Xq = X[rng.choice(n, size=nq, replace=False)] + 0.0
+    Xq[:, :40] *= 1.0 + 0.01 * rng.standard_normal((nq, 40))
+    _captured.clear()
+    m = NeoLSSVM().fit(X, y)
+    assert m.primal_
+    afm = m.primal_feature_map_.affine_feature_map
+    out = dict(
+        kind="primal", task="reg", X=X, y=y, s=np.ones(n), has_weights=False, Xq=Xq, D=512,
+        shift=np.ravel(afm.shift_), scale=np.ravel(afm.scale_), B=afm.A_, Z_shape=np.array(m.primal_feature_map_.Z_.shape),
+        lam=_captured["lam"], gammas=m.γs_, loo_errors_gammas=m.loo_errors_γs_, gamma=m.γ_,
+        opt=int(np.argmin(np.abs(m.γs_ - m.γ_))), beta=m.β̂_, loo_residuals=m.loo_residuals_, loo_yhat=m.loo_ŷ_,
+        loo_leverage=m.loo_leverage_, loo_error=m.loo_error_, loo_score=m.loo_score_, loo_std=m.loo_std_,
+        residuals=m.residuals_, L=np.zeros(0), L_lower=bool(m.L_[1]), decision_function=m.decision_function(Xq),
+        predict_std=m.predict_std(Xq), predict=m.predict(Xq), phi_q=m.primal_feature_map_.transform(Xq[:8]),
+    )  # fmt: skip
+    np.savez_compressed(HERE / f"{name}.npz", **out)
+    print(name, "gamma", m.γ_, "opt", out["opt"], "loo_score", m.loo_score_, "X", X.shape, "r", afm.A_.shape,
+          "min|scale|", np.abs(afm.scale_).min())
+
+
+def exact_complexity_case(name, n, d, D, task, seed, nq=65):
+    """the exact complexity matrix (``_ztz_prod_sinc_zmz`` with ``fast_approx=False``,
+    ``_feature_maps.py:46-55``) and the generalised-EVD branch it sends ``_optimize_beta_gamma`` down
+    (``eigh(a=A, b=C)`` + LU, ``_neo_ls_svm.py:122-124,131,139``).  Unreachable upstream (``fast_approx=True`` is
+    hard-wired at ``_feature_maps.py:133``); here the flag is flipped by wrapping the module-level function."""
+    import neo_ls_svm._feature_maps as fm_mod
+
+    orig = fm_mod._ztz_prod_sinc_zmz
+    fm_mod._ztz_prod_sinc_zmz = lambda Z, fast_approx=False: orig(Z, fast_approx=False)
+    try:
+        rng, X, y = synth(n, d, task, seed)
+        Xq = rng.standard_normal((nq, d))
+        _captured.clear()
+        fm = OrthogonalRandomFourierFeatures(num_features=D)
+        m = NeoLSSVM(primal_feature_map=fm, dual=False).fit(X, y)
+        Cm = np.array(m.primal_feature_map_.complexity_matrix)
+        assert not np.all(np.diag(np.diag(Cm)) == Cm)
+        afm = m.primal_feature_map_.affine_feature_map
+        out = dict(
+            kind="primal", task=task, X=X, y=y, s=np.ones(n), has_weights=False, Xq=Xq, D=D,
+            shift=np.ravel(afm.shift_), scale=np.ravel(afm.scale_), B=afm.A_, Z=m.primal_feature_map_.Z_, C=Cm,
+            gammas=m.γs_, loo_errors_gammas=m.loo_errors_γs_, gamma=m.γ_, opt=int(np.argmin(np.abs(m.γs_ - m.γ_))),
+            beta=m.β̂_, loo_residuals=m.loo_residuals_, loo_yhat=m.loo_ŷ_, loo_leverage=m.loo_leverage_,
+            loo_error=m.loo_error_, loo_score=m.loo_score_, loo_std=m.loo_std_, residuals=m.residuals_,
+            L=m.L_[0], L_lower=bool(m.L_[1]), cho_in=_captured["cho_in"], decision_function=m.decision_function(Xq),
+            predict_std=m.predict_std(Xq), predict=m.predict(Xq),
+        )  # fmt: skip
+        np.savez_compressed(HERE / f"{name}.npz", **out)
+        print(name, "gamma", m.γ_, "opt", out["opt"], "loo_score", m.loo_score_, "Z", m.primal_feature_map_.Z_.shape,
+              "cond(C)", np.linalg.cond(Cm))
+    finally:
+        fm_mod._ztz_prod_sinc_zmz = orig
+
+
 def sigma_case(name, base, sigmas):
     """gamma x sigma grid semantics of SURVEY.md 8(d) c5: B / sigma_k, 32-point sub-grid [::33]."""
     z = np.load(HERE / f"{base}.npz")
@@ -199,6 +292,13 @@ def sigma_case(name, base, sigmas):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[2] == "ames":  # only the ames-shaped case (added in round 2)
+        ames_case("primal_reg_ames_n2930_d301_D512")
+        raise SystemExit(0)
+    if len(sys.argv) > 2 and sys.argv[2] == "exactC":  # only the exact-complexity-matrix cases (added in round 2)
+        exact_complexity_case("primal_reg_n400_d8_D192_exactC", 400, 8, 192, "reg", seed=9)
+        exact_complexity_case("primal_clf_n300_d6_D128_exactC", 300, 6, 128, "clf", seed=10)
+        raise SystemExit(0)
     primal_case("primal_reg_n3000_d20_D256", 3000, 20, 256, "reg", "unit", seed=0, store_A=True)
     primal_case("primal_reg_n5000_d16_D256_w", 5000, 16, 256, "reg", "uniform", seed=1)
     primal_case("primal_clf_n3000_d16_D256_wz", 3000, 16, 256, "clf", "zeros", seed=2)
@@ -208,3 +308,6 @@ if __name__ == "__main__":
     dual_case("dual_clf_n500_d20_wz", 500, 20, "clf", "zeros", seed=6)
     dual_case("dual_reg_n1000_d32_w", 1000, 32, "reg", "uniform", seed=7)
     sigma_case("sigma_grid_reg_n3000", "primal_reg_n3000_d20_D256", [0.5, 1.0, 2.0])
+    ames_case("primal_reg_ames_n2930_d301_D512")
+    exact_complexity_case("primal_reg_n400_d8_D192_exactC", 400, 8, 192, "reg", seed=9)
+    exact_complexity_case("primal_clf_n300_d6_D128_exactC", 300, 6, 128, "clf", seed=10)

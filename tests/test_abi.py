@@ -32,18 +32,148 @@ def test_library_exports_every_declared_symbol():
     for name in declared_symbols():
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
-    assert lib.nls_abi_version() == 1
+    assert lib.nls_abi_version() == 2
 
 
 def test_struct_layout_matches_header():
     from neo_ls_svm_amd import _lib
 
-    # 7 pointers, int64, 5 int32 (+4 pad), 12 pointers
-    assert ctypes.sizeof(_lib.PrimalFitArgs) == 7 * 8 + 8 + 5 * 4 + 4 + 12 * 8
-    assert _lib.PrimalFitArgs.n.offset == 56 and _lib.PrimalFitArgs.beta.offset == 88
+    # 7 pointers, int64, 6 int32, Cmat pointer, finish_below double, 13 output pointers
+    assert ctypes.sizeof(_lib.PrimalFitArgs) == 7 * 8 + 8 + 6 * 4 + 8 + 8 + 13 * 8
+    assert _lib.PrimalFitArgs.n.offset == 56 and _lib.PrimalFitArgs.flags.offset == 84
+    assert _lib.PrimalFitArgs.Cmat.offset == 88 and _lib.PrimalFitArgs.finish_below.offset == 96
+    assert _lib.PrimalFitArgs.beta.offset == 104
     # 4 pointers, int64, 4 int32, 11 pointers
     assert ctypes.sizeof(_lib.DualFitArgs) == 4 * 8 + 8 + 4 * 4 + 11 * 8
     assert _lib.DualFitArgs.alpha.offset == 56
+
+
+def test_struct_layout_matches_the_compiler(tmp_path):
+    """offsetof / sizeof as gcc lays the header's structs out == the ctypes mirror (field by field)."""
+    import subprocess
+
+    from neo_ls_svm_amd import _lib
+
+    def prog(struct, fields):
+        lines = "\n".join(f'  printf("{struct}.{f} %zu\\n", offsetof({struct}, {f}));' for f in fields)
+        return f'  printf("sizeof_{struct} %zu\\n", sizeof({struct}));\n{lines}\n'
+
+    pf = [f[0] for f in _lib.PrimalFitArgs._fields_]
+    df = [f[0] for f in _lib.DualFitArgs._fields_]
+    src = tmp_path / "layout.c"
+    src.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "neolssvm_hip.h"\nint main(void) {\n'
+        + prog("nls_primal_fit_args", pf) + prog("nls_dual_fit_args", df) + "  return 0;\n}\n"
+    )
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", str(ROOT / "include"), str(src), "-o", str(exe)], check=True)
+    out = dict(line.split() for line in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines())
+    assert int(out["sizeof_nls_primal_fit_args"]) == ctypes.sizeof(_lib.PrimalFitArgs)
+    assert int(out["sizeof_nls_dual_fit_args"]) == ctypes.sizeof(_lib.DualFitArgs)
+    for f in pf:
+        assert int(out[f"nls_primal_fit_args.{f}"]) == getattr(_lib.PrimalFitArgs, f).offset, f
+    for f in df:
+        assert int(out[f"nls_dual_fit_args.{f}"]) == getattr(_lib.DualFitArgs, f).offset, f
+
+
+def test_estimator_hands_its_device_to_the_prestep(monkeypatch):
+    """NeoLSSVM(device=k) must run the pre-step's GPU statistics and the solver on context k only (one upload of X):
+    no call may fall back to the default context of device 0."""
+    import neo_ls_svm_amd.estimator as est
+    from neo_ls_svm_amd import _prestep
+
+    asked = []
+
+    class FakeCtx:
+        device = 1
+
+        def hold(self, a):
+            import contextlib
+
+            return contextlib.nullcontext()
+
+    fake = FakeCtx()
+
+    def fake_default(device=0):
+        asked.append(device)
+        if device != 1:
+            raise AssertionError(f"default_context({device}) requested by an estimator with device=1")
+        return fake
+
+    seen = []
+
+    def fake_bin_stats(X, labels, sw=None, ctx=None):
+        seen.append(ctx)
+        lab = np.asarray(labels)
+        w = np.ones(len(lab)) if sw is None else np.asarray(sw)
+        cen, spr = [], []
+        for b in range(lab.max() + 1):
+            m = lab == b
+            mu = _prestep.weighted_median_columns(X[m], w[m] / w[m].sum())
+            cen.append(mu[0])
+            spr.append(((w[m] / w[m].sum())[None, :] @ np.abs(X[m] - mu))[0])
+        return np.array(cen), np.array(spr)
+
+    class Stop(Exception):
+        pass
+
+    def fake_fit(*a, ctx=None, **k):
+        seen.append(ctx)
+        raise Stop
+
+    monkeypatch.setattr(est, "default_context", fake_default)
+    monkeypatch.setattr(est.hotpath, "bin_stats", fake_bin_stats)
+    monkeypatch.setattr(est.hotpath, "primal_fit", fake_fit)
+    rng = np.random.default_rng(0)
+    X, y = rng.standard_normal((1500, 6)), rng.standard_normal(1500)
+    with pytest.raises(Stop):
+        est.NeoLSSVM(device=1, dual=False).fit(X, y)
+    assert asked and set(asked) == {1}
+    assert len(seen) >= 2 and all(c is fake for c in seen)
+
+
+def test_no_torch_in_the_product():
+    """The product and bench.py are torch-free (north star: ctypes + HIP + RCCL); torch appears in test workers only."""
+    import ast
+
+    files = list((ROOT / "neo_ls_svm_amd").glob("*.py")) + [ROOT / "bench.py", ROOT / "__graft_entry__.py"]
+    for f in files:
+        tree = ast.parse(f.read_text())
+        for node in ast.walk(tree):
+            names = []
+            if isinstance(node, ast.Import):
+                names = [a.name for a in node.names]
+            elif isinstance(node, ast.ImportFrom):
+                names = [node.module or ""]
+            assert not any(n == "torch" or n.startswith("torch.") for n in names), f"{f} imports torch"
+
+
+def test_rendezvous_file_exchange(tmp_path, monkeypatch):
+    """distributed.exchange_unique_id: rank 0 publishes 128 bytes atomically, the others read exactly those."""
+    import threading
+
+    from neo_ls_svm_amd import distributed
+
+    monkeypatch.setenv("NLS_RENDEZVOUS_DIR", str(tmp_path))
+
+    class Ctx:
+        def comm_unique_id(self):
+            return bytes(range(128))
+
+    got = {}
+
+    def reader(rank):
+        got[rank] = distributed.exchange_unique_id(Ctx(), rank, 3, key="t1", timeout=20)
+
+    ts = [threading.Thread(target=reader, args=(r,)) for r in (1, 2)]
+    for t in ts:
+        t.start()
+    got[0] = distributed.exchange_unique_id(Ctx(), 0, 3, key="t1")
+    for t in ts:
+        t.join()
+    assert got[0] == got[1] == got[2] == bytes(range(128))
+    with pytest.raises(TimeoutError):
+        distributed.exchange_unique_id(Ctx(), 1, 2, key="absent", timeout=0.2)
 
 
 def test_no_cpu_fallback_without_gpu():

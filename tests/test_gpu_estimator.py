@@ -108,16 +108,28 @@ def test_auto_switch_pandas_and_score():
     assert 0.9 < mc.loo_score_ <= 1.0
 
 
+# sklearn's conformance checks this estimator does not pass, by design of the reference's API: a
+# regressor that has decision_function, a binary-only classifier, and weights that act on the LOO calibration split.
+EXPECTED_CHECK_FAILURES = {
+    "regressor": {"check_regressors_no_decision_function", "check_sample_weight_equivalence_on_dense_data"},
+    "classifier": {
+        "check_classifier_not_supporting_multiclass",
+        "check_classifiers_regression_target",
+        "check_sample_weight_equivalence_on_dense_data",
+    },
+}
+
+
 def test_sklearn_check_estimator_report():
-    """sklearn's conformance suite; the reference itself fails 3 version-drift checks."""
+    """sklearn's conformance suite: the failures are exactly the known list, everything else passes."""
     from sklearn.utils.estimator_checks import check_estimator
 
     from neo_ls_svm_amd import NeoLSSVM
 
     for kind in ("regressor", "classifier"):
         res = check_estimator(NeoLSSVM(estimator_type=kind), on_fail=None)
-        failed = [r for r in res if r["status"] == "failed"]
-        names = sorted(r["check_name"] for r in failed)
-        print(kind, "passed", sum(r["status"] == "passed" for r in res), "failed", names)
-        assert sum(r["status"] == "passed" for r in res) >= 35
-        assert len(failed) <= 6, names
+        failed = sorted(r["check_name"] for r in res if r["status"] == "failed")
+        passed = sum(r["status"] == "passed" for r in res)
+        print(kind, "passed", passed, "failed", failed)
+        assert set(failed) == EXPECTED_CHECK_FAILURES[kind], failed
+        assert passed >= 50

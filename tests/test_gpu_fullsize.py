@@ -32,7 +32,7 @@ def test_c3_identities():
     ctx = hp.default_context()
     X, y = bench.synth(n, d, 0, n)
     s = np.ones(n)
-    shift, scale, B = bench.affine_params(d, D)
+    shift, scale, B = bench.affine_params(n, d, D, ctx=ctx)  # pre-step on the 2e5-row prefix
     dX = ctx.to_device(X)
     r = hp.primal_fit(dX, y, s, shift, scale, B, False, ctx=ctx)
     D1 = D + 1
@@ -41,6 +41,7 @@ def test_c3_identities():
     g, lam = r["gamma"], r["lam"]
     assert r["gammas"].shape == (1024,) and np.all(np.isfinite(r["loo_errors_gammas"]))
     assert r["opt"] == int(np.argmin(r["loo_errors_gammas"]))
+    assert 0 < r["opt"] < 1023, "with the prescribed affine parameters the LOO curve has an interior minimum"
 
     # eigenvalues and normal equations
     A, b = hp.gram(dX, y, s, shift, scale, B, ctx=ctx)

@@ -211,18 +211,107 @@ def test_argument_errors_raise_like_the_reference(hp):
         hp.featuremap(X, np.zeros(3), np.ones(3), rng.standard_normal((4, 8)))
 
 
-def test_predict_std_reuses_and_refreshes_the_cached_factor(golden_loader, hp):
-    """nls_primal_predict keeps the inverse of the last L; a different L (other address or other content) replaces it."""
+def test_predict_std_factor_handle(golden_loader, hp):
+    """predict_std from an explicit factor handle (U^-1 kept on the device) equals the on-the-fly path; an edited L needs
+    a new handle - nothing is recognised by address."""
     g = golden_loader("primal_reg_n3000_d20_D256")
     y = signed_targets(g)
+    ctx = hp.default_context()
     r = hp.primal_fit(g["X"], y, g["s"], g["shift"], g["scale"], g["B"], False)
     L = np.ascontiguousarray(r["L"])
     _, s1 = hp.primal_predict(g["Xq"], g["shift"], g["scale"], g["B"], L=L)
-    _, s2 = hp.primal_predict(g["Xq"][:100], g["shift"], g["scale"], g["B"], L=L)  # cached factor
-    assert np.array_equal(s1[:100], s2) and relerr(s1, g["predict_std"]) < TOL
-    L2 = L * 2.0  # U -> 2 U: sigma halves; new array, new content
-    _, s3 = hp.primal_predict(g["Xq"], g["shift"], g["scale"], g["B"], L=L2)
-    assert relerr(s3, s1 / 2) < 1e-12
-    L *= 2.0  # same address, edited diagonal: the checksum notices
+    f = hp.Factor(ctx, L)
+    _, s2 = hp.primal_predict(g["Xq"][:100], g["shift"], g["scale"], g["B"], factor=f)
+    y3, s3 = hp.primal_predict(g["Xq"], g["shift"], g["scale"], g["B"], beta=r["beta"], factor=f)
+    assert np.array_equal(s1[:100], s2) and np.array_equal(s1, s3) and relerr(s1, g["predict_std"]) < TOL
+    assert relerr(y3, g["decision_function"]) < TOL
+    L *= 2.0  # in-place edit: the on-the-fly path sees it, the handle (a snapshot) does not
     _, s4 = hp.primal_predict(g["Xq"], g["shift"], g["scale"], g["B"], L=L)
-    assert relerr(s4, s1 / 2) < 1e-12
+    _, s5 = hp.primal_predict(g["Xq"], g["shift"], g["scale"], g["B"], factor=f)
+    assert relerr(s4, s1 / 2) < 1e-12 and np.array_equal(s5, s1)
+    f2 = hp.Factor(ctx, L)
+    _, s6 = hp.primal_predict(g["Xq"], g["shift"], g["scale"], g["B"], factor=f2)
+    assert relerr(s6, s1 / 2) < 1e-12
+    f.close()
+    f2.close()
+    with pytest.raises(ValueError):
+        hp.primal_predict(g["Xq"], g["shift"], g["scale"], g["B"], factor=f)
+    with pytest.raises(ValueError):  # wrong feature count
+        hp.primal_predict(g["Xq"], g["shift"], g["scale"], g["B"][:, :100], factor=hp.Factor(ctx, L))
+
+
+def test_cholesky_failure_raises_linalgerror(golden_loader, hp):
+    """rocsolver_zpotrf info > 0 -> numpy.linalg.LinAlgError, as scipy's cho_factor raises in the reference (:177)."""
+    g = golden_loader("primal_reg_n2000_d48_D32")
+    y = signed_targets(g)
+    with pytest.raises(np.linalg.LinAlgError):  # gamma * c I + A is indefinite for a hugely negative gamma
+        hp.primal_fit(g["X"], y, g["s"], g["shift"], g["scale"], g["B"], False, gammas=np.array([-1e9]))
+    r = hp.primal_fit(g["X"], y, g["s"], g["shift"], g["scale"], g["B"], False)  # the context is usable afterwards
+    assert relerr(r["beta"], g["beta"]) < TOL
+
+
+def test_sweep_only_and_finish_below(golden_loader, hp):
+    g = golden_loader("primal_reg_n3000_d20_D256")
+    y = signed_targets(g)
+    full = hp.primal_fit(g["X"], y, g["s"], g["shift"], g["scale"], g["B"], False)
+    so = hp.primal_fit(g["X"], y, g["s"], g["shift"], g["scale"], g["B"], False, sweep_only=True)
+    assert not so["finished"] and "beta" not in so and "L" not in so and so["opt"] == full["opt"]
+    assert np.array_equal(so["loo_errors_gammas"], full["loo_errors_gammas"]) and np.array_equal(so["lam"], full["lam"])
+    assert so["timings"]["cholesky"] == 0.0 and so["timings"]["residuals"] == 0.0
+    best = full["objective"][full["opt"]]
+    lo = hp.primal_fit(g["X"], y, g["s"], g["shift"], g["scale"], g["B"], False, finish_below=best)  # not strictly below
+    hi = hp.primal_fit(g["X"], y, g["s"], g["shift"], g["scale"], g["B"], False, finish_below=best * (1 + 1e-9))
+    assert not lo["finished"] and hi["finished"] and np.array_equal(hi["beta"], full["beta"])
+
+
+def test_workspace_limit_and_release(golden_loader, hp):
+    """An explicit workspace limit is a hard bound for buffers that cannot be chunked (the EVD's n x n matrices), and
+    nls_ws_release returns the arena."""
+    ctx = hp.Context(0)
+    try:
+        g = golden_loader("primal_reg_n3000_d20_D256")
+        r = hp.primal_fit(g["X"], signed_targets(g), g["s"], g["shift"], g["scale"], g["B"], False, ctx=ctx)
+        assert r["finished"]
+        held = ctx.release_workspace(min_bytes=1 << 20)
+        assert held < 64 << 20
+        assert ctx.release_workspace() == 0
+        ctx._check(ctx.lib.nls_set_workspace_limit(ctx.handle, 8 << 20))
+        A = np.eye(3000)
+        with pytest.raises(ValueError):  # 72 MB for one 3000 x 3000 matrix > 8 MB (+ slack)
+            hp.eigh(A, ctx=ctx)
+        ctx._check(ctx.lib.nls_set_workspace_limit(ctx.handle, 0))
+        lam, _ = hp.eigh(A[:200, :200], ctx=ctx)
+        assert np.allclose(lam, 1.0)
+    finally:
+        ctx.close()
+
+
+def test_eigh_of_badly_scaled_matrices(hp):
+    """Entries far outside [1e-146, 1e146] go through the driver-level scaling (LAPACK zheev convention)."""
+    rng = np.random.default_rng(3)
+    M = rng.standard_normal((150, 150)) + 1j * rng.standard_normal((150, 150))
+    A = M @ M.conj().T / 150
+    lam0 = np.linalg.eigvalsh(A)
+    for f in (1e-200, 1e200):
+        lam, Q = hp.eigh(A * f)
+        assert np.max(np.abs(lam / f - lam0)) <= 1e-11 * lam0[-1]
+        assert np.max(np.abs(Q.conj().T @ Q - np.eye(150))) <= 1e-11
+
+
+def test_single_rank_rccl_communicator(golden_loader, hp):
+    """A one-rank native RCCL communicator: the library's collectives (all-reduce of the packed Gram, broadcast,
+    all-gather) really run through librccl on the device buffers and leave the results bit-identical."""
+    g = golden_loader("primal_reg_n3000_d20_D256")
+    y = signed_targets(g)
+    r0 = hp.primal_fit(g["X"], y, g["s"], g["shift"], g["scale"], g["B"], False)
+    ctx = hp.Context(0)
+    try:
+        ctx.comm_init(ctx.comm_unique_id(), 0, 1)
+        assert np.array_equal(ctx.comm_allreduce([1.5, -2.0], "max"), [1.5, -2.0])
+        ctx.comm_barrier()
+        r1 = hp.primal_fit(g["X"], y, g["s"], g["shift"], g["scale"], g["B"], False, ctx=ctx)
+        for k in ("beta", "loo_residuals", "loo_errors_gammas", "lam", "L"):
+            assert np.array_equal(r0[k], r1[k]), k
+        ctx.comm_destroy()
+    finally:
+        ctx.close()

@@ -113,3 +113,50 @@ def test_sigma_grid_matches_reference(golden_loader):
     for k, sigma in enumerate(sg["sigmas"]):
         r = orc.primal_fit_streamed(g["X"], g["y"], g["s"], g["shift"], g["scale"], g["B"] / sigma, False, gammas=gam)
         assert relerr(r["loo_errors_gammas"], sg["loo_errors"][k]) < TOL
+
+
+def test_ames_shaped_case_pins_prestep_and_oracle(golden_loader):
+    """BASELINE config 1 (plumbing): wide d with one-hot, all-zero and constant columns.  The package's pre-step
+    reproduces the reference's shift_/scale_/A_ (incl. the eps clamp, ``_affine_normalizer.py:88``) and the oracle its fit."""
+    from neo_ls_svm_amd import _prestep, hotpath
+
+    g = golden_loader("primal_reg_ames_n2930_d301_D512")
+    shift, scale, A = _prestep.fit_affine_separator(g["X"], g["y"], None)
+    assert relerr(np.ravel(shift), g["shift"]) < 1e-12 and relerr(np.ravel(scale), g["scale"]) < 1e-12
+    assert np.sum(np.abs(np.ravel(scale)) == np.finfo(np.float64).eps) == 18
+    assert A.shape[1] == int(g["Z_shape"][0])
+    B = A @ hotpath.orf_frequencies(A.shape[1], 512, 42)
+    assert relerr(B, g["B"]) < 1e-9
+    r = orc.primal_fit_streamed(g["X"], g["y"], g["s"], g["shift"], g["scale"], g["B"], False)
+    assert r["opt"] == int(g["opt"]) and r["gamma"] == float(g["gamma"])
+    for k in ("lam", "loo_errors_gammas", "beta", "loo_residuals", "loo_leverage", "residuals"):
+        assert relerr(r[k], g[k]) < TOL, k
+    assert relerr(r["loo_std"], g["loo_std"]) < 1e-7
+    assert relerr(orc.primal_decision_function(g["Xq"], g["shift"], g["scale"], g["B"], r["beta"]), g["decision_function"]) < TOL
+
+
+EXACT_C_CASES = ["primal_reg_n400_d8_D192_exactC", "primal_clf_n300_d6_D128_exactC"]
+
+
+@pytest.mark.parametrize("name", EXACT_C_CASES)
+def test_exact_complexity_matrix_and_generalised_branch(name, golden_loader):
+    """the oracle's restatement of the exact complexity matrix (``_feature_maps.py:46-55``) and of the
+    generalised-EVD branch (``_neo_ls_svm.py:122-124,131,139``) against fixtures from the reference run with
+    ``fast_approx=False``; the product's host-side matrix builder agrees with both."""
+    from neo_ls_svm_amd import hotpath
+
+    g = golden_loader(name)
+    Cm = orc.exact_complexity_matrix(g["Z"])
+    assert relerr(Cm, g["C"]) < 1e-13
+    assert relerr(hotpath.exact_complexity_matrix(g["Z"]), g["C"]) < 1e-13
+    y, is_clf = signed_targets(g), g["task"] == "clf"
+    phi = orc.feature_map(g["X"], g["shift"], g["scale"], g["B"])
+    r = orc.primal_fit_faithful(phi, y, g["s"], is_clf, C=g["C"])
+    assert r["opt"] == int(g["opt"]) and r["gamma"] == float(g["gamma"])
+    assert relerr(r["loo_errors_gammas"], g["loo_errors_gammas"]) < TOL
+    for k in ("beta", "loo_residuals", "loo_leverage", "residuals", "loo_yhat"):
+        assert relerr(r[k], g[k]) < TOL, k
+    assert relerr(r["loo_std"], g["loo_std"]) < 1e-7
+    assert abs(r["loo_score"] - float(g["loo_score"])) < 1e-10
+    iu = np.triu_indices(phi.shape[1])
+    assert relerr(r["L"][iu], g["L"][iu]) < TOL

@@ -189,9 +189,9 @@ static bool evd_use_rocsolver() {
   return m && std::string(m) == "rocsolver";
 }
 
-// LAPACK's zheev / dsyev scale the matrix when its largest entry leaves [rmin, rmax] = [sqrt(safmin / eps), 1 / rmin]; the
-// panel's larfg (nls_trd.h) has no safmin rescaling loop of its own, so a general-purpose nls_eigh_only relies on this:
-// inside the safe range sums of squares of entries neither overflow nor lose more than entries already negligible
+// LAPACK's zheev / dsyev scale the matrix when its largest entry leaves [sqrt(safmin / eps), sqrt(eps / safmin)]; the panel's
+// larfg (nls_trd.h) has no safmin rescaling loop of its own, so a general-purpose nls_eigh_only relies on a scaling at
+// the driver level too: then sums of squares of entries neither overflow nor lose more than entries already negligible
 // against the matrix norm.  Returns the factor applied (1 = none); eigenvalues are divided by it afterwards.
 __global__ void k_absmax_lower(const double* A, long lda_d, int n, int comps, unsigned long long* out) {
   // A viewed as doubles; comps = 2 for complex.  One block per column.
@@ -225,10 +225,10 @@ static int evd_prescale(nls_ctx* ctx, void* A, int n, int comps, double* factor)
   double anrm;
   std::memcpy(&anrm, &bits, sizeof(anrm));
   if (!std::isfinite(anrm)) return fail(ctx, NLS_ERR_LINALG, "eigendecomposition: the matrix contains NaN or Inf");
-  const double rmin = std::sqrt(2.2250738585072014e-308 / 1.1102230246251565e-16), rmax = 1.0 / rmin;
+  // Outside [1e-100, 1e100] scale by the power of two that brings the largest entry to [1, 2): exact, and everything
+  // downstream (sums of squares in larfg, rocSOLVER's stedc) sees an O(1) matrix.
   *factor = 1.0;
-  if (anrm > 0.0 && anrm < rmin) *factor = rmin / anrm;
-  if (anrm > rmax) *factor = rmax / anrm;
+  if (anrm > 0.0 && (anrm < 1e-100 || anrm > 1e100)) *factor = std::ldexp(1.0, -std::ilogb(anrm));
   if (*factor != 1.0) {
     hipLaunchKernelGGL(k_scale_lower, dim3((unsigned)n), dim3(256), 0, ctx->stream, static_cast<double*>(A), (long)n * comps, n, comps, *factor);
     HIPCHK(ctx, hipGetLastError());

@@ -112,9 +112,12 @@ __device__ __forceinline__ double frag_b3(const lds_f64* rd, int ks, int nt) { r
 // operations (fragment reads of the next sub-step; at ks == 1 also the LDS stores of slice kt + 1 and the global
 // loads of slice kt + 2).  Two slices per trip so that the LDS buffer parity is a compile-time
 // constant and every LDS address is a loop-invariant register plus an immediate.
+// koff (in slices, 0 <= koff < ktiles): the walk starts at slice koff and wraps around - workgroups that share an operand
+// panel in one L2 can be taken out of phase (one leads and misses, the others hit) without changing what is summed,
+// only the order (the slice index is SALU arithmetic: free).
 template <bool A_KMAJOR, class ALoad, class BLoad, int ABL = 0>
 __device__ __forceinline__ void mainloop_3m(const ALoad& lac, const ALoad& las, const BLoad& lbr, const BLoad& lbi, long kbegin,
-                                            int ktiles, double* smem) {
+                                            int ktiles, double* smem, int koff = 0) {
   constexpr int KS = BK / 4;
   static_assert(KS == 4, "fragment parity relies on an even number of sub-steps");
   static_assert(ALoad::NREG == STAGE_A && BLoad::NREG == STAGE_B, "staging plan");
@@ -141,7 +144,12 @@ __device__ __forceinline__ void mainloop_3m(const ALoad& lac, const ALoad& las, 
       rbi[it] = lbi.fetch1(k, it);
     }
   };
-  fetch_all(kbegin);
+  auto kpos = [&](int kt) -> long {  // global k of slice number kt of the walk (uniform -> scalar ALU)
+    int w = kt + koff;
+    w = w >= ktiles ? w - ktiles : w;
+    return kbegin + (long)w * BK;
+  };
+  fetch_all(kpos(0));
 #pragma unroll
   for (int it = 0; it < STAGE_A; ++it) {
     ALoad::store1(wrA[0], it, rac[it]);
@@ -152,7 +160,7 @@ __device__ __forceinline__ void mainloop_3m(const ALoad& lac, const ALoad& las, 
     BLoad::store1(wrB[0], it, rbr[it]);
     BLoad::store1(wrB[0] + TILE_B, it, rbi[it]);
   }
-  fetch_all(kbegin + (ktiles > 1 ? BK : 0));
+  fetch_all(kpos(ktiles > 1 ? 1 : 0));
   __syncthreads();
   double ac[2][MT3], as[2][MT3], br[2][NTL3], bi[2][NTL3];
 #pragma unroll
@@ -169,7 +177,7 @@ __device__ __forceinline__ void mainloop_3m(const ALoad& lac, const ALoad& las, 
   auto slice = [&](auto parity, int kt) {
     constexpr int P = decltype(parity)::value;
     const int kt2 = kt + 2 < ktiles ? kt + 2 : ktiles - 1;  // clamped: branch-free body
-    const long k2 = kbegin + (long)kt2 * BK;
+    const long k2 = kpos(kt2);
     static_for<KS>([&](auto ksc) {
       constexpr int ks = decltype(ksc)::value;
       constexpr int c = ks & 1, n = c ^ 1;

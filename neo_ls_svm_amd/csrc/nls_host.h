@@ -65,6 +65,8 @@ struct nls_ctx {
   // XCD patch shape of k_rotate3 (NLS_ROT_PATCH=RxC; 0x0 = plain order, the default: patches raise the L2 hit rate
   // from 0.57 to 0.78 and halve the fabric traffic but run 1-4 % slower, profiles/r01_pmc_summary.md)
   int rot_pr = 0, rot_pc = 0;
+  int k1_stagger_ticks = 0;  // NLS_K1_STAGGER_US: period over which the first-round workgroups of K1 are spread (k1_stagger)
+  int rot_kstagger = 0;  // NLS_ROT_KSTAGGER=S: K-walk phase (tr + tc) % S slices per workgroup (see mainloop_3m)
   bool no_resident = false;  // NLS_NO_RESIDENT_PLANES=1: recompute the feature planes per phase even when they would fit
   // stage timing
   struct Span {
@@ -220,7 +222,9 @@ struct SpanGuard {  // RAII so early returns still close the span
       return fail(ctx, NLS_ERR_COMM, "%s failed: %s (%s:%d)", #call, (api)->GetErrorString(r__), __FILE__, __LINE__); \
   } while (0)
 
-static inline bool multi_rank(const nls_ctx* ctx) { return ctx->world > 1 && (ctx->comm || ctx->allreduce); }
+// A native communicator always takes the collective path, also with one rank (the RCCL calls then run on the device
+// buffers for real: how the single-GPU box validates them); a hook only matters with more than one rank.
+static inline bool multi_rank(const nls_ctx* ctx) { return ctx->comm != nullptr || (ctx->world > 1 && ctx->allreduce); }
 
 static int do_allreduce(nls_ctx* ctx, double* dbuf, size_t count) {
   if (!multi_rank(ctx)) return NLS_OK;

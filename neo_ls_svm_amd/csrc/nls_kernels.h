@@ -10,6 +10,7 @@
 #pragma once
 #include "nls_gemm.h"
 #include "nls_gemm3m.h"
+#include "nls_sincos.h"
 
 namespace nls {
 
@@ -36,7 +37,24 @@ struct FeatureMapParams {
   double* Fc;  // rows_pad x Kf
   double* Fs;
   double* phi;  // rows x (D+1) complex interleaved (complex variant only)
+  int stagger_ticks;  // > 0: the workgroups of the first round start out of phase (see k1_stagger)
+  SinCosCoef sc;      // constants of the short sincos (kernel arguments -> SGPR operands, nls_sincos.h)
 };
+
+// The tile kernels of K1 have two phases - matrix pipe (K = d is short), then sincos + 2 x 128 stores per lane - and all
+// workgroups take the same time, so the 512 workgroups that start together (2 per CU) stay in lock-step: the whole chip
+// stores at once, then not at all.  Delaying the first-round workgroups by different fractions of one tile time spreads
+// the store bursts evenly (equal durations keep the phases apart for the rest of the launch).  Ticks of the 100 MHz
+// wall clock.
+__device__ __forceinline__ void k1_stagger(int ticks) {
+  if (ticks <= 0) return;
+  const long b = (long)blockIdx.y * gridDim.x + blockIdx.x;
+  if (b >= 512) return;
+  const int phase = (int)(((b >> 8) * 4 + (b & 3) * 2 + ((b >> 2) & 1)) & 7);  // the two residents of a CU differ by half a period
+  const long long wait = (long long)ticks * phase / 8;
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+}
 
 template <bool COMPLEX_OUT>
 __global__ void __launch_bounds__(Cfg4::NTHREADS, 1) k_featuremap(FeatureMapParams p) {
@@ -44,6 +62,7 @@ __global__ void __launch_bounds__(Cfg4::NTHREADS, 1) k_featuremap(FeatureMapPara
   extern __shared__ double smem[];
   const long row0 = (long)blockIdx.y * BM;
   const long col0 = (long)blockIdx.x * BN;
+  k1_stagger(p.stagger_ticks);
   v4d acc[C::MT][C::NTL];
   zero_acc(acc);
   if (col0 < p.D) {
@@ -51,34 +70,123 @@ __global__ void __launch_bounds__(Cfg4::NTHREADS, 1) k_featuremap(FeatureMapPara
     KMajorLoader<C::NTHREADS, BN> lb{p.Bs, p.Kf, col0};
     mainloop_real<C, false>(acc, la, lb, 0, p.dk / BK, smem);
   }
+  // One range test per thread: |t| <= 2^30 everywhere (always, in practice) -> the short sincos, else the library's.
+  double tmax = 0.0;
 #pragma unroll
   for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const long row = row0 + C::acc_row(mt, r);
-      const bool live = row < p.rows;
-      const double rs = live ? (p.rowscale ? p.rowscale[row] : 1.0) : 0.0;
+    for (int nt = 0; nt < C::NTL; ++nt)
 #pragma unroll
-      for (int nt = 0; nt < C::NTL; ++nt) {
-        const long col = col0 + C::acc_col(nt);
-        double c = 0.0, s = 0.0;
-        if (col < p.D) {
-          double sv, cv;
-          sincos(acc[mt][nt][r], &sv, &cv);
-          c = cv * p.inv_sqrt_D * rs;
-          s = sv * p.inv_sqrt_D * rs;
-        } else if (COMPLEX_OUT && col == p.D) {
-          c = rs;
-        }
-        if constexpr (COMPLEX_OUT) {
-          if (live && col <= p.D)
-            *reinterpret_cast<double2*>(p.phi + 2 * (row * (p.D + 1) + col)) = make_double2(c, -s);
-        } else {
-          p.Fc[row * p.Kf + col] = c;
-          p.Fs[row * p.Kf + col] = s;
+      for (int r = 0; r < 4; ++r) tmax = fmax(tmax, fabs(acc[mt][nt][r]));  // NaN: fmax drops it, the slow path is not needed for it
+  auto epilogue = [&](auto fastc) {
+    constexpr bool FAST = decltype(fastc)::value;
+#pragma unroll
+    for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long row = row0 + C::acc_row(mt, r);
+        const bool live = row < p.rows;
+        const double rs = live ? (p.rowscale ? p.rowscale[row] : 1.0) : 0.0;
+        const double f = p.inv_sqrt_D * rs;
+#pragma unroll
+        for (int nt = 0; nt < C::NTL; ++nt) {
+          const long col = col0 + C::acc_col(nt);
+          double c = 0.0, s = 0.0;
+          if (col < p.D) {
+            double sv, cv;
+            if constexpr (FAST) sincos_reduced_full(acc[mt][nt][r], sv, cv, p.sc);
+            else sincos(acc[mt][nt][r], &sv, &cv);
+            c = cv * f;
+            s = sv * f;
+          } else if (COMPLEX_OUT && col == p.D) {
+            c = rs;
+          }
+          if constexpr (COMPLEX_OUT) {
+            if (live && col <= p.D)
+              *reinterpret_cast<double2*>(p.phi + 2 * (row * (p.D + 1) + col)) = make_double2(c, -s);
+          } else {
+            p.Fc[row * p.Kf + col] = c;
+            p.Fs[row * p.Kf + col] = s;
+          }
         }
       }
-    }
+  };
+  if (tmax <= 1073741824.0) epilogue(std::true_type{});
+  else epilogue(std::false_type{});
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1 + K8 fused (decision_function, P10): yhat_i = Re(phi_i . beta) without ever writing phi.  Same tile loop as
+// k_featuremap; the epilogue multiplies cos / sin by the (1 / sqrt(D))-scaled weight planes and reduces over the
+// tile's columns: per accumulator row the 16 lanes of a row group are summed with shuffles, and every wave writes ONE
+// partial per row for its 64 columns: part[(2 blockIdx.x + wave_n) * rows_pad + row].  k_gemv_finish adds the
+// Kf / 64 partials in a fixed order (+ Re beta[D]): bit-reproducible, and 512 B per row of traffic instead of the
+// 2 x 16 D bytes of writing the planes and reading them back (decision_function: 24 -> ~50 M rows/s at D = 4096).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(Cfg4::NTHREADS, 1) k_featuremap_gemv(FeatureMapParams p, const double* wr, const double* wi, long rows_pad,
+                                                                     double* part) {
+  using C = Cfg4;
+  extern __shared__ double smem[];
+  const long row0 = (long)blockIdx.y * BM;
+  const long col0 = (long)blockIdx.x * BN;
+  v4d acc[C::MT][C::NTL];
+  zero_acc(acc);
+  MMajorLoader<C::NTHREADS, BM> la{p.Xs, p.dk, row0};
+  KMajorLoader<C::NTHREADS, BN> lb{p.Bs, p.Kf, col0};
+  mainloop_real<C, false>(acc, la, lb, 0, p.dk / BK, smem);
+  double br[C::NTL], bi[C::NTL];  // weights of this lane's columns (zero beyond D: padded columns drop out)
+#pragma unroll
+  for (int nt = 0; nt < C::NTL; ++nt) {
+    const long col = col0 + C::acc_col(nt);
+    br[nt] = wr[col];
+    bi[nt] = wi[col];
+  }
+  double* out = part + ((long)blockIdx.x * C::WAVES_N + C::wave_n()) * rows_pad;
+  double tmax = 0.0;
+#pragma unroll
+  for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < C::NTL; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tmax = fmax(tmax, fabs(acc[mt][nt][r]));
+  auto epilogue = [&](auto fastc) {
+    constexpr bool FAST = decltype(fastc)::value;
+#pragma unroll
+    for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double sum = 0.0;
+#pragma unroll
+        for (int nt = 0; nt < C::NTL; ++nt) {
+          double sv, cv;
+          if constexpr (FAST) sincos_reduced_full(acc[mt][nt][r], sv, cv, p.sc);
+          else sincos(acc[mt][nt][r], &sv, &cv);
+          sum += cv * br[nt] + sv * bi[nt];
+        }
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) sum += __shfl_xor(sum, m, 64);
+        if ((threadIdx.x & 15) == 0) out[row0 + C::acc_row(mt, r)] = sum;
+      }
+  };
+  if (tmax <= 1073741824.0) epilogue(std::true_type{});
+  else epilogue(std::false_type{});
+}
+
+// yhat[i] = sum_b part[b][i] + bias  (b in block order)
+__global__ void k_gemv_finish(const double* part, int nparts, long rows_pad, long rows, double bias, double* out) {
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= rows) return;
+  double v = 0.0;
+  for (int b = 0; b < nparts; ++b) v += part[(long)b * rows_pad + i];
+  out[i] = v + bias;
+}
+
+// wr[j] = Re beta[j] / sqrt(D), wi[j] = Im beta[j] / sqrt(D) for j < D, zero up to Kf:  Re(phi . beta) = cos t . wr + sin t . wi
+__global__ void k_gemv_weights(const double2* beta, int D, int Kf, double inv_sqrt_D, double* wr, double* wi) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= Kf) return;
+  wr[j] = j < D ? beta[j].x * inv_sqrt_D : 0.0;
+  wi[j] = j < D ? beta[j].y * inv_sqrt_D : 0.0;
 }
 
 // Xs[r][k] = X[r][k] - shift[k] for r < rows, k < d; zero elsewhere (rows_pad x dk).  One cheap pass (16 n d bytes against the
@@ -326,7 +434,8 @@ __global__ void k_compute_v(const double2* Qcm, long ldq, const double2* b, int 
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(m3::NT3, 1)
     k_rotate3(const double* Fc, const double* Fs, int Kf, const double* Mr, const double* Mi, const double* mbr, const double* mbi,
-              int Np, const double* vr, const double* vi, double* U, double* Gm, const double* inv_rs, long tiles_r, int PR, int PC) {
+              int Np, const double* vr, const double* vi, double* U, double* Gm, const double* inv_rs, long tiles_r, int PR, int PC,
+              int kstagger) {
   using namespace m3;
   extern __shared__ double smem[];
   long tr, tc;
@@ -342,7 +451,9 @@ __global__ void __launch_bounds__(m3::NT3, 1)
   acc_zero();
   MMajorLoader3 lac{Fc, Kf, row0}, las{Fs, Kf, row0};
   KMajorLoader3<BN3, STAGE_B> lbr{Mr, Np, col0}, lbi{Mi, Np, col0};
-  mainloop_3m<false>(lac, las, lbr, lbi, 0, Kf / BK, smem);
+  // K-walk phase of this workgroup: neighbours in the tile grid (which share an A or a B panel) differ by one slice
+  const int koff = kstagger > 0 ? (int)((tr + tc) % kstagger) : 0;
+  mainloop_3m<false>(lac, las, lbr, lbi, 0, Kf / BK, smem, koff);
   acc_settle();
   static_for<NTL3>([&](auto ntc) {
     constexpr int nt = decltype(ntc)::value;

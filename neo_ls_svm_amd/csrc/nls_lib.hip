@@ -55,7 +55,7 @@ constexpr size_t SMEM_REAL = 2 * 2 * TILE_DOUBLES * sizeof(double);  // double-b
 // K1 into split planes for `rows` rows starting at Xchunk.
 static int launch_featuremap_planes(nls_ctx* ctx, const MapParams& mp, const double* Xchunk, long rows, long rows_pad,
                                     const double* rowscale, double* Fc, double* Fs) {
-  FeatureMapParams p;
+  FeatureMapParams p{};
   p.X = Xchunk;
   double* Xs = nullptr;
   NLSCHK(ws_get_t(ctx, "fm.Xs", (size_t)rows_pad * mp.dk, &Xs));
@@ -74,6 +74,8 @@ static int launch_featuremap_planes(nls_ctx* ctx, const MapParams& mp, const dou
   p.Fc = Fc;
   p.Fs = Fs;
   p.phi = nullptr;
+  p.stagger_ticks = ctx->k1_stagger_ticks;
+  p.sc = sincos_coef();
   dim3 grid((unsigned)(mp.Kf / BN), (unsigned)(rows_pad / BM));
   hipLaunchKernelGGL(k_featuremap<false>, grid, dim3(Cfg4::NTHREADS), SMEM_REAL, ctx->stream, p);
   HIPCHK(ctx, hipGetLastError());
@@ -87,7 +89,7 @@ static int launch_rotate(nls_ctx* ctx, const MapParams& mp, const double* Fc, co
   const long tiles_r = rows_pad / BM, tiles_c = mp.Np / m3::BN3;
   const long grid = ctx->rot_pr > 0 ? xcd_patch_grid(tiles_r, tiles_c, ctx->rot_pr, ctx->rot_pc) : tiles_r * tiles_c;
   hipLaunchKernelGGL(k_rotate3, dim3((unsigned)grid), dim3(m3::NT3), m3::SMEM3, ctx->stream, Fc, Fs, mp.Kf, Mr, Mi, mbr, mbi, mp.Np,
-                     vr, vi, U, Gm, inv_rs, tiles_r, ctx->rot_pr, ctx->rot_pc);
+                     vr, vi, U, Gm, inv_rs, tiles_r, ctx->rot_pr, ctx->rot_pc, ctx->rot_kstagger);
   HIPCHK(ctx, hipGetLastError());
   return NLS_OK;
 }
@@ -140,6 +142,8 @@ extern "C" int nls_ctx_create(int device, nls_ctx** out) {
   ctx->cus = prop.multiProcessorCount;
   if (const char* ep = std::getenv("NLS_ROT_PATCH")) std::sscanf(ep, "%dx%d", &ctx->rot_pr, &ctx->rot_pc);
   if (const char* er = std::getenv("NLS_NO_RESIDENT_PLANES")) ctx->no_resident = er[0] == '1';
+  if (const char* es = std::getenv("NLS_K1_STAGGER_US")) ctx->k1_stagger_ticks = std::max(0, std::min(100000, (int)(std::atof(es) * 100.0)));
+  if (const char* ek = std::getenv("NLS_ROT_KSTAGGER")) ctx->rot_kstagger = std::max(0, std::min(16, std::atoi(ek)));
   if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess)
     return bail("hipStreamCreate", hipGetErrorString(e));
   if (rocblas_create_handle(&ctx->blas) != rocblas_status_success) return bail("rocblas_create_handle", "status != success");
@@ -151,6 +155,7 @@ extern "C" int nls_ctx_create(int device, nls_ctx** out) {
   lds(reinterpret_cast<const void*>(k_sweep), SMEM_REAL);
   lds(reinterpret_cast<const void*>(k_featuremap<false>), SMEM_REAL);
   lds(reinterpret_cast<const void*>(k_featuremap<true>), SMEM_REAL);
+  lds(reinterpret_cast<const void*>(k_featuremap_gemv), SMEM_REAL);
   lds(reinterpret_cast<const void*>(k_gemm<EPI_STORE>), SMEM_REAL);
   lds(reinterpret_cast<const void*>(k_gemm<EPI_RBF>), SMEM_REAL);
   *out = ctx;
@@ -272,7 +277,7 @@ extern "C" int nls_featuremap(nls_ctx* ctx, const double* X, int64_t n, int d, c
   if (!out_dev) NLSCHK(ws_get_t(ctx, "fm.phi", (size_t)rc * mp.D1 * 2, &dphi));
   for (long r0 = 0; r0 < n; r0 += rc) {
     const long rows = std::min<long>(rc, n - r0);
-    FeatureMapParams p;
+    FeatureMapParams p{};
     p.X = dX + r0 * d;
     const long rows_pad = round_up(rows, BM);
     double* Xs = nullptr;
@@ -289,6 +294,7 @@ extern "C" int nls_featuremap(nls_ctx* ctx, const double* X, int64_t n, int d, c
     p.D = mp.D;
     p.Kf = mp.Kf;
     p.inv_sqrt_D = 1.0 / std::sqrt((double)D);
+    p.sc = sincos_coef();
     p.Fc = p.Fs = nullptr;
     p.phi = out_dev ? phi + 2 * r0 * mp.D1 : dphi;
     dim3 grid((unsigned)(round_up(mp.D1, BN) / BN), (unsigned)(round_up(rows, BM) / BM));  // covers the bias column D
@@ -936,6 +942,50 @@ extern "C" int nls_primal_predict(nls_ctx* ctx, const double* X, int64_t m, int 
   const int D1 = mp.D1, Kf = mp.Kf, Np = mp.Np;
   const double* dX = nullptr;
   NLSCHK(resident(ctx, "in.X", X, (size_t)m * d, &dX));
+  if (yhat && !sigma) {
+    // decision_function alone: feature map and weight product fused (k_featuremap_gemv), phi never reaches HBM.
+    const long m_pad_all = round_up(m, BM);
+    const long rcf = std::min<long>(m_pad_all, 1L << 20);
+    const int nparts = 2 * (Kf / BN);
+    double *dy = nullptr, *part = nullptr, *wr = nullptr, *wi = nullptr, *Xs = nullptr;
+    double2* dbeta = nullptr;
+    NLSCHK(ws_get_t(ctx, "out.res", (size_t)m_pad_all, &dy));
+    NLSCHK(ws_get_t(ctx, "pred.part", (size_t)nparts * rcf, &part));
+    NLSCHK(ws_get_t(ctx, "chol.beta", (size_t)D1, &dbeta));
+    NLSCHK(ws_get_t(ctx, "chol.br", (size_t)Kf, &wr));
+    NLSCHK(ws_get_t(ctx, "chol.bi", (size_t)Kf, &wi));
+    NLSCHK(ws_get_t(ctx, "fm.Xs", (size_t)rcf * mp.dk, &Xs));
+    HIPCHK(ctx, hipMemcpyAsync(dbeta, beta, sizeof(double2) * D1, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_gemv_weights, dim3((unsigned)((Kf + 255) / 256)), dim3(256), 0, ctx->stream, dbeta, D, Kf, 1.0 / std::sqrt((double)D),
+                       wr, wi);
+    HIPCHK(ctx, hipGetLastError());
+    const double bias = beta[2 * (size_t)D];  // Re beta[D]: the bias feature phi[:, D] = 1
+    for (long r0 = 0; r0 < m; r0 += rcf) {
+      const long rows = std::min<long>(rcf, m - r0), rows_pad = round_up(rows, BM);
+      hipLaunchKernelGGL(k_shift_pad, dim3((unsigned)((rows_pad * mp.dk + 255) / 256)), dim3(256), 0, ctx->stream, dX + r0 * d, mp.shift,
+                         rows, mp.d, rows_pad, mp.dk, Xs);
+      FeatureMapParams p{};
+      p.X = dX + r0 * d;
+      p.Xs = Xs;
+      p.shift = mp.shift;
+      p.Bs = mp.Bs;
+      p.rows = rows;
+      p.d = mp.d;
+      p.dk = mp.dk;
+      p.D = mp.D;
+      p.Kf = mp.Kf;
+      p.inv_sqrt_D = 1.0 / std::sqrt((double)D);
+      p.sc = sincos_coef();
+      hipLaunchKernelGGL(k_featuremap_gemv, dim3((unsigned)(Kf / BN), (unsigned)(rows_pad / BM)), dim3(Cfg4::NTHREADS), SMEM_REAL,
+                         ctx->stream, p, wr, wi, rows_pad, part);
+      hipLaunchKernelGGL(k_gemv_finish, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, ctx->stream, part, nparts, rows_pad, rows, bias,
+                         dy + r0);
+      HIPCHK(ctx, hipGetLastError());
+    }
+    HIPCHK(ctx, hipMemcpyAsync(yhat, dy, sizeof(double) * m, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return NLS_OK;
+  }
   const long rc = pick_row_chunk(ctx, m, mp, 4ull * D1 * D1 * 16);
   double *Fc = nullptr, *Fs = nullptr, *br = nullptr, *bi = nullptr, *dy = nullptr, *dsig = nullptr;
   NLSCHK(ws_get_t(ctx, "chunk.Fc", (size_t)rc * Kf, &Fc));

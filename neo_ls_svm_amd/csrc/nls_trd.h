@@ -17,7 +17,7 @@
 // by the NEXT column's k_trd_column.  All reductions go through per-block partials summed in a fixed order: results
 // are bit-reproducible.  After nb = 32 columns the trailing matrix gets the rank-2nb update (rocBLAS her2k / syr2k).
 // LAPACK's rescaling loop for |beta| < safmin is replaced by the driver-level scaling of the whole matrix into
-// [sqrt(safmin / eps), sqrt(eps / safmin)] (evd_prescale in nls_evd.hip, as zheev / dsyev do).
+// an O(1) range (evd_prescale in nls_evd.hip; zheev / dsyev scale at the driver level too).
 #pragma once
 #include <hip/hip_runtime.h>
 

@@ -205,6 +205,14 @@ typedef struct nls_primal_fit_args {
 
 int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* args);
 
+/* Test hook of the compressed gamma sweep (host arithmetic only, no GPU needed).  For a strictly increasing positive grid of
+ * more than 256 points spanning at most e^17.2 (the reference's: 2e7) nls_primal_fit evaluates the rational functions of _neo_ls_svm.py:146-149 at NLS_SWEEP_NODES
+ * Chebyshev nodes in ln(gamma) and interpolates:  1 / (gammas[g] + lam) = sum_q W[q][g] / (nodes[q] + lam)  for every
+ * lam >= 0, to rounding.  nodes: NLS_SWEEP_NODES, W: NLS_SWEEP_NODES x G row-major.  *applies = 0 when the grid takes the
+ * direct product instead (nodes / W untouched). */
+#define NLS_SWEEP_NODES 128
+int nls_sweep_weights(const double* gammas, int G, double* nodes, double* W, int* applies);
+
 /* ---- primal inference -------------------------------------------------------------------------
  * A factor handle keeps U^-1 of one fitted Cholesky factor on the device (as the B-operand planes of the rotation
  * kernel), so that repeated predict_std calls skip the (D+1)^2 upload and the triangular inversion.  The handle is

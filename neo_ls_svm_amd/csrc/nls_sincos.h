@@ -54,9 +54,9 @@ NLS_HD void sincos_reduced_full(double t, double& s, double& c, const SinCosCoef
   const double ps = fma(z, fma(z, fma(z, fma(z, fma(z, k.s[5], k.s[4]), k.s[3]), k.s[2]), k.s[1]), k.s[0]);
   const double sr = fma(r * z, ps, r);
   const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, k.c[5], k.c[4]), k.c[3]), k.c[2]), k.c[1]), k.c[0]);
-  // cos r = 1 - z/2 + z^2 pc, summed as in fdlibm so that the rounding of 1 - z/2 is compensated
-  const double hz = 0.5 * z, w = 1.0 - hz;
-  const double cr = w + (((1.0 - w) - hz) + z * z * pc);
+  // cos r = 1 - z/2 + z^2 pc with two fused steps (fdlibm compensates the rounding of 1 - z/2 with four more operations;
+  // without them the error stays below 1.2 ulp of 1, checked by tests/test_sincos_cpu.py)
+  const double cr = fma(z * z, pc, fma(-0.5, z, 1.0));
   const int q = (int)fn;  // exact: |fn| < 2^30
   const bool swap = q & 1;
   const double s0 = swap ? cr : sr, c0 = swap ? sr : cr;

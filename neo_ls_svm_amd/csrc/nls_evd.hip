@@ -58,6 +58,10 @@ static int trd_fused(nls_ctx* ctx, T* A, int n, long lda, double* d, double* e, 
   a.e = e;
   a.tau = tau;
   a.nrowblocks = nrb;
+  {
+    const char* m = std::getenv("NLS_TRD_BOUSTROPHEDON");
+    a.boustrophedon = m ? (m[0] == '1') : ((size_t)n * n * sizeof(T) / 2 > ((size_t)200 << 20));
+  }
   NLSCHK(ws_get_t(ctx, "trd.W", (size_t)n * NB, &a.W));
   NLSCHK(ws_get_t(ctx, "trd.wtmp", (size_t)n, &a.wtmp));
   NLSCHK(ws_get_t(ctx, "trd.xvec", (size_t)n, &a.xvec));

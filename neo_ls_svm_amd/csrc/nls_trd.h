@@ -128,6 +128,7 @@ struct Args {
   T* wtmp_prev;     // w' of column j - 1 (wtmp holds the one being written)
   T* spart_prev;    // partials of w'^H v of column j - 1 (spart holds the ones being written)
   int make_base;    // k_trd_finish2: also prepare bvec for column j + 1 (same panel)
+  int boustrophedon;  // reverse the tile order of the matrix-vector product on odd columns (large n)
 };
 
 // Sum of cnt per-block partials, computed by the first wave of the block in a fixed order (lane-strided, then a
@@ -272,7 +273,9 @@ __global__ void __launch_bounds__(256, 2) k_trd_hemv(Args<T> a, int S0, int ntil
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave index as a scalar: x[c] below becomes scalar loads
   if ((int)blockIdx.x < ntiles) {
     // tile (R, C) of RT x TS = 64 x 64; lane = row, wave w = columns 16 w .. 16 w + 15 (all 16 loads in flight at once)
-    int t = blockIdx.x, Rr = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+    // Odd columns walk the tiles backwards: a trailing matrix larger than the 256 MB Infinity Cache (real n = 10^4: 400 MB of
+    // lower triangle) then starts each column on the tiles the previous column touched last, which are still resident.
+    int t = (a.boustrophedon && (a.j & 1)) ? ntiles - 1 - (int)blockIdx.x : (int)blockIdx.x, Rr = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
     while ((Rr + 1) * (Rr + 2) / 2 <= t) ++Rr;
     while (Rr * (Rr + 1) / 2 > t) --Rr;
     const int R = S0 + Rr, C = S0 + (t - Rr * (Rr + 1) / 2);
@@ -500,7 +503,9 @@ __global__ void __launch_bounds__(256, 2) k_trd_hemv2(Args<T> a, int S0, int nti
     return i > 0 ? a.bvec[q] + ps.mu * a.A[q + (long)(j - 1) * a.lda] : a.A[q + (long)j * a.lda];
   };
   if ((int)blockIdx.x < ntiles) {
-    int t = blockIdx.x, Rr = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+    // Odd columns walk the tiles backwards: a trailing matrix larger than the 256 MB Infinity Cache (real n = 10^4: 400 MB of
+    // lower triangle) then starts each column on the tiles the previous column touched last, which are still resident.
+    int t = (a.boustrophedon && (a.j & 1)) ? ntiles - 1 - (int)blockIdx.x : (int)blockIdx.x, Rr = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
     while ((Rr + 1) * (Rr + 2) / 2 <= t) ++Rr;
     while (Rr * (Rr + 1) / 2 > t) --Rr;
     const int R = S0 + Rr, C = S0 + (t - Rr * (Rr + 1) / 2);

@@ -17,6 +17,7 @@ It is O(n d log n) sort/select work on the CPU - SURVEY.md 8(f) lists it as the 
 from __future__ import annotations
 
 import numpy as np
+from threadpoolctl import threadpool_limits
 
 __all__ = ["target_bins", "weighted_median_columns", "fit_affine_normalizer", "fit_affine_separator"]
 
@@ -280,6 +281,13 @@ def fit_affine_separator(
     X = np.asarray(X)
     y = np.ravel(np.asarray(y)).astype(X.dtype)
     shift, scale = (normalizer or fit_affine_normalizer)(X, y, sample_weight)
+    # The edge-sample products below are a few hundred rows wide: on a 64-thread BLAS they spend their time in thread
+    # hand-offs (13 ms per 1536 x 128 x 1536 product against 3 ms on 8 threads).
+    with threadpool_limits(limits=8, user_api="blas"):
+        return _separator_directions(X, y, sample_weight, shift, scale, rank_threshold, edge_sample_size, edge_search_multiplier, random_state)
+
+
+def _separator_directions(X, y, sample_weight, shift, scale, rank_threshold, edge_sample_size, edge_search_multiplier, random_state):
     sw = (np.ones(y.shape) if sample_weight is None else np.ravel(np.asarray(sample_weight))).astype(y.dtype)
     labels = target_bins(y)
     ids = [np.flatnonzero(labels == i) for i in range(np.min(labels), np.max(labels) + 1)]

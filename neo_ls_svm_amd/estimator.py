@@ -137,7 +137,7 @@ class NeoLSSVM(BaseEstimator):
         estimator_type="auto",
         random_state=42,
         device=0,
-        release_workspace=True,
+        release_workspace=False,
     ):
         self.primal_feature_map = primal_feature_map
         self.dual_feature_map = dual_feature_map
@@ -252,8 +252,10 @@ class NeoLSSVM(BaseEstimator):
         self.residuals_ = r["residuals"]
         self.loo_std_ = r["loo_std"]
         self.fit_timings_ = r["timings"]
-        # The context's workspace only grows between calls; give the large fit-only buffers (feature planes, sweep
-        # tables: ~100 GB after a c3-size fit) back so that other users of the GPU in this process are not starved.
+        # The context's workspace is a caching arena (it only grows between calls: ~100 GB after a c3-size fit, so that the
+        # next fit allocates nothing).  release_workspace=True hands the large fit-only buffers back at the end of every fit
+        # for processes that share the GPU - at a price: freeing and re-allocating ~180 GB costs ~3 s per c3-size fit
+        # (profiles/r02_profile_fit.log), which is why it is opt-in; Context.release_workspace() does the same on demand.
         if self.release_workspace:
             ctx.release_workspace(min_bytes=256 << 20)
         # Isotonic probability calibration on the LOO predictions (:406-412).

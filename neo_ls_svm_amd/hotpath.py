@@ -349,7 +349,9 @@ def primal_fit_sigma_grid(
     table, objective, seconds = np.zeros((S, G)), np.zeros((S, G)), np.zeros(S)
     timings: dict = {}
     best = None
-    for k in range(rank, S, world):
+    # This rank's sigmas, nearest to 1 first: sigma = 1 is the bandwidth the separator chose in closed form
+    # (``_affine_separator.py:200-209``), so the incumbent is good from the start and few later sigmas need finishing.
+    for k in sorted(range(rank, S, world), key=lambda i: (abs(np.log(sigmas[i])), i)):
         r = primal_fit(X, y, s, shift, scale, B / sigmas[k], is_classifier, gammas=gammas, ctx=ctx,
                        finish_below=None if best is None else best[0])  # fmt: skip
         table[k], objective[k], seconds[k] = r["loo_errors_gammas"], r["objective"], r["timings"]["total"]

@@ -216,3 +216,65 @@ def test_3m_engine_agpr_invariant():
     tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "check_agpr.py")
     r = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_sigma_grid_merge_over_ranks(monkeypatch):
+    """primal_fit_sigma_grid: sigmas dealt round-robin over ranks, tables merged with a sum all-reduce (every sigma has one
+    owner), only a sigma that beats the rank's incumbent is finished.  The solver is replaced by a deterministic stand-in
+    (no GPU): this checks the driver's bookkeeping, the GPU test test_sigma_grid_driver checks the numbers."""
+    from neo_ls_svm_amd import hotpath
+
+    S, G = 7, 5
+    sig = np.linspace(0.5, 2.0, S)
+    rng = np.random.default_rng(0)
+    curves = rng.uniform(1.0, 2.0, (S, G))
+    curves[4, 2] = 0.5  # the joint minimum
+    calls = []
+
+    def fake_fit(X, y, s, shift, scale, B, is_clf, gammas=None, ctx=None, finish_below=None, **kw):
+        k = int(np.argmin(np.abs(sig - 1.0 / B[0, 0])))
+        obj = curves[k]
+        opt = int(np.argmin(obj))
+        finished = finish_below is None or obj[opt] < finish_below
+        calls.append((k, finish_below, finished))
+        r = {"loo_errors_gammas": obj + 10.0, "objective": obj, "opt": opt, "finished": finished, "timings": {"total": 1.0, "gram": 0.5}}
+        if finished:
+            r["beta"] = np.full(3, float(k))
+        return r
+
+    monkeypatch.setattr(hotpath, "primal_fit", fake_fit)
+    B = np.ones((1, 1))
+    world = 3
+    contribs = []
+    for rank in range(world):  # pass 1: what every rank hands to the all-reduce
+        hotpath.primal_fit_sigma_grid(None, None, None, None, None, B, False, sig, gammas=np.arange(1.0, G + 1), rank=rank, world=world,
+                                      allreduce_sum=lambda a: contribs.append(a.copy()) or a)  # fmt: skip
+    total = sum(contribs)
+    calls.clear()
+    parts = []
+    for rank in range(world):  # pass 2: every rank receives the sum
+        g = hotpath.primal_fit_sigma_grid(None, None, None, None, None, B, False, sig, gammas=np.arange(1.0, G + 1), rank=rank, world=world,
+                                          allreduce_sum=lambda a: total.copy())  # fmt: skip
+        parts.append((g, None))
+        assert (g["sigma_index"], g["gamma_index"]) == (4, 2)
+        assert np.allclose(g["objective"], curves) and np.allclose(g["loo_errors"], curves + 10.0)
+    table = total[: S * G].reshape(S, G)
+    objective = total[S * G : 2 * S * G].reshape(S, G)
+    assert np.allclose(objective, curves) and np.allclose(table, curves + 10.0)
+    assert np.allclose(total[2 * S * G :], 1.0)  # seconds per sigma: every sigma timed exactly once
+    owner = 4 % world
+    assert parts[owner][0]["best"] is not None and parts[owner][0]["best"]["beta"][0] == 4.0
+    assert all(parts[r][0]["best"] is None for r in range(world) if r != owner)
+    # a sigma is finished only when it beats the incumbent of its rank
+    for rank in range(world):
+        mine = [c for c in calls if c[0] % world == rank]
+        best = np.inf
+        for k, bound, finished in mine:
+            assert (bound is None) == (best == np.inf)
+            assert finished == (curves[k].min() < best)
+            best = min(best, curves[k].min()) if finished else best
+    # single rank, no all-reduce: the full table and the winner
+    calls.clear()
+    g = hotpath.primal_fit_sigma_grid(None, None, None, None, None, B, False, sig, gammas=np.arange(1.0, G + 1))
+    assert (g["sigma_index"], g["gamma_index"]) == (4, 2) and g["best"]["beta"][0] == 4.0
+    assert g["timings"]["gram"] == 0.5 * S

@@ -9,7 +9,7 @@ from conftest import DUAL_CASES, PRIMAL_CASES, load_golden, relerr, signed_targe
 
 print("max |x - ref| / max |ref| per output; reference = fixtures captured from the unmodified reference (tests/golden)")
 print(f"{'fixture':34s} {'argmin':>7s} {'lam':>9s} {'loo_err(g)':>10s} {'beta':>9s} {'loo_resid':>9s} {'leverage':>9s} {'loo_std':>9s} {'resid':>9s} {'yhat(Xq)':>9s} {'std(Xq)':>9s}")
-for name in PRIMAL_CASES:
+for name in PRIMAL_CASES + ["primal_reg_ames_n2930_d301_D512"]:
     g = load_golden(name)
     y, clf = signed_targets(g), g["task"] == "clf"
     r = hp.primal_fit(g["X"], y, g["s"], g["shift"], g["scale"], g["B"], clf)
@@ -27,3 +27,11 @@ for name in DUAL_CASES:
     e = [relerr(r[k], g[k]) for k in ("loo_errors_gammas", "alpha", "loo_residuals", "loo_std", "residuals")]
     e += [relerr(yq, g["decision_function"]), relerr(sq, g["predict_std"])]
     print(f"{name:34s} {'same' if r['opt'] == int(g['opt']) else 'DIFF':>7s} " + " ".join(f"{v:9.1e}" for v in e))
+
+print("\nexact complexity matrix / generalised-EVD branch (fixtures from the reference run with fast_approx=False)")
+for name in ["primal_reg_n400_d8_D192_exactC", "primal_clf_n300_d6_D128_exactC"]:
+    g = load_golden(name)
+    y, clf = signed_targets(g), g["task"] == "clf"
+    r = hp.primal_fit(g["X"], y, g["s"], g["shift"], g["scale"], g["B"], clf, complexity_matrix=g["C"])
+    e = [relerr(r[k], g[k]) for k in ("loo_errors_gammas", "beta", "loo_residuals", "loo_leverage", "loo_std", "residuals")]
+    print(f"{name:34s} {'same' if r['opt'] == int(g['opt']) else 'DIFF':>7s} {'':>9s} " + " ".join(f"{v:9.1e}" for v in e))

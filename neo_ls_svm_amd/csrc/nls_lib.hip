@@ -676,24 +676,21 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
   NLSCHK(ws_get_t(ctx, "evd.info", 4, &dinfo));
   NLSCHK(rot_buffers(ctx, mp, &rb));
   std::vector<double> hnodes, hW;
-  const bool compressed = sweep_compression(a->gammas, G, Gp, hnodes, hW);
-  const int Gr = compressed ? SWEEP_GN : Gp;  // columns of the matrix the U / Gm products run against
+  bool compressed = sweep_compression(a->gammas, G, Gp, hnodes, hW);  // final once the smallest eigenvalue is known (below)
   double* Wd = nullptr;
   NLSCHK(ws_get_t(ctx, "sweep.gammas", (size_t)std::max(G, SWEEP_GN), &dgam));
-  NLSCHK(ws_get_t(ctx, "sweep.R", (size_t)Np * Gr, &R));
+  NLSCHK(ws_get_t(ctx, "sweep.R", (size_t)Np * Gp, &R));
   if (compressed) {
     NLSCHK(ws_get_t(ctx, "sweep.W", (size_t)SWEEP_GN * Gp, &Wd));
     HIPCHK(ctx, hipMemcpyAsync(Wd, hW.data(), sizeof(double) * hW.size(), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(dgam, hnodes.data(), sizeof(double) * SWEEP_GN, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // hW / hnodes are locals of this call
-  } else {
-    HIPCHK(ctx, hipMemcpyAsync(dgam, a->gammas, sizeof(double) * G, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // hW is a local of this call
   }
   // Identity complexity matrix (the only one the reference reaches): A / c = Q Lam Q^H with c = 1 / (n (D+1)), Q unitary,
   // leverage s^2 |phi Q|^2 / c.  General C (8(f) #4): C <- C / mean|diag C| / (n (D+1)) (_neo_ls_svm.py:117), C = Lc Lc^H,
   // Lc^-1 A Lc^-H = W Lam W^H, Q = Lc^-H W, which is what eigh(A, b=C) returns (Q^H C Q = I, so lu_solve(C Q, x) = Q^H x):
   // the same rotation with the 1 / c factors replaced by 1.
   const bool general_C = a->Cmat != nullptr;
+  int Gr = Gp;  // columns of the matrix the U / Gm products run against: the 128 nodes when the sweep is compressed
   const double inv_c = general_C ? 1.0 : 1.0 / st.c;
   double2 *Cn = nullptr, *Lc = nullptr;
   {
@@ -733,6 +730,18 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
     }
     NLSCHK(build_rot_planes(ctx, mp, Qev, 1L, (long)D1, false, rb));  // column-major Q
     hipLaunchKernelGGL(k_compute_v, dim3((unsigned)Np), dim3(256), 0, ctx->stream, Qev, (long)D1, db, D1, inv_c, rb.vr, rb.vi);
+    if (compressed) {
+      // The interpolation identity needs every pole -lam_j to the left of the grid.  A / c is positive semi-definite, so
+      // lam_min >= -eps lam_max in exact-ish arithmetic; an eigenvalue below -gamma_min / 2 (degenerate weights: lam_max up to
+      // 2 n (D+1)) puts a pole of the reference's own formula inside the grid - then evaluate that formula directly.
+      double lam_min = 0.0;
+      HIPCHK(ctx, hipMemcpyAsync(&lam_min, lam, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      if (!(lam_min > -0.5 * a->gammas[0])) compressed = false;
+    }
+    Gr = compressed ? SWEEP_GN : Gp;
+    HIPCHK(ctx, hipMemcpyAsync(dgam, compressed ? hnodes.data() : a->gammas, sizeof(double) * (compressed ? SWEEP_GN : G), hipMemcpyHostToDevice,
+                               ctx->stream));
     const long tot = (long)Np * Gr;
     hipLaunchKernelGGL(k_rgrid, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, lam, dgam, D1, compressed ? SWEEP_GN : G, Np,
                        Gr, R);

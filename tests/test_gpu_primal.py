@@ -315,3 +315,19 @@ def test_single_rank_rccl_communicator(golden_loader, hp):
         ctx.comm_destroy()
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("name", ["primal_reg_n3000_d20_D256", "primal_clf_n3000_d16_D256_wz"])
+def test_compressed_sweep_equals_direct_products(name, golden_loader, hp, monkeypatch):
+    """The 1024-point sweep through 128 Chebyshev nodes (default) against the direct n x (D+1) x G products."""
+    g = golden_loader(name)
+    y, is_clf = signed_targets(g), g["task"] == "clf"
+    rc = hp.primal_fit(g["X"], y, g["s"], g["shift"], g["scale"], g["B"], is_clf)
+    monkeypatch.setenv("NLS_SWEEP_DIRECT", "1")
+    rd = hp.primal_fit(g["X"], y, g["s"], g["shift"], g["scale"], g["B"], is_clf)
+    assert rc["opt"] == rd["opt"]
+    assert relerr(rc["loo_errors_gammas"], rd["loo_errors_gammas"]) < 1e-12
+    assert relerr(rc["objective"], rd["objective"]) < 1e-12
+    for k in ("loo_residuals", "loo_leverage", "loo_std"):
+        assert relerr(rc[k], rd[k]) < 1e-11, k
+    assert np.array_equal(rc["beta"], rd["beta"])  # the re-solve does not depend on the sweep

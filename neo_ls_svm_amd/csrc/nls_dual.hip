@@ -151,7 +151,12 @@ extern "C" int nls_dual_fit(nls_ctx* ctx, const nls_dual_fit_args* a) {
     NLSCHK(evd_symmetric(ctx, Q, (int)n, lam, evd_e, dinfo, &Qev));
   }
   // ---- D3: reduced sweep -------------------------------------------------------------------------
-  double *T = nullptr, *HD = nullptr, *AG = nullptr, *FA = nullptr;
+  double *T = nullptr, *HD = nullptr, *AG = nullptr, *FA = nullptr, *SG = nullptr;
+  // (Kt W)^2 lives in the buffer the EVD has consumed (its eigenvectors are in the EVD's own workspace, or - rocSOLVER
+  // path - in Q itself, in which case a separate buffer is taken); the Cholesky stage reuses Q only after the sweep.
+  double* KW2 = Q;
+  if (Qev == Q) NLSCHK(ws_get_t(ctx, "dual.KW2", NN, &KW2));
+  NLSCHK(ws_get_t(ctx, "dual.SG", (size_t)n_pad * Gp, &SG));
   NLSCHK(ws_get_t(ctx, "dual.T", (size_t)n_pad * Gp, &T));
   NLSCHK(ws_get_t(ctx, "dual.HD", (size_t)n_pad * Gp, &HD));
   NLSCHK(ws_get_t(ctx, "dual.AG", (size_t)n_pad * Gp, &AG));
@@ -163,7 +168,15 @@ extern "C" int nls_dual_fit(nls_ctx* ctx, const nls_dual_fit_args* a) {
     hipLaunchKernelGGL(k_zero_diag_copy, grid2(n_pad, n_pad), dim3(256), 0, ctx->stream, F, n_pad, n_pad, n, F0);
     HIPCHK(ctx, hipGetLastError());
     NLSCHK(gemm_store(ctx, F0, n_pad, W, n_pad, M, n_pad, n_pad, n_pad, n_pad));
-    hipLaunchKernelGGL(k_dual_hadamards, grid2(n_pad, n_pad), dim3(256), 0, ctx->stream, W, M, qy, n, n_pad, M, WW, WQ);
+    // column sums of W for Kt W = M + 2 W - 1 cs (see k_dual_hadamards)
+    const long cchunks = std::min<long>(64, (n + 127) / 128), crows = (n + cchunks - 1) / cchunks;
+    double *cpart2 = nullptr, *cs = nullptr;
+    NLSCHK(ws_get_t(ctx, "dual.cpart", (size_t)cchunks * n_pad, &cpart2));
+    NLSCHK(ws_get_t(ctx, "dual.cs", (size_t)n_pad, &cs));
+    hipLaunchKernelGGL(k_col_partial_sums, dim3((unsigned)((n_pad + 255) / 256), (unsigned)cchunks), dim3(256), 0, ctx->stream, W, n, n_pad,
+                       crows, cpart2);
+    hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, ctx->stream, cpart2, cchunks, n_pad, cs, 0);
+    hipLaunchKernelGGL(k_dual_hadamards, grid2(n_pad, n_pad), dim3(256), 0, ctx->stream, W, M, qy, cs, n, n_pad, M, WW, WQ, KW2);
     HIPCHK(ctx, hipGetLastError());
     tm[NLS_T_ROTATE_LAUNCHES] += 1;
     tm[NLS_T_ROTATE_FLOPS] += 2.0 * n * n * n;
@@ -177,10 +190,11 @@ extern "C" int nls_dual_fit(nls_ctx* ctx, const nls_dual_fit_args* a) {
     NLSCHK(gemm_store(ctx, WW, n_pad, R, Gp, HD, Gp, n_pad, Gp, n_pad));
     NLSCHK(gemm_store(ctx, WQ, n_pad, R, Gp, AG, Gp, n_pad, Gp, n_pad));
     NLSCHK(gemm_store(ctx, F0, n_pad, AG, Gp, FA, Gp, n_pad, Gp, n_pad));
+    NLSCHK(gemm_store(ctx, KW2, n_pad, R, Gp, SG, Gp, n_pad, Gp, n_pad));  // sum_j (Kt W)_ij^2 / (gamma_g + lam_j): 1 - sigma^2 on the grid
     hipLaunchKernelGGL(k_dual_yloo, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, T, HD, AG, FA, tot);
     HIPCHK(ctx, hipGetLastError());
-    tm[NLS_T_SWEEP_LAUNCHES] += 4;
-    tm[NLS_T_SWEEP_FLOPS] += 8.0 * n * n * G;
+    tm[NLS_T_SWEEP_LAUNCHES] += 5;
+    tm[NLS_T_SWEEP_FLOPS] += 10.0 * n * n * G;
   }
   // ---- D4: selection -----------------------------------------------------------------------------
   const long nblk = (n + 63) / 64;
@@ -228,29 +242,23 @@ extern "C" int nls_dual_fit(nls_ctx* ctx, const nls_dual_fit_args* a) {
   HIPCHK(ctx, hipMemcpyAsync(hsum, csum, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
 
   // ---- D5: Cholesky re-solve, residuals, sigma -----------------------------------------------------
-  double* M2 = Q;   // n x n, Q is dead
-  double* Kp = W;   // n x n, W is dead
-  double* Z = WW;   // n x n
+  double* M2 = Q;  // n x n, Q is dead
   {
     SpanGuard g(ctx, NLS_T_CHOLESKY);
-    hipLaunchKernelGGL(k_dual_chol_inputs, grid2(n, n), dim3(256), 0, ctx->stream, F, n_pad, d_sn, n, gamma_opt, M2, Kp);
+    hipLaunchKernelGGL(k_dual_chol_inputs, grid2(n, n), dim3(256), 0, ctx->stream, F, n_pad, d_sn, n, gamma_opt, M2, (double*)nullptr);
     HIPCHK(ctx, hipGetLastError());
     BLASCHK(ctx, rocsolver_dpotrf(ctx->blas, rocblas_fill_lower, (rocblas_int)n, M2, (rocblas_int)n, dinfo));
     NLSCHK(check_info(ctx, dinfo, "rocsolver_dpotrf"));
     HIPCHK(ctx, hipMemcpyAsync(alpha, dy, sizeof(double) * n, hipMemcpyDeviceToDevice, ctx->stream));
     BLASCHK(ctx, rocsolver_dpotrs(ctx->blas, rocblas_fill_lower, (rocblas_int)n, 1, M2, (rocblas_int)n, alpha, (rocblas_int)n));
-    // sigma needs diag(Kp M^-1 Kp^T) only: one triangular solve Z = L^-1 Kp (Kp symmetric) and column norms,
-    // sigma2_i = 1 - ||Z[:, i]||^2, instead of the two solves of cho_solve (_neo_ls_svm.py:321-322) - half the flops.
-    const double one = 1.0;
-    HIPCHK(ctx, hipMemcpyAsync(Z, Kp, sizeof(double) * n * n, hipMemcpyDeviceToDevice, ctx->stream));
-    BLASCHK(ctx, rocblas_dtrsm(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit,
-                               (rocblas_int)n, (rocblas_int)n, &one, M2, (rocblas_int)n, Z, (rocblas_int)n));
   }
   {
     SpanGuard g(ctx, NLS_T_RESIDUALS);
     hipLaunchKernelGGL(k_dual_gemv, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, F, n_pad, n, n, alpha, 0.0, dy, is_clf, res);
-    // column i of the column-major Z is row i of the buffer read row-major
-    hipLaunchKernelGGL(k_dual_sigma, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, Z, Z, n, n, n, sig);
+    // sigma^2 = 1 - diag(Kt M^-1 Kt^T) (_neo_ls_svm.py:321-322) with M^-1 = W (gamma + Lam)^-1 W^T from the eigendecomposition the
+    // sweep already has: the selected column of SG.  The reference's n x n cho_solve (one 10^12-flop triangular solve here in round 1)
+    // is not needed for it; L is still factorised for alpha and returned as L_.
+    hipLaunchKernelGGL(k_dual_sigma_col, dim3((unsigned)cblk), dim3(256), 0, ctx->stream, SG, Gp, opt, n, sig);
     HIPCHK(ctx, hipGetLastError());
   }
   {

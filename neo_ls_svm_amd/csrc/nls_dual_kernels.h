@@ -128,17 +128,39 @@ __global__ void k_dual_qty(const double* Qcm, long n, const double* sn, const do
   if (threadIdx.x == 0) qy[k] = sh[0];
 }
 
-// The three left operands of the reduced sweep (D3): WM = W o M, WW = W o W, WQ = W o qy^T (in place on M ok).
-__global__ void k_dual_hadamards(const double* W, const double* M, const double* qy, long n, long n_pad, double* WM,
-                                 double* WW, double* WQ) {
+// The left operands of the reduced sweep (D3): WM = W o M, WW = W o W, WQ = W o qy^T (in place on M ok), and for the
+// predictive variance (D5) KW2 = (Kt W)^2 elementwise with Kt = rbf(X_, 1/2) = F - 1:  Kt W = F0 W + 2 W - 1 colsum(W)
+// (F = F0 + 2 I: the kernel's unit diagonal plus the + 1), i.e. M + 2 W - cs, everything the sweep has at hand anyway.
+__global__ void k_dual_hadamards(const double* W, const double* M, const double* qy, const double* cs, long n, long n_pad, double* WM,
+                                 double* WW, double* WQ, double* KW2) {
   const long k = blockIdx.x * (long)blockDim.x + threadIdx.x;
   const long i = blockIdx.y;
   if (k >= n_pad || i >= n_pad) return;
   const long o = i * n_pad + k;
-  const double w = W[o];
-  WM[o] = w * M[o];
+  const double w = W[o], m = M[o];
+  const double kw = (i < n && k < n) ? m + 2.0 * w - cs[k] : 0.0;
+  WM[o] = w * m;
   WW[o] = w * w;
   WQ[o] = (k < n) ? w * qy[k] : 0.0;
+  KW2[o] = kw * kw;
+}
+
+// part[chunk][k] = sum of W[i][k] over the rows of the chunk (column sums in two steps: k_sum_partials finishes).
+__global__ void k_col_partial_sums(const double* W, long n, long ld, long rows_per_chunk, double* part) {
+  const long k = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (k >= ld) return;
+  const long r0 = (long)blockIdx.y * rows_per_chunk;
+  long r1 = r0 + rows_per_chunk;
+  if (r1 > n) r1 = n;
+  double a = 0.0;
+  for (long i = r0; i < r1; ++i) a += W[i * ld + k];
+  part[(long)blockIdx.y * ld + k] = a;
+}
+
+// sigma_i = sqrt(1 - SG[i][g]) : the predictive standard deviation at the selected gamma from the sweep's table.
+__global__ void k_dual_sigma_col(const double* SG, int Gp, int g, long n, double* out) {
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i < n) out[i] = sqrt(1.0 - SG[i * Gp + g]);
 }
 
 // yloo = -(t / hd) a + Fa with hd == 0 -> eps (_neo_ls_svm.py:279-286), in place into t.

@@ -77,6 +77,12 @@ class _StdoutToStderr:
         return self
 
     def __exit__(self, *exc):
+        import ctypes
+
+        try:  # the banner sits in the C library's stdout buffer (fully buffered on a pipe): push it out while fd 1 is stderr
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         os.dup2(self.saved, 1)
         os.close(self.saved)
         return False

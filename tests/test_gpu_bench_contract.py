@@ -1,0 +1,54 @@
+"""bench.py's output contract on the small plumbing configuration (GPU): one JSON line with the fields the driver reads,
+the executed-flops roofline, the K1 roofline and the CPU baseline; and the same run through a one-rank RCCL communicator
+(file rendezvous + nls_comm_init_rank + barrier / max collectives, exactly what an N-rank launch does per rank)."""
+from __future__ import annotations
+
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+pytestmark = pytest.mark.gpu
+
+
+def run_bench(extra_env=None, args=()):
+    env = dict(os.environ, **(extra_env or {}))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--config", "c0", "--steps", "2", "--warmup", "1", *args], env=env,
+                       capture_output=True, text=True, timeout=900)  # fmt: skip
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, f"stdout must be exactly one line, got {len(lines)}: {r.stdout[:500]}"
+    return json.loads(lines[0])
+
+
+def test_bench_line_contract():
+    d = run_bench()
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):  # fmt: skip
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["dtype"] == "f64" and d["data"] == "synthetic"
+    assert d["vs_baseline"] is None and d["higher_is_better"] is True and "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+    ro = d["roofline"]
+    assert ro["bound"] == "mfma" and ro["unit"] == "TFLOP/s" and ro["peak"] == 78.6 and abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-12
+    assert 0 < ro["frac"] < 1.0, "frac is the matrix-pipe utilisation: executed flops / time / peak"
+    assert 1.0 < ro["algorithmic_gain"] < 1.5
+    k1 = d["roofline_k1"]
+    assert k1["bound"] == "hbm" and k1["unit"] == "GB/s" and k1["peak"] == 8000.0 and 0 < k1["frac"] < 1
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["unit"] == "fits/s" and cb["cores"] >= 1 and cb["host_cpus"] >= cb["cores"] and "mode" in cb and "sample" in cb
+    assert cb["value"] > 0 and "seconds_mode_R" in cb and "seconds_mode_S" in cb  # c0 fits host RAM: both schedules at full size
+    assert d["value_pcie_inclusive"] and d["value_pcie_inclusive"] <= d["value"] * 1.2
+
+
+def test_bench_through_a_one_rank_rccl_communicator(tmp_path):
+    d = run_bench({"NLS_BENCH_FORCE_COMM": "1", "NLS_RENDEZVOUS_DIR": str(tmp_path)}, args=("--no-cpu-baseline",))
+    assert d["n_gpus"] == 1 and d["cpu_baseline"] is None and d["value"] > 0
+    assert d["stage_ms_per_step"]["allreduce"] > 0.0  # the collectives really ran (RCCL on the device buffers)
+    assert not list(tmp_path.iterdir()), "rank 0 removes the rendezvous file"

@@ -219,7 +219,7 @@ class DeviceArray:
         ctx._check(ctx.lib.nls_device_malloc(ctx.handle, max(self.nbytes, 8), C.byref(p)))
         self.ptr = p.value
 
-    # Lets torch / cupy wrap the buffer without a copy (used for the RCCL all-reduce of A||b).
+    # Lets an array library (cupy, ...) wrap the buffer without a copy.
     @property
     def __cuda_array_interface__(self):
         return {"shape": self.shape, "typestr": "<f8", "data": (self.ptr, False), "version": 2, "strides": None}

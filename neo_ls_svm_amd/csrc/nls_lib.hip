@@ -175,6 +175,7 @@ extern "C" void nls_ctx_destroy(nls_ctx* ctx) {
   (void)nls_comm_destroy(ctx);
   if (ctx->comm_scratch) (void)hipFree(ctx->comm_scratch);
   for (nls_factor* f : ctx->factors) factor_free(f);
+  for (auto& kv : ctx->graphs) (void)hipGraphExecDestroy(kv.second);
   for (auto& kv : ctx->ws)
     if (kv.second.p) (void)hipFree(kv.second.p);
   for (auto ev : ctx->event_pool) (void)hipEventDestroy(ev);
@@ -206,6 +207,8 @@ extern "C" int nls_ws_release(nls_ctx* ctx, size_t min_bytes, size_t* still_held
   if (!ctx) return NLS_ERR_ARG;
   HIPCHK(ctx, hipSetDevice(ctx->device));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  for (auto& kv : ctx->graphs) (void)hipGraphExecDestroy(kv.second);  // they hold addresses of the buffers that go away
+  ctx->graphs.clear();
   for (auto it = ctx->ws.begin(); it != ctx->ws.end();) {
     if (it->second.p && it->second.bytes >= min_bytes) {
       HIPCHK(ctx, hipFree(it->second.p));

@@ -488,7 +488,7 @@ __device__ __forceinline__ PrevScalars<T> prev_scalars(const Args<T>& a, T* slot
 }
 
 template <class T>
-__global__ void __launch_bounds__(256, 2) k_trd_hemv2(Args<T> a, int S0, int ntiles) {
+__device__ __forceinline__ void trd_hemv2_body(const Args<T>& a, int S0, int ntiles, int bid) {
   __shared__ T sh[4][TS];
   __shared__ T slot;
   const int n = a.n, j = a.j, i = a.j - a.j0;
@@ -502,10 +502,10 @@ __global__ void __launch_bounds__(256, 2) k_trd_hemv2(Args<T> a, int S0, int nti
     if (q <= j || q >= n) return make_<T>(0.0, 0.0);
     return i > 0 ? a.bvec[q] + ps.mu * a.A[q + (long)(j - 1) * a.lda] : a.A[q + (long)j * a.lda];
   };
-  if ((int)blockIdx.x < ntiles) {
+  if (bid < ntiles) {
     // Odd columns walk the tiles backwards: a trailing matrix larger than the 256 MB Infinity Cache (real n = 10^4: 400 MB of
     // lower triangle) then starts each column on the tiles the previous column touched last, which are still resident.
-    int t = (a.boustrophedon && (a.j & 1)) ? ntiles - 1 - (int)blockIdx.x : (int)blockIdx.x, Rr = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+    int t = (a.boustrophedon && (a.j & 1)) ? ntiles - 1 - bid : bid, Rr = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
     while ((Rr + 1) * (Rr + 2) / 2 <= t) ++Rr;
     while (Rr * (Rr + 1) / 2 > t) --Rr;
     const int R = S0 + Rr, C = S0 + (t - Rr * (Rr + 1) / 2);
@@ -543,7 +543,7 @@ __global__ void __launch_bounds__(256, 2) k_trd_hemv2(Args<T> a, int S0, int nti
     if (w == 0 && r < n) a.ylow[(long)C * n + r] = ((sh[0][lane] + sh[1][lane]) + sh[2][lane]) + sh[3][lane];
   } else {
     // dot block b: rows j + 64 b + lane (row j itself included: it carries d[j]); wave w: panel columns p = w, w + 4, ...
-    const int b = blockIdx.x - ntiles;
+    const int b = bid - ntiles;
     const long r = (long)j + (long)b * RD + lane;
     const bool inrange = r < n;
     T xfull = make_<T>(0.0, 0.0), wt = make_<T>(0.0, 0.0), vprev = make_<T>(0.0, 0.0);
@@ -597,15 +597,19 @@ __global__ void __launch_bounds__(256, 2) k_trd_hemv2(Args<T> a, int S0, int nti
     }
   }
 }
+template <class T>
+__global__ void __launch_bounds__(256, 2) k_trd_hemv2(Args<T> a, int S0, int ntiles) {
+  trd_hemv2_body<T>(a, S0, ntiles, (int)blockIdx.x);
+}
 
 template <class T>
-__global__ void __launch_bounds__(ROWT * TPR) k_trd_finish2(Args<T> a, int S0, int NS) {
+__device__ __forceinline__ void trd_finish2_body(const Args<T>& a, int S0, int NS, int bid) {
   __shared__ T zsh[4][2 * NB], zw[NB], zv[NB], wj1[NB], vj1[NB], red[ROWT];
   __shared__ double dslot;
   constexpr int PPT = NB / TPR;
   const int n = a.n, j = a.j, i = a.j - a.j0;
   const int q = threadIdx.x % TPR, rl = threadIdx.x / TPR;
-  const long r = (long)blockIdx.x * ROWT + rl;
+  const long r = (long)bid * ROWT + rl;
   const bool live = r < n && r >= j + 1;
   // ---- loads
   double pn = 0.0;
@@ -713,18 +717,26 @@ __global__ void __launch_bounds__(ROWT * TPR) k_trd_finish2(Args<T> a, int S0, i
   __syncthreads();
   if (threadIdx.x < 64) {
     const T t = wave_sum(sel_(threadIdx.x < ROWT, red[threadIdx.x % ROWT], make_<T>(0.0, 0.0)));
-    if (threadIdx.x == 0) a.spart[blockIdx.x] = t;
+    if (threadIdx.x == 0) a.spart[bid] = t;
   }
+}
+template <class T>
+__global__ void __launch_bounds__(ROWT * TPR) k_trd_finish2(Args<T> a, int S0, int NS) {
+  trd_finish2_body<T>(a, S0, NS, (int)blockIdx.x);
 }
 
 // End of a panel (last column jl): finish column jl - j0 of W for the rows the rank-2nb update reads.
 template <class T>
-__global__ void k_trd_panel_end(Args<T> a, int jl) {
+__device__ __forceinline__ void trd_panel_end_body(const Args<T>& a, int jl, int bid) {
   __shared__ T slot;
-  const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long r = (long)bid * blockDim.x + threadIdx.x;
   const T alpha2 = (-0.5) * (a.tau[jl] * sum_partials(a.spart, a.nrowblocks, &slot));
   if (r >= a.n || r <= jl) return;
   a.W[r + (long)(jl - a.j0) * a.n] = a.wtmp[r] + alpha2 * a.A[r + (long)jl * a.lda];
+}
+template <class T>
+__global__ void k_trd_panel_end(Args<T> a, int jl) {
+  trd_panel_end_body<T>(a, jl, (int)blockIdx.x);
 }
 // Trailing update of a panel:  C -= V2 W2^H + W2 V2^H  on the lower triangle of C = A[jend:, jend:], with
 // V2 = A[jend:, j0 : j0 + nb] and W2 = W[jend:, 0 : nb]  (zher2k / dsyr2k of zhetrd).  rocBLAS runs this rank-2nb
@@ -733,9 +745,9 @@ __global__ void k_trd_panel_end(Args<T> a, int jl) {
 // each thread accumulates a 4 x 4 block in registers.
 constexpr int UT = 64, UK = 16;
 template <class T>
-__global__ void __launch_bounds__(256) k_trd_rank2k(T* A, long lda, const T* W, long ldw, int n, int j0, int nb, int jend) {
+__device__ __forceinline__ void trd_rank2k_body(T* A, long lda, const T* W, long ldw, int n, int j0, int nb, int jend, int bid) {
   __shared__ T Vr[UK][UT], Wr[UK][UT], Vc[UK][UT], Wc[UK][UT];
-  int t = blockIdx.x, R = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+  int t = bid, R = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
   while ((R + 1) * (R + 2) / 2 <= t) ++R;
   while (R * (R + 1) / 2 > t) --R;
   const int C = t - R * (R + 1) / 2;
@@ -787,12 +799,140 @@ __global__ void __launch_bounds__(256) k_trd_rank2k(T* A, long lda, const T* W, 
       }
     }
 }
+template <class T>
+__global__ void __launch_bounds__(256) k_trd_rank2k(T* A, long lda, const T* W, long ldw, int n, int j0, int nb, int jend) {
+  trd_rank2k_body<T>(A, lda, W, ldw, n, j0, nb, jend, (int)blockIdx.x);
+}
 
 // After the trailing update: put e back on the sub-diagonal of the panel's columns (LAPACK layout).
 template <class T>
 __global__ void k_trd_restore_subdiag(T* A, long lda, const double* e, int j0, int cnt) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p < cnt) A[(long)(j0 + p + 1) + (long)(j0 + p) * lda] = make_<T>(e[j0 + p], 0.0);
+}
+
+// ================================================================================================================
+// Persistent panel (opt-in diagnostic, NLS_TRD_PERSIST_MAX).  Up to n ~ 2000 a column is not bound by its arithmetic or its
+// traffic but by the two dependent kernel boundaries it crosses (n = 1025: 9 us of kernel time in 18 us of wall time per
+// column; a hipGraph of the same launches changes nothing - the cost is on the GPU side, profiles/r02_trd_graph.log).  Here the
+// WHOLE tridiagonalisation is one launch of a few workgroups that walk the same sequence of phases - matrix-vector tiles, row
+// blocks, panel end, trailing update - as "virtual blocks" of the bodies above, separated by a device-wide barrier (one
+// atomic counter, relaxed polling between a release and an acquire).  The arithmetic and its order are those of the
+// two-kernel variant: results are bit-identical (tests/test_gpu_evd.py).  MEASURED SLOWER than separate launches on this
+// chip (profiles/r02_trd_persistent.log): the cache maintenance a software barrier needs costs more than a kernel boundary.
+// A workgroup that waits longer than ~2 s raises ctl[1] and everybody leaves (the host reports an error): no hang.
+// ================================================================================================================
+// ONE_XCD: all participating workgroups sit on one XCD and share its L2, so the release side needs no L2 write-back: stores are
+// complete in L2 once vmcnt has drained (the vector L1 is write-through).  The acquire side still needs buffer_inv sc1 -
+// buffer_inv sc0 does NOT drop the CU's L1 here (measured: wrong results) - which keeps this variant at 25 ms for n = 1025
+// against 33 ms chip-wide and 18.5 ms for the launch-per-kernel panel.
+template <bool ONE_XCD>
+__device__ __forceinline__ bool trd_grid_barrier(unsigned* ctl, unsigned nwg, unsigned& epoch) {
+  __shared__ int ok_sh;
+  // release side (every wave): its own stores performed
+  if (!ONE_XCD) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");    // + written back past the L2
+  else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // acknowledged by the (shared) L2
+  __syncthreads();
+  ++epoch;
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int ok = 1;
+    unsigned spins = 0;
+    while (__hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch * nwg) {
+      if (__hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+        ok = 0;
+        break;
+      }
+      if (++spins > 4000000u) {
+        __hip_atomic_store(ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = 0;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    ok_sh = ok;
+  }
+  __syncthreads();
+  // acquire side (every wave)
+  if (!ONE_XCD) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  else asm volatile("buffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
+  return ok_sh != 0;
+}
+
+// ONE_XCD: launched with 8 x the workgroups; only those the dispatcher places on XCD 0 (blockIdx % 8 == 0, round-robin) take part.
+// The placement is VERIFIED, not assumed: every participant records the XCC_ID hardware register and a mismatch makes all of them
+// leave with ctl[1] = 2 before anything is written - the host then runs the launch-per-kernel panel.
+template <class T, bool ONE_XCD>
+__global__ void __launch_bounds__(256, 1)
+    k_trd_persistent(Args<T> a, T* wt0, T* wt1, T* sp0, T* sp1, int NSC, int NSR, unsigned* ctl) {
+  int nwg = gridDim.x, wg = blockIdx.x;
+  unsigned epoch = 0;
+  if (ONE_XCD) {
+    if ((blockIdx.x & 7u) != 0u) return;
+    nwg >>= 3;
+    wg >>= 3;
+    if (threadIdx.x == 0) {
+      const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xfu;  // HW_REG_XCC_ID[3:0]
+      __hip_atomic_fetch_min(ctl + 2, xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_max(ctl + 3, xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!trd_grid_barrier<ONE_XCD>(ctl, nwg, epoch)) return;
+    if (__hip_atomic_load(ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != __hip_atomic_load(ctl + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+      if (threadIdx.x == 0) __hip_atomic_store(ctl + 1, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+  }
+  const int n = a.n;
+  T* wt[2] = {wt0, wt1};
+  T* sp[2] = {sp0, sp1};
+  int cur = 0;
+  for (int j0 = 0; j0 < n; j0 += NB) {
+    const int jend = j0 + NB < n ? j0 + NB : n;
+    a.j0 = j0;
+    for (int j = j0; j < jend; ++j) {
+      a.j = j;
+      const int S0 = (j + 1) / TS, K = NSC - S0, ntiles = j < n - 1 ? K * (K + 1) / 2 : 0;
+      a.wtmp = wt[cur];
+      a.spart = sp[cur];
+      a.wtmp_prev = wt[cur ^ 1];
+      a.spart_prev = sp[cur ^ 1];
+      a.ndot = (n - j + RD - 1) / RD;
+      a.make_base = j + 1 < jend;
+      for (int vb = wg; vb < ntiles + a.ndot; vb += nwg) {
+        trd_hemv2_body<T>(a, S0, ntiles, vb);
+        __syncthreads();
+      }
+      if (!trd_grid_barrier<ONE_XCD>(ctl, nwg, epoch)) return;
+      if (j < n - 1) {
+        for (int vb = wg; vb < a.nrowblocks; vb += nwg) {
+          trd_finish2_body<T>(a, S0, NSR, vb);
+          __syncthreads();
+        }
+        if (!trd_grid_barrier<ONE_XCD>(ctl, nwg, epoch)) return;
+        cur ^= 1;
+      }
+    }
+    const int jl = jend - 1 < n - 2 ? jend - 1 : n - 2, n2 = n - jend;
+    if (n2 > 0) {
+      Args<T> ae = a;  // the last finished column wrote the buffers that are "previous" now
+      ae.wtmp = wt[cur ^ 1];
+      ae.spart = sp[cur ^ 1];
+      for (int vb = wg; vb < (n + 255) / 256; vb += nwg) {
+        trd_panel_end_body<T>(ae, jl, vb);
+        __syncthreads();
+      }
+      if (!trd_grid_barrier<ONE_XCD>(ctl, nwg, epoch)) return;
+      const int ut = (n2 + UT - 1) / UT;
+      for (int vb = wg; vb < ut * (ut + 1) / 2; vb += nwg) {
+        trd_rank2k_body<T>(a.A, a.lda, a.W, (long)n, n, j0, jend - j0, jend, vb);
+        __syncthreads();
+      }
+      if (!trd_grid_barrier<ONE_XCD>(ctl, nwg, epoch)) return;
+    }
+    if (jl >= j0 && wg == 0 && (int)threadIdx.x < jl - j0 + 1)
+      a.A[(long)(j0 + threadIdx.x + 1) + (long)(j0 + threadIdx.x) * a.lda] = make_<T>(a.e[j0 + threadIdx.x], 0.0);
+    if (jend < n && !trd_grid_barrier<ONE_XCD>(ctl, nwg, epoch)) return;
+  }
 }
 
 // ---- back-transformation  C <- Q C,  Q = H_0 H_1 ... H_{n-2}  (zunmtr / dormtr, left, lower, no transpose) --------------

@@ -256,6 +256,29 @@ def _ptr(a):
     return a.ctypes.data
 
 
+class _StdoutToStderr:
+    """librccl prints a version banner on file descriptor 1 when the first communicator is created (and leaves it in the C
+    library's stdout buffer when that is a pipe); a driver that parses this process's stdout - bench.py's one JSON line -
+    must not see it.  While active, fd 1 points at stderr; on exit the C buffers are flushed before fd 1 is restored."""
+
+    def __enter__(self):
+        import sys
+
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        try:
+            C.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 class Factor:
     """Device-resident inverse of one fitted Cholesky factor ``L_`` (``nls_factor_create``): what repeated
     ``predict_std`` calls reuse instead of uploading and inverting (D+1)^2 complex numbers every time.  Explicit state:
@@ -326,7 +349,8 @@ class Context:
     def comm_unique_id(self) -> bytes:
         """Rank 0: a fresh communicator id (128 bytes) to hand to the other ranks (file, socket, env ...)."""
         buf = C.create_string_buffer(COMM_ID_BYTES)
-        rc = self.lib.nls_comm_get_unique_id(buf)
+        with _StdoutToStderr():
+            rc = self.lib.nls_comm_get_unique_id(buf)
         if rc != NLS_OK:
             msg = self.lib.nls_last_error(None)
             raise NlsError(f"nls_comm_get_unique_id failed: {msg.decode() if msg else rc}")
@@ -337,7 +361,9 @@ class Context:
         rank's block of a row-sharded problem."""
         if len(unique_id) != COMM_ID_BYTES:
             raise ValueError(f"unique_id must be {COMM_ID_BYTES} bytes")
-        self._check(self.lib.nls_comm_init_rank(self.handle, C.c_char_p(unique_id), int(rank), int(world)))
+        with _StdoutToStderr():
+            rc = self.lib.nls_comm_init_rank(self.handle, C.c_char_p(unique_id), int(rank), int(world))
+        self._check(rc)
 
     def comm_destroy(self):
         self._check(self.lib.nls_comm_destroy(self.handle))

@@ -64,38 +64,13 @@ def exchange_unique_id(ctx, rank: int, world: int, key: str | None = None, timeo
         time.sleep(0.02)
 
 
-class _StdoutToStderr:
-    """librccl prints a version banner on file descriptor 1 when the first communicator is created; a driver that parses
-    this process's stdout (bench.py's one JSON line) must not see it."""
-
-    def __enter__(self):
-        import sys
-
-        sys.stdout.flush()
-        self.saved = os.dup(1)
-        os.dup2(2, 1)
-        return self
-
-    def __exit__(self, *exc):
-        import ctypes
-
-        try:  # the banner sits in the C library's stdout buffer (fully buffered on a pipe): push it out while fd 1 is stderr
-            ctypes.CDLL(None).fflush(None)
-        except Exception:
-            pass
-        os.dup2(self.saved, 1)
-        os.close(self.saved)
-        return False
-
-
 def init_from_env(ctx, key: str | None = None) -> tuple[int, int]:
     """Join ``ctx`` to the RCCL communicator of the launch described by RANK / WORLD_SIZE; returns (rank, world).
     World size 1 also goes through RCCL (a one-rank communicator), so the collective code path is the one that runs."""
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-    with _StdoutToStderr():
-        uid = exchange_unique_id(ctx, rank, world, key)
-        ctx.comm_init(uid, rank, world)
-        ctx.comm_barrier()
+    uid = exchange_unique_id(ctx, rank, world, key)
+    ctx.comm_init(uid, rank, world)  # (librccl's version banner is kept off this process's stdout, see Context.comm_init)
+    ctx.comm_barrier()
     if rank == 0:  # everyone has read the id once the barrier returns
         try:
             _rendezvous_file(key).unlink()

@@ -331,3 +331,41 @@ def test_compressed_sweep_equals_direct_products(name, golden_loader, hp, monkey
     for k in ("loo_residuals", "loo_leverage", "loo_std"):
         assert relerr(rc[k], rd[k]) < 1e-11, k
     assert np.array_equal(rc["beta"], rd["beta"])  # the re-solve does not depend on the sweep
+
+
+def test_c_abi_edge_cases_of_the_round2_entry_points(golden_loader, hp):
+    """Device-pointer L for nls_factor_create, the communicator / hook exclusivity, size limits of the utility collective."""
+    import ctypes as C
+
+    g = golden_loader("primal_reg_n2000_d48_D32")
+    y = signed_targets(g)
+    ctx = hp.Context(0)
+    try:
+        r = hp.primal_fit(g["X"], y, g["s"], g["shift"], g["scale"], g["B"], False, ctx=ctx)
+        L = np.ascontiguousarray(r["L"])
+        D = L.shape[0] - 1
+        dL = ctx.to_device(L.view(np.float64))  # the factor may already be resident
+        h = C.c_void_p()
+        ctx._check(ctx.lib.nls_factor_create(ctx.handle, C.c_void_p(dL.ptr), D, C.byref(h)))
+        f = hp.Factor.__new__(hp.Factor)
+        f.ctx, f.D, f.handle = ctx, D, h
+        _, s_dev = hp.primal_predict(g["Xq"], g["shift"], g["scale"], g["B"], factor=f, ctx=ctx)
+        _, s_host = hp.primal_predict(g["Xq"], g["shift"], g["scale"], g["B"], L=L, ctx=ctx)
+        assert np.array_equal(s_dev, s_host) and relerr(s_dev, g["predict_std"]) < TOL
+        f.close()
+        assert ctx.lib.nls_factor_destroy(ctx.handle, h) != 0  # already destroyed: not a live handle any more
+        with pytest.raises(ValueError):
+            hp.Factor(ctx, np.eye(3)[:2])  # not square
+        # a context with a native communicator refuses a hook, and the utility collective has a size limit
+        ctx.comm_init(ctx.comm_unique_id(), 0, 1)
+        with pytest.raises(ValueError):
+            ctx.set_allreduce(lambda p, c: None, 0, 2)
+        with pytest.raises(ValueError):
+            ctx.comm_allreduce(np.zeros(9000))
+        assert np.array_equal(ctx.comm_allreduce(np.arange(5.0), "sum"), np.arange(5.0))
+        ctx.comm_destroy()
+        ctx.set_allreduce(None, 0, 1)  # fine again once the communicator is gone
+        with pytest.raises(ValueError):
+            ctx.comm_init(b"short", 0, 1)
+    finally:
+        ctx.close()

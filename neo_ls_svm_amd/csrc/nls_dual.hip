@@ -175,7 +175,7 @@ extern "C" int nls_dual_fit(nls_ctx* ctx, const nls_dual_fit_args* a) {
     NLSCHK(ws_get_t(ctx, "dual.cs", (size_t)n_pad, &cs));
     hipLaunchKernelGGL(k_col_partial_sums, dim3((unsigned)((n_pad + 255) / 256), (unsigned)cchunks), dim3(256), 0, ctx->stream, W, n, n_pad,
                        crows, cpart2);
-    hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, ctx->stream, cpart2, cchunks, n_pad, cs, 0);
+    hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)((n_pad + 31) / 32)), dim3(256), 0, ctx->stream, cpart2, cchunks, n_pad, cs, 0);
     hipLaunchKernelGGL(k_dual_hadamards, grid2(n_pad, n_pad), dim3(256), 0, ctx->stream, W, M, qy, cs, n, n_pad, M, WW, WQ, KW2);
     HIPCHK(ctx, hipGetLastError());
     tm[NLS_T_ROTATE_LAUNCHES] += 1;
@@ -204,7 +204,7 @@ extern "C" int nls_dual_fit(nls_ctx* ctx, const nls_dual_fit_args* a) {
   {
     SpanGuard g(ctx, NLS_T_LOO);
     hipLaunchKernelGGL(k_dual_errors, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, T, dy, d_s1, n, G, Gp, is_clf, part);
-    hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)((3 * Gp + 255) / 256)), dim3(256), 0, ctx->stream, part, nblk, 3L * Gp, errs);
+    hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)((3 * Gp + 31) / 32)), dim3(256), 0, ctx->stream, part, nblk, 3L * Gp, errs);
     HIPCHK(ctx, hipGetLastError());
   }
   std::vector<double> herrs((size_t)3 * Gp), hobj((size_t)G);
@@ -235,7 +235,7 @@ extern "C" int nls_dual_fit(nls_ctx* ctx, const nls_dual_fit_args* a) {
     SpanGuard g(ctx, NLS_T_LOO);
     hipLaunchKernelGGL(k_dual_column, dim3((unsigned)cblk), dim3(256), 0, ctx->stream, T, dy, d_s1, n, Gp, opt, is_clf, ybar, loo_res,
                        cpart);
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(64), 0, ctx->stream, cpart, cblk, 2L, csum);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, ctx->stream, cpart, cblk, 2L, csum);
     HIPCHK(ctx, hipGetLastError());
   }
   double hsum[2];

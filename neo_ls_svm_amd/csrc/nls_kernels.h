@@ -14,7 +14,7 @@
 
 namespace nls {
 
-constexpr int LOO_ROWS_PER_BLOCK = 256;
+constexpr int LOO_ROWS_PER_BLOCK = 256;  // upper bound; small problems take fewer rows per block so that the chip is filled
 
 // ------------------------------------------------------------------------------------------------
 // K1: feature map.  T = (X - shift) Bs on the matrix pipe (K = d), sincos on the vector pipe in the
@@ -514,12 +514,12 @@ __global__ void __launch_bounds__(Cfg4::NTHREADS, 2)
 // P6/P7: LOO residuals for every (row, gamma) and their weighted column sums.
 //   e = (num - y) / (1 - s^2 hs); classifier: zero on the correct side (_neo_ls_svm.py:153-155)
 //   part[blk][0][g] = sum s |e|, [1] = sum s [|e| >= 1], [2] = sum s max(0, |e| - 1)
-// grid.x = ceil(n / LOO_ROWS_PER_BLOCK), block = 256 threads striding over g.
+// grid.x = ceil(n / rows_per_block), block = 256 threads striding over g.
 // ------------------------------------------------------------------------------------------------
 __global__ void k_loo_errors(const double* num, const double* hs, const double* y, const double* s, long n, int G,
-                             int Gp, int is_clf, double* part) {
-  const long r0 = (long)blockIdx.x * LOO_ROWS_PER_BLOCK;
-  long r1 = r0 + LOO_ROWS_PER_BLOCK;
+                             int Gp, int is_clf, int rows_per_block, double* part) {
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  long r1 = r0 + rows_per_block;
   if (r1 > n) r1 = n;
   for (int g = threadIdx.x; g < G; g += blockDim.x) {
     double e0 = 0.0, e1 = 0.0, e2 = 0.0;
@@ -543,13 +543,24 @@ __global__ void k_loo_errors(const double* num, const double* hs, const double* 
   }
 }
 
-// out[idx] = (accumulate ? out[idx] : 0) + sum_blk part[blk][idx] in block order.
-__global__ void k_sum_partials(const double* part, long nblk, long width, double* out, int accumulate = 0) {
-  const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
-  if (idx >= width) return;
-  double v = accumulate ? out[idx] : 0.0;
-  for (long b = 0; b < nblk; ++b) v += part[b * width + idx];
-  out[idx] = v;
+// out[idx] = (accumulate ? out[idx] : 0) + sum_blk part[blk][idx].  256 threads = 32 outputs x 8 slices of the block range
+// (slice q takes blocks q, q + 8, ...), combined in a fixed order: bit-reproducible, and 8 loads in flight per output
+// instead of one dependent chain over all blocks.  Launch with 256 threads and grid.x = ceil(width / 32).
+__global__ void __launch_bounds__(256) k_sum_partials(const double* part, long nblk, long width, double* out, int accumulate = 0) {
+  __shared__ double sh[8][32];
+  const int o = threadIdx.x & 31, q = threadIdx.x >> 5;
+  const long idx = (long)blockIdx.x * 32 + o;
+  double v = 0.0;
+  if (idx < width)
+    for (long b = q; b < nblk; b += 8) v += part[b * width + idx];
+  sh[q][o] = v;
+  __syncthreads();
+  if (q == 0 && idx < width) {
+    double t = accumulate ? out[idx] : 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += sh[k][o];
+    out[idx] = t;
+  }
 }
 
 // Column of the selected gamma: P7 / P9 outputs and the score sums.

@@ -368,7 +368,7 @@ static int primal_prepare(nls_ctx* ctx, PrimalState& st, const double* X, const 
   HIPCHK(ctx, hipMemsetAsync(sums, 0, 4 * sizeof(double), ctx->stream));
   if (n > 0) {
     hipLaunchKernelGGL(k_weight_sums, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, st.ds, st.dy, n, part);
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(64), 0, ctx->stream, part, nblk, 2L, sums, 0);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, ctx->stream, part, nblk, 2L, sums, 0);
     HIPCHK(ctx, hipGetLastError());
   }
   double hn = (double)n;
@@ -459,7 +459,7 @@ static int primal_gram_phase(nls_ctx* ctx, PrimalState& st, double* timings) {
       const long bns = (rows + brps - 1) / brps;
       hipLaunchKernelGGL(k_border, dim3((unsigned)(mp.Kf / 128), (unsigned)bns), dim3(256), 0, ctx->stream, planes_c(st, r0),
                          planes_s(st, r0), mp.Kf, st.rs + r0, st.dy + r0, rows, brps, bpart);
-      hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)((bwidth + 255) / 256)), dim3(256), 0, ctx->stream, bpart, bns, bwidth,
+      hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)((bwidth + 31) / 32)), dim3(256), 0, ctx->stream, bpart, bns, bwidth,
                          st.gacc + st.tile_elems, 1);
       HIPCHK(ctx, hipGetLastError());
       if (timings) {
@@ -796,15 +796,17 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
   }
 
   // ---- P7: per-gamma errors, selection ---------------------------------------------------------
-  const long nblk = (n + LOO_ROWS_PER_BLOCK - 1) / LOO_ROWS_PER_BLOCK;
+  // rows per block of the error reduction: at most 256, fewer for small n so that there are ~4 blocks per CU
+  const int loo_rows = (int)std::max<long>(16, std::min<long>(LOO_ROWS_PER_BLOCK, n / (4L * ctx->cus)));
+  const long nblk = (n + loo_rows - 1) / loo_rows;
   double *part = nullptr, *errs = nullptr;
   NLSCHK(ws_get_t(ctx, "loo.part", (size_t)nblk * 3 * Gp, &part));
   NLSCHK(ws_get_t(ctx, "loo.errs", (size_t)3 * Gp, &errs));
   {
     SpanGuard g(ctx, NLS_T_LOO);
     hipLaunchKernelGGL(k_loo_errors, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, num, hs, st.dy, st.s_norm, n, G, Gp, is_clf,
-                       part);
-    hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)((3 * Gp + 255) / 256)), dim3(256), 0, ctx->stream, part, nblk, 3L * Gp, errs, 0);
+                       loo_rows, part);
+    hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)((3 * Gp + 31) / 32)), dim3(256), 0, ctx->stream, part, nblk, 3L * Gp, errs, 0);
     HIPCHK(ctx, hipGetLastError());
   }
   {
@@ -856,7 +858,7 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
     SpanGuard g(ctx, NLS_T_LOO);
     hipLaunchKernelGGL(k_loo_column, dim3((unsigned)cblk), dim3(256), 0, ctx->stream, num, hs, st.dy, st.s_norm, n, Gp, opt, is_clf,
                        ybar, loo_res, loo_lev, loo_std, cpart);
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(64), 0, ctx->stream, cpart, cblk, 2L, csum, 0);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, ctx->stream, cpart, cblk, 2L, csum, 0);
     HIPCHK(ctx, hipGetLastError());
   }
   {

@@ -34,33 +34,49 @@ def row_shard(n: int, rank: int, world: int) -> tuple[int, int]:
     return (n * rank) // world, (n * (rank + 1)) // world
 
 
-def _rendezvous_file(key: str | None) -> Path:
-    if key is None:
-        # all ranks of one launch are children of one launcher process; the port separates launches of one parent
-        key = f"{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}"
+def _rendezvous_files(key: str | None) -> tuple[Path, Path | None]:
+    """(primary, secondary).  Primary: keyed on the launcher's pid - all ranks of one launch are children of one launcher
+    process - and the rendezvous port.  Secondary (only without an explicit key): keyed on the port alone, for a launcher
+    that puts an intermediate process between itself and the ranks; it carries a timestamp and is accepted only while fresh."""
     base = Path(os.environ.get("NLS_RENDEZVOUS_DIR", "/tmp"))
-    return base / f"nls_rccl_id_{key}"
+    if key is not None:
+        return base / f"nls_rccl_id_{key}", None
+    port, run = os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none")
+    return base / f"nls_rccl_id_{os.getppid()}_{port}_{run}", base / f"nls_rccl_id_port{port}_{run}"
+
+
+_FRESH_SECONDS = 900.0
 
 
 def exchange_unique_id(ctx, rank: int, world: int, key: str | None = None, timeout: float = 300.0) -> bytes:
     """Rank 0 creates the communicator id and publishes it (atomic rename); the other ranks wait for the file."""
-    path = _rendezvous_file(key)
+    primary, secondary = _rendezvous_files(key)
     if rank == 0:
         uid = ctx.comm_unique_id()
-        tmp = path.with_suffix(f".tmp{os.getpid()}")
-        tmp.write_bytes(uid)
-        os.replace(tmp, path)
+        for path, payload in ((primary, uid), (secondary, uid + repr(time.time()).encode())):
+            if path is None:
+                continue
+            tmp = path.with_suffix(f".tmp{os.getpid()}")
+            tmp.write_bytes(payload)
+            os.replace(tmp, path)
         return uid
     t0 = time.monotonic()
     while True:
         try:
-            uid = path.read_bytes()
+            uid = primary.read_bytes()
             if len(uid) == 128:
                 return uid
         except FileNotFoundError:
             pass
+        if secondary is not None and time.monotonic() - t0 > 15.0:  # the parent-pid key found nothing: try the port key
+            try:
+                raw = secondary.read_bytes()
+                if len(raw) > 128 and abs(time.time() - float(raw[128:].decode())) < _FRESH_SECONDS:
+                    return raw[:128]
+            except (FileNotFoundError, ValueError):
+                pass
         if time.monotonic() - t0 > timeout:
-            raise TimeoutError(f"rank {rank}: no communicator id at {path} after {timeout:.0f} s")
+            raise TimeoutError(f"rank {rank}: no communicator id at {primary} after {timeout:.0f} s")
         time.sleep(0.02)
 
 
@@ -72,8 +88,10 @@ def init_from_env(ctx, key: str | None = None) -> tuple[int, int]:
     ctx.comm_init(uid, rank, world)  # (librccl's version banner is kept off this process's stdout, see Context.comm_init)
     ctx.comm_barrier()
     if rank == 0:  # everyone has read the id once the barrier returns
-        try:
-            _rendezvous_file(key).unlink()
-        except OSError:
-            pass
+        for path in _rendezvous_files(key):
+            try:
+                if path is not None:
+                    path.unlink()
+            except OSError:
+                pass
     return rank, world

@@ -174,6 +174,14 @@ def test_rendezvous_file_exchange(tmp_path, monkeypatch):
     assert got[0] == got[1] == got[2] == bytes(range(128))
     with pytest.raises(TimeoutError):
         distributed.exchange_unique_id(Ctx(), 1, 2, key="absent", timeout=0.2)
+    # no explicit key: parent-pid file plus a port-keyed, time-stamped fallback for launchers with an intermediate process
+    monkeypatch.setenv("MASTER_PORT", "34567")
+    assert distributed.exchange_unique_id(Ctx(), 0, 2) == bytes(range(128))
+    prim, sec = distributed._rendezvous_files(None)
+    assert prim.read_bytes() == bytes(range(128)) and sec.read_bytes()[:128] == bytes(range(128))
+    prim.unlink()  # a rank whose parent pid differs would not find the primary: after 15 s it takes the fresh secondary
+    monkeypatch.setattr(distributed.time, "monotonic", iter([0.0, 16.0, 17.0, 18.0]).__next__)
+    assert distributed.exchange_unique_id(Ctx(), 1, 2, timeout=100) == bytes(range(128))
 
 
 def test_no_cpu_fallback_without_gpu():

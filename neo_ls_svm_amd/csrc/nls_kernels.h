@@ -56,6 +56,23 @@ __device__ __forceinline__ void k1_stagger(int ticks) {
   while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(8);
 }
 
+// One range test per thread for the short sincos: largest |t| over the thread's accumulators <= 2^30, taken on the high words
+// as integers (two 32-bit instructions per element; a NaN or Inf compares large and takes the library routine, which handles them).
+template <int MT, int NTL>
+__device__ __forceinline__ bool all_args_small(const v4d (&acc)[MT][NTL]) {
+  unsigned m = 0;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NTL; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const unsigned h = (unsigned)__double2hiint(acc[mt][nt][r]) & 0x7fffffffu;
+        m = h > m ? h : m;
+      }
+  return m < 0x41d00000u;  // high word of 2^30
+}
+
 template <bool COMPLEX_OUT>
 __global__ void __launch_bounds__(Cfg4::NTHREADS, 1) k_featuremap(FeatureMapParams p) {
   using C = Cfg4;
@@ -71,13 +88,31 @@ __global__ void __launch_bounds__(Cfg4::NTHREADS, 1) k_featuremap(FeatureMapPara
     mainloop_real<C, false>(acc, la, lb, 0, p.dk / BK, smem);
   }
   // One range test per thread: |t| <= 2^30 everywhere (always, in practice) -> the short sincos, else the library's.
-  double tmax = 0.0;
+  const bool small = all_args_small(acc);
+  if constexpr (!COMPLEX_OUT) {
+    if (small && col0 + BN <= p.D) {
+      // Plane tile without padded columns (every tile when D is a multiple of 128): no per-element column test, one address
+      // per accumulator row and plane, the four column groups at immediate offsets.
+      const long cbase = col0 + C::acc_col(0);
 #pragma unroll
-  for (int mt = 0; mt < C::MT; ++mt)
+      for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < C::NTL; ++nt)
+        for (int r = 0; r < 4; ++r) {
+          const long row = row0 + C::acc_row(mt, r);
+          const double f = row < p.rows ? p.inv_sqrt_D * (p.rowscale ? p.rowscale[row] : 1.0) : 0.0;
+          double* pc = p.Fc + row * p.Kf + cbase;
+          double* ps = p.Fs + row * p.Kf + cbase;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) tmax = fmax(tmax, fabs(acc[mt][nt][r]));  // NaN: fmax drops it, the slow path is not needed for it
+          for (int nt = 0; nt < C::NTL; ++nt) {
+            double sv, cv;
+            sincos_reduced_full(acc[mt][nt][r], sv, cv, p.sc);
+            pc[nt * 16] = cv * f;
+            ps[nt * 16] = sv * f;
+          }
+        }
+      return;
+    }
+  }
   auto epilogue = [&](auto fastc) {
     constexpr bool FAST = decltype(fastc)::value;
 #pragma unroll
@@ -111,7 +146,7 @@ __global__ void __launch_bounds__(Cfg4::NTHREADS, 1) k_featuremap(FeatureMapPara
         }
       }
   };
-  if (tmax <= 1073741824.0) epilogue(std::true_type{});
+  if (small) epilogue(std::true_type{});
   else epilogue(std::false_type{});
 }
 
@@ -142,13 +177,7 @@ __global__ void __launch_bounds__(Cfg4::NTHREADS, 1) k_featuremap_gemv(FeatureMa
     bi[nt] = wi[col];
   }
   double* out = part + ((long)blockIdx.x * C::WAVES_N + C::wave_n()) * rows_pad;
-  double tmax = 0.0;
-#pragma unroll
-  for (int mt = 0; mt < C::MT; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < C::NTL; ++nt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) tmax = fmax(tmax, fabs(acc[mt][nt][r]));
+  const bool small = all_args_small(acc);
   auto epilogue = [&](auto fastc) {
     constexpr bool FAST = decltype(fastc)::value;
 #pragma unroll
@@ -168,7 +197,7 @@ __global__ void __launch_bounds__(Cfg4::NTHREADS, 1) k_featuremap_gemv(FeatureMa
         if ((threadIdx.x & 15) == 0) out[row0 + C::acc_row(mt, r)] = sum;
       }
   };
-  if (tmax <= 1073741824.0) epilogue(std::true_type{});
+  if (small) epilogue(std::true_type{});
   else epilogue(std::false_type{});
 }
 

@@ -60,8 +60,14 @@ NLS_HD void sincos_reduced_full(double t, double& s, double& c, const SinCosCoef
   const int q = (int)fn;  // exact: |fn| < 2^30
   const bool swap = q & 1;
   const double s0 = swap ? cr : sr, c0 = swap ? sr : cr;
+  // sin flips sign in quadrants 2, 3 (bit 1 of q), cos in quadrants 1, 2 (bit 1 of q + 1): move that bit onto the sign bit
+#if defined(__HIP_DEVICE_COMPILE__)
+  s = __hiloint2double(__double2hiint(s0) ^ (int)(((unsigned)q << 30) & 0x80000000u), __double2loint(s0));
+  c = __hiloint2double(__double2hiint(c0) ^ (int)(((unsigned)(q + 1) << 30) & 0x80000000u), __double2loint(c0));
+#else
   s = (q & 2) ? -s0 : s0;
   c = ((q + 1) & 2) ? -c0 : c0;
+#endif
 }
 
 NLS_HD void sincos_fast(double t, double& s, double& c, const SinCosCoef& k) {

@@ -37,6 +37,8 @@ CONFIGS = {
     "c5": dict(n=1_000_000, d=128, D=4096, G=32, sigmas=16, name="gamma x sigma LOO grid 32 x 16, n=1e6 d=128 D=4096 ORF, primal"),
     # one row chunk of c3 (profiling: same kernels, same D, 1/4 of the rows)
     "c3q": dict(n=262_144, d=128, D=4096, G=1024, name="synthetic regression n=262144 d=128 D=4096 ORF, primal, G=1024"),
+    # BASELINE.json configs[3]: dual path, binary classification, explicit n x n kernel + eigendecomposition gamma-sweep (G = 128)
+    "c4": dict(n=10_000, d=256, G=128, dual=True, name="synthetic binary classification n=1e4 d=256, dual path (n x n RBF kernel, EVD gamma-sweep G=128)"),
     # small plumbing configuration for quick checks
     "c0": dict(n=20_000, d=32, D=512, G=1024, name="synthetic regression n=2e4 d=32 D=512 ORF, primal, G=1024"),
 }
@@ -156,6 +158,144 @@ def cpu_baseline(cfg, shift, scale, B, gammas):
     return out
 
 
+def synth_clf(n, d):
+    """SURVEY 8(d) classification generator: y = (X w + 0.3 eps > 0)."""
+    import numpy as np
+
+    rng = np.random.default_rng(0)
+    X = rng.standard_normal((n, d))
+    w = rng.standard_normal(d) / np.sqrt(d)
+    y01 = (X @ w + 0.3 * rng.standard_normal(n) > 0).astype(np.float64)
+    return X, y01
+
+
+def run_dual(args, cfg):
+    """BASELINE config 4: one step = one ``nls_dual_fit`` (D1-D5: RBF kernel, EVD of sn K sn, reduced LOO sweep over G = 128,
+    selection, Cholesky re-solve, residuals, sigma) on the affine-transformed rows X_, resident in HBM.  The dual path does
+    not shard (the n x n EVD): N > 1 runs N independent replicas ("replicas only")."""
+    import numpy as np
+
+    import neo_ls_svm_amd as hp
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    n, d, G = cfg["n"], cfg["d"], cfg["G"]
+    ctx = hp.Context(local_rank)
+    cctx = None
+    if world > 1:
+        from neo_ls_svm_amd.distributed import init_from_env
+
+        cctx = hp.Context(local_rank)
+        init_from_env(cctx)
+    X, y01 = synth_clf(n, d)
+    y = np.where(y01 == 1.0, 1.0, -1.0)
+    s = np.ones(n)
+    sep = hp.AffineSeparator().fit(X, y, s, ctx=ctx)  # the package's own supervised pre-step (SURVEY 8(f) #1): X -> X_
+    Xt = np.ascontiguousarray(sep.transform(X))
+    gammas = hp.gamma_grid(G)
+    dX, dy, ds = ctx.to_device(Xt), ctx.to_device(y), ctx.to_device(s)
+
+    def barrier():
+        ctx.synchronize()
+        if cctx is not None:
+            cctx.comm_barrier()
+
+    def step(X_=dX, y_=dy, s_=ds):
+        return hp.dual_fit(X_, y_, s_, True, gammas=gammas, ctx=ctx)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    stage = {}
+    for _ in range(args.steps):
+        r = step()
+        for k, v in r["timings"].items():
+            stage[k] = stage.get(k, 0.0) + v
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if cctx is not None:
+        elapsed = float(cctx.comm_allreduce([elapsed], "max")[0])
+    pcie = None
+    if world == 1:
+        tp = time.perf_counter()
+        step(Xt, y, s)
+        ctx.synchronize()
+        pcie = time.perf_counter() - tp
+    if rank == 0:
+        r_ = Xt.shape[1]
+        mw_tflops = stage["rotate_flops"] / max(stage["rotate"], 1e-12) / 1e12  # M = F0 W: 2 n^3 per fit
+        alg = 2.0 * n * n * r_ + 2.0 * n**3 + 10.0 * n * n * G  # SURVEY 8(d) dual F (+ the variance product of D5)
+        out = {
+            "metric": "fits/sec (dual path, full gamma-sweep), n=1e4 d=256",
+            "unit_note": "one step = one dual fit",
+            "value": world * args.steps / elapsed,
+            "unit": "fits/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "value_pcie_inclusive": None if pcie is None else 1.0 / pcie,
+            "config": {
+                "workload": cfg["name"],
+                "n": n, "d": d, "r": int(r_), "G": G,
+                "parallelism": f"{world} independent replicas (the n x n EVD does not shard)" if world > 1 else "single GPU",
+                "affine": "package pre-step (AffineSeparator) fitted on all rows",
+                "gamma_index": r["opt"],
+                "loo_score": r["loo_score"],
+            },
+            "roofline": {
+                "kernel": "k_gemm (M = F0 W, the 2 n^3 product of the reduced sweep; stage time includes its n^2 helper kernels)",
+                "bound": "mfma",
+                "achieved": mw_tflops,
+                "peak": FP64_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": mw_tflops / FP64_MFMA_PEAK_TFLOPS,
+                "traffic": None,
+                "avg_launch_ms": 1e3 * stage["rotate"] / max(stage["rotate_launches"], 1.0),
+                "whole_fit_algorithmic_tflops": alg * args.steps / elapsed / 1e12,
+                "note": "the eigendecomposition (stage evd) is O(n^3) too but reported as wall-time share (SURVEY 8(d)); its own stage split is in "
+                "evd_stage_ms",
+            },
+            "stage_ms_per_step": {
+                k: round(1e3 * stage.get(k, 0.0) / args.steps, 3)
+                for k in ("upload", "gram", "evd", "rotate", "sweep", "loo", "cholesky", "residuals", "download", "total")
+            },
+            "evd_stage_ms": ctx.evd_stage_ms() if hasattr(ctx, "evd_stage_ms") else None,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            from threadpoolctl import threadpool_limits
+
+            sys.path.insert(0, str(ROOT / "oracle"))
+            import neolssvm_oracle as orc
+
+            ctx.release_workspace()
+            threads, blas = _blas_info()
+            with threadpool_limits(limits=int(threads), user_api="blas"):
+                t0 = time.perf_counter()
+                o = orc.dual_fit_reduced(Xt, y, s, True, gammas=gammas)
+                tc = time.perf_counter() - t0
+            out["cpu_baseline"] = {
+                "value": 1.0 / tc, "unit": "fits/s", "cores": int(threads), "host_cpus": os.cpu_count(), "blas": blas, "kind": "port",
+                "sample": f"the oracle's reduced schedule (dual_fit_reduced: numpy eigh + one 2 n^3 product + cho_factor / cho_solve with n right-hand "
+                f"sides) at FULL size, all {n} rows: {tc:.1f} s; the reference's own n x G x n schedule (102 GB here) cannot run this size",
+                "argmin_cpu_gpu": [int(o["opt"]), int(r["opt"])],
+                "gpu_over_cpu": (args.steps / elapsed) * tc,
+            }  # fmt: skip
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if cctx is not None:
+        cctx.close()
+    ctx.close()
+
+
 def spawn_ranks(args) -> int:
     """``python bench.py --gpus N`` without a launcher: start N copies of this script, one per GPU, before anything here
     has touched the GPU; relay rank 0's JSON line."""
@@ -191,6 +331,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     args.gpus = world
+    if cfg.get("dual"):
+        return run_dual(args, cfg)
 
     import numpy as np
 
@@ -279,6 +421,11 @@ def main():
         fm_bytes = fm_rows * (8.0 * d + 16.0 * (D + 1))  # 8 n d + 16 n (D+1) algorithmic bytes
         fm_gbs = fm_bytes / max(stage["featuremap"], 1e-12) / 1e9
         whole_alg = (stage["rotate_flops"] + stage["gram_flops"] + stage["sweep_flops"] + stage["featuremap_flops"]) / elapsed / 1e12
+        # flops the kernels actually execute: Hermitian half + 3M Gram, 3M rotation, compressed sweep when the
+        # library takes it (G > 256 on the reference's grid), the K = d feature-map product; EVD / Cholesky time is inside `elapsed`
+        rows_all = stage["gram_flops"] / (4.0 * (D + 1) ** 2)
+        sweep_exec = (4.0 * Np * 128 + 4.0 * 128 * G) if G > 256 else 4.0 * Np * G
+        whole_exec = (3.0 * rows_all * Kf * Kf + 6.0 * rot_rows * Kf * Np + rot_rows * sweep_exec + stage["featuremap_flops"]) / elapsed / 1e12
         out = {
             "metric": "fits/sec (full gamma-sweep), n=1e6 d=128 D=4096" if args.config == "c3"
             else ("gamma x sigma grids/sec (16 sigma x 32 gamma), n=1e6 d=128 D=4096" if grid_mode else f"fits/sec (full gamma-sweep), {args.config}"),
@@ -320,6 +467,8 @@ def main():
                 "avg_launch_ms": 1e3 * stage["rotate"] / rot_launches,
                 "executed_flops_per_launch": 6.0 * rot_rows * Kf * Np / rot_launches,
                 "whole_fit_algorithmic_tflops": whole_alg,
+                "whole_fit_executed_tflops": whole_exec,
+                "whole_fit_executed_frac": whole_exec / (FP64_MFMA_PEAK_TFLOPS * world),
             },
             "roofline_k1": {
                 "kernel": "k_featuremap (+ k_shift_pad)",

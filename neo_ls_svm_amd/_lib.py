@@ -292,6 +292,7 @@ class Factor:
         h = C.c_void_p()
         ctx._check(ctx.lib.nls_factor_create(ctx.handle, L.ctypes.data, self.D, C.byref(h)))
         self.handle = h
+        self.comm_world = 1  # world size of the native communicator this context has joined (1: none or one rank)
 
     def close(self):
         if getattr(self, "handle", None) and getattr(self.ctx, "handle", None):
@@ -317,6 +318,7 @@ class Context:
             raise NlsError(f"nls_ctx_create failed: {msg.decode() if msg else rc}")
         self.handle = h
         self.device = int(device)
+        self.comm_world = 1  # world size of the native communicator this context has joined (1: none, or one rank)
         self._hook = None  # keep the ctypes callback alive
 
     def _check(self, rc: int):
@@ -364,9 +366,11 @@ class Context:
         with _StdoutToStderr():
             rc = self.lib.nls_comm_init_rank(self.handle, C.c_char_p(unique_id), int(rank), int(world))
         self._check(rc)
+        self.comm_world = int(world)
 
     def comm_destroy(self):
         self._check(self.lib.nls_comm_destroy(self.handle))
+        self.comm_world = 1
 
     def comm_allreduce(self, values, op: str = "sum") -> np.ndarray:
         """Sum / max of a few host doubles over the ranks (driver utility: barrier, timing)."""

@@ -79,9 +79,9 @@ static int trd_fused(nls_ctx* ctx, T* A, int n, long lda, double* d, double* e, 
     NLSCHK(ws_get_t(ctx, "trd.spart2", (size_t)nrb, &sp[1]));
     NLSCHK(ws_get_t(ctx, "trd.bvec", (size_t)n, &a.bvec));
   }
-  // The launch sequence below (2-3 kernels per column, ~8200 launches at n = 4097) depends only on n, the variant and the
-  // buffer addresses, so it is captured once into a hipGraph and replayed: for small matrices the columns are bound by the
-  // host's launch rate (n = 1025: 9 us of kernels per column, 18 us of wall time), which a graph launch takes out.
+  // 2-3 kernels per column, ~8200 launches at n = 4097.  (A hipGraph replay of this sequence and a persistent one-launch
+  // panel were built and measured slower in round 2 - the cost is the GPU's own dependent-dispatch latency: profiles/r02_trd_graph.log,
+  // profiles/r02_trd_persistent.log; they are in the history, not in the library.)
   auto enqueue = [&]() -> int {
   int cur = 0;  // buffer that the column being finished writes (two-kernel variant)
   for (int j0 = 0; j0 < n; j0 += NB) {
@@ -137,67 +137,7 @@ static int trd_fused(nls_ctx* ctx, T* A, int n, long lda, double* d, double* e, 
   return NLS_OK;
   };  // enqueue
 
-  // Opt-in diagnostic: one persistent launch (k_trd_persistent; NLS_TRD_PERSIST_MAX = largest n it is used for, default 0 = never;
-  // NLS_TRD_PERSIST_XCD=0 takes the chip-wide variant instead of the one-XCD one).
-  int persist_max = 0, persist_wg = 32;  // off by default: measured slower than the launch-per-kernel panel (nls_trd.h)
-  bool one_xcd = true;
-  if (const char* pm = std::getenv("NLS_TRD_PERSIST_MAX")) persist_max = std::atoi(pm);
-  if (const char* px = std::getenv("NLS_TRD_PERSIST_XCD")) one_xcd = px[0] != '0';
-  if (const char* pw = std::getenv("NLS_TRD_PERSIST_WG")) persist_wg = std::max(1, std::min(one_xcd ? ctx->cus / 8 : ctx->cus, std::atoi(pw)));
-  if (two_kernels && !trd_use_rocblas_rank2k() && n >= 64 && n <= persist_max) {
-    unsigned* ctl = nullptr;
-    NLSCHK(ws_get_t(ctx, "trd.ctl", 4, &ctl));
-    const unsigned init[4] = {0u, 0u, 0xffffffffu, 0u};  // barrier counter, status, min / max XCC_ID seen
-    HIPCHK(ctx, hipMemcpyAsync(ctl, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
-    if (one_xcd)
-      hipLaunchKernelGGL((k_trd_persistent<T, true>), dim3((unsigned)persist_wg * 8u), dim3(256), 0, ctx->stream, a, wt[0], wt[1], sp[0], sp[1], NSC,
-                         NSR, ctl);
-    else
-      hipLaunchKernelGGL((k_trd_persistent<T, false>), dim3((unsigned)persist_wg), dim3(256), 0, ctx->stream, a, wt[0], wt[1], sp[0], sp[1], NSC, NSR,
-                         ctl);
-    HIPCHK(ctx, hipGetLastError());
-    unsigned hctl[4] = {0, 0, 0, 0};
-    HIPCHK(ctx, hipMemcpyAsync(hctl, ctl, sizeof(hctl), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    if (hctl[1] == 1u) return fail(ctx, NLS_ERR_HIP, "persistent tridiagonalisation: a workgroup timed out at a device-wide barrier (n = %d)", n);
-    if (hctl[1] == 0u) return NLS_OK;
-    // status 2: the workgroups were not all placed on one XCD; nothing was written - take the launch-per-kernel panel
-    ctx->trd_xcd_fallbacks++;
-  }
-  // hipGraph replay of the launch sequence: measured to change nothing (profiles/r02_trd_graph.log: the cost of a dependent
-  // kernel boundary is on the GPU side), kept as an opt-in diagnostic.
-  const char* genv = std::getenv("NLS_TRD_GRAPH");
-  const bool use_graph = (genv && genv[0] == '1') && !trd_use_rocblas_rank2k() && n >= 64;
-  if (!use_graph) return enqueue();
-  // key: everything the captured kernel arguments depend on
-  char key[512];
-  std::snprintf(key, sizeof(key), "%zu|%d|%ld|%d|%d|%d|%p|%p|%p|%p|%p|%p|%p|%p|%p|%p|%p|%p|%p|%p|%p", sizeof(T), n, lda, (int)two_kernels,
-                trd_dotgroups(n), a.boustrophedon, (void*)A, (void*)d, (void*)e, (void*)tau, (void*)a.W, (void*)wt[0], (void*)wt[1], (void*)a.xvec,
-                (void*)a.ylow, (void*)a.yup, (void*)a.zpart, (void*)sp[0], (void*)sp[1], (void*)a.pnorm, (void*)a.bvec);
-  auto it = ctx->graphs.find(key);
-  if (it == ctx->graphs.end()) {
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
-    if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
-      (void)hipGetLastError();
-      return enqueue();
-    }
-    const int rc = enqueue();
-    const hipError_t ee = hipStreamEndCapture(ctx->stream, &graph);  // always: leaves capture mode
-    if (rc != NLS_OK || ee != hipSuccess || !graph || hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
-      (void)hipGetLastError();
-      if (graph) (void)hipGraphDestroy(graph);
-      return enqueue();  // nothing was executed during the capture: run the sequence eagerly
-    }
-    (void)hipGraphDestroy(graph);
-    if (ctx->graphs.size() >= 6) {  // a handful of shapes per process; drop everything rather than track ages
-      for (auto& kv : ctx->graphs) (void)hipGraphExecDestroy(kv.second);
-      ctx->graphs.clear();
-    }
-    it = ctx->graphs.emplace(key, exec).first;
-  }
-  HIPCHK(ctx, hipGraphLaunch(it->second, ctx->stream));
-  return NLS_OK;
+  return enqueue();
 }
 
 // rocBLAS shims for the blocked back-transformation

@@ -62,8 +62,6 @@ struct nls_ctx {
   double* comm_scratch = nullptr;  // a few doubles on the device for nls_comm_allreduce
   size_t ws_bytes = 0;        // bytes currently held by the workspace arena
   std::vector<nls_factor*> factors;
-  long trd_xcd_fallbacks = 0;  // times the one-XCD persistent panel found its workgroups on several XCDs and fell back
-  std::map<std::string, hipGraphExec_t> graphs;  // captured launch sequences of the tridiagonalisation (nls_evd.hip), by shape + buffers
   // XCD patch shape of k_rotate3 (NLS_ROT_PATCH=RxC; 0x0 = plain order, the default: patches raise the L2 hit rate
   // from 0.57 to 0.78 and halve the fabric traffic but run 1-4 % slower, profiles/r01_pmc_summary.md)
   int rot_pr = 0, rot_pc = 0;

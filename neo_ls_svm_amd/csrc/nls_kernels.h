@@ -177,7 +177,10 @@ __global__ void __launch_bounds__(Cfg4::NTHREADS, 1) k_featuremap_gemv(FeatureMa
     bi[nt] = wi[col];
   }
   double* out = part + ((long)blockIdx.x * C::WAVES_N + C::wave_n()) * rows_pad;
-  const bool small = all_args_small(acc);
+  // Wave-uniform choice: both branches hold the 16-lane shuffle reduction, and the 16 lanes of a row group own different
+  // columns, so a per-thread choice would let a row whose arguments straddle 2^30 split the group across the branches
+  // (shuffles would then read inactive lanes).
+  const bool small = __all(all_args_small(acc));
   auto epilogue = [&](auto fastc) {
     constexpr bool FAST = decltype(fastc)::value;
 #pragma unroll

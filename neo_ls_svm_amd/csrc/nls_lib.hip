@@ -149,7 +149,16 @@ extern "C" int nls_ctx_create(int device, nls_ctx** out) {
   if (rocblas_create_handle(&ctx->blas) != rocblas_status_success) return bail("rocblas_create_handle", "status != success");
   rocblas_set_stream(ctx->blas, ctx->stream);
   // Opt in to > 64 KiB of dynamic LDS for the tile kernels.
-  auto lds = [](const void* f, size_t bytes) { (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); };
+  const char* lds_fail = nullptr;
+  hipError_t lds_err = hipSuccess;
+  auto lds_named = [&](const void* f, size_t bytes, const char* name) {
+    const hipError_t r = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (r != hipSuccess && !lds_fail) {
+      lds_fail = name;
+      lds_err = r;
+    }
+  };
+#define lds(f, bytes) lds_named(f, bytes, #f)
   lds(reinterpret_cast<const void*>(k_gram3), m3::SMEM3);
   lds(reinterpret_cast<const void*>(k_rotate3), m3::SMEM3);
   lds(reinterpret_cast<const void*>(k_sweep), SMEM_REAL);
@@ -158,6 +167,14 @@ extern "C" int nls_ctx_create(int device, nls_ctx** out) {
   lds(reinterpret_cast<const void*>(k_featuremap_gemv), SMEM_REAL);
   lds(reinterpret_cast<const void*>(k_gemm<EPI_STORE>), SMEM_REAL);
   lds(reinterpret_cast<const void*>(k_gemm<EPI_RBF>), SMEM_REAL);
+#undef lds
+  if (lds_fail) {  // without the opt-in the first tile launch would fail later with a generic launch error
+    static char what[256];
+    std::snprintf(what, sizeof(what), "dynamic LDS opt-in (%s)", lds_fail);
+    rocblas_destroy_handle(ctx->blas);
+    (void)hipStreamDestroy(ctx->stream);
+    return bail(what, hipGetErrorString(lds_err));
+  }
   *out = ctx;
   return NLS_OK;
 }
@@ -175,7 +192,6 @@ extern "C" void nls_ctx_destroy(nls_ctx* ctx) {
   (void)nls_comm_destroy(ctx);
   if (ctx->comm_scratch) (void)hipFree(ctx->comm_scratch);
   for (nls_factor* f : ctx->factors) factor_free(f);
-  for (auto& kv : ctx->graphs) (void)hipGraphExecDestroy(kv.second);
   for (auto& kv : ctx->ws)
     if (kv.second.p) (void)hipFree(kv.second.p);
   for (auto ev : ctx->event_pool) (void)hipEventDestroy(ev);
@@ -207,8 +223,6 @@ extern "C" int nls_ws_release(nls_ctx* ctx, size_t min_bytes, size_t* still_held
   if (!ctx) return NLS_ERR_ARG;
   HIPCHK(ctx, hipSetDevice(ctx->device));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  for (auto& kv : ctx->graphs) (void)hipGraphExecDestroy(kv.second);  // they hold addresses of the buffers that go away
-  ctx->graphs.clear();
   for (auto it = ctx->ws.begin(); it != ctx->ws.end();) {
     if (it->second.p && it->second.bytes >= min_bytes) {
       HIPCHK(ctx, hipFree(it->second.p));
@@ -734,13 +748,15 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
     NLSCHK(build_rot_planes(ctx, mp, Qev, 1L, (long)D1, false, rb));  // column-major Q
     hipLaunchKernelGGL(k_compute_v, dim3((unsigned)Np), dim3(256), 0, ctx->stream, Qev, (long)D1, db, D1, inv_c, rb.vr, rb.vi);
     if (compressed) {
-      // The interpolation identity needs every pole -lam_j to the left of the grid.  A / c is positive semi-definite, so
-      // lam_min >= -eps lam_max in exact-ish arithmetic; an eigenvalue below -gamma_min / 2 (degenerate weights: lam_max up to
-      // 2 n (D+1)) puts a pole of the reference's own formula inside the grid - then evaluate that formula directly.
+      // The interpolation identity needs every pole -lam_j well to the left of the grid: measured through nls_sweep_weights
+      // (tests/test_sweep_compression.py), the interpolant of 1 / (gamma + lam) is exact to rounding (1.8e-15) for lam >= -gamma_min / 8,
+      // 6e-14 at -gamma_min / 4 and 5e-10 at -gamma_min / 2 (the pole is then 0.69 from the first Chebyshev piece).  A / c is positive
+      // semi-definite, so lam_min >= -eps lam_max ~ -1e-12 for the path's matrices (lam_max ~ D + 1); an eigenvalue below
+      // -gamma_min / 8 (degenerate weights: lam_max up to 2 n (D+1)) takes the reference's own formula evaluated directly.
       double lam_min = 0.0;
       HIPCHK(ctx, hipMemcpyAsync(&lam_min, lam, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
       HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-      if (!(lam_min > -0.5 * a->gammas[0])) compressed = false;
+      if (!(lam_min > -0.125 * a->gammas[0])) compressed = false;
     }
     Gr = compressed ? SWEEP_GN : Gp;
     HIPCHK(ctx, hipMemcpyAsync(dgam, compressed ? hnodes.data() : a->gammas, sizeof(double) * (compressed ? SWEEP_GN : G), hipMemcpyHostToDevice,

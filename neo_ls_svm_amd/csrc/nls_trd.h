@@ -811,130 +811,6 @@ __global__ void k_trd_restore_subdiag(T* A, long lda, const double* e, int j0, i
   if (p < cnt) A[(long)(j0 + p + 1) + (long)(j0 + p) * lda] = make_<T>(e[j0 + p], 0.0);
 }
 
-// ================================================================================================================
-// Persistent panel (opt-in diagnostic, NLS_TRD_PERSIST_MAX).  Up to n ~ 2000 a column is not bound by its arithmetic or its
-// traffic but by the two dependent kernel boundaries it crosses (n = 1025: 9 us of kernel time in 18 us of wall time per
-// column; a hipGraph of the same launches changes nothing - the cost is on the GPU side, profiles/r02_trd_graph.log).  Here the
-// WHOLE tridiagonalisation is one launch of a few workgroups that walk the same sequence of phases - matrix-vector tiles, row
-// blocks, panel end, trailing update - as "virtual blocks" of the bodies above, separated by a device-wide barrier (one
-// atomic counter, relaxed polling between a release and an acquire).  The arithmetic and its order are those of the
-// two-kernel variant: results are bit-identical (tests/test_gpu_evd.py).  MEASURED SLOWER than separate launches on this
-// chip (profiles/r02_trd_persistent.log): the cache maintenance a software barrier needs costs more than a kernel boundary.
-// A workgroup that waits longer than ~2 s raises ctl[1] and everybody leaves (the host reports an error): no hang.
-// ================================================================================================================
-// ONE_XCD: all participating workgroups sit on one XCD and share its L2, so the release side needs no L2 write-back: stores are
-// complete in L2 once vmcnt has drained (the vector L1 is write-through).  The acquire side still needs buffer_inv sc1 -
-// buffer_inv sc0 does NOT drop the CU's L1 here (measured: wrong results) - which keeps this variant at 25 ms for n = 1025
-// against 33 ms chip-wide and 18.5 ms for the launch-per-kernel panel.
-template <bool ONE_XCD>
-__device__ __forceinline__ bool trd_grid_barrier(unsigned* ctl, unsigned nwg, unsigned& epoch) {
-  __shared__ int ok_sh;
-  // release side (every wave): its own stores performed
-  if (!ONE_XCD) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");    // + written back past the L2
-  else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // acknowledged by the (shared) L2
-  __syncthreads();
-  ++epoch;
-  if (threadIdx.x == 0) {
-    __hip_atomic_fetch_add(ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    int ok = 1;
-    unsigned spins = 0;
-    while (__hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch * nwg) {
-      if (__hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-        ok = 0;
-        break;
-      }
-      if (++spins > 4000000u) {
-        __hip_atomic_store(ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ok = 0;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(1);
-    }
-    ok_sh = ok;
-  }
-  __syncthreads();
-  // acquire side (every wave)
-  if (!ONE_XCD) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  else asm volatile("buffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
-  return ok_sh != 0;
-}
-
-// ONE_XCD: launched with 8 x the workgroups; only those the dispatcher places on XCD 0 (blockIdx % 8 == 0, round-robin) take part.
-// The placement is VERIFIED, not assumed: every participant records the XCC_ID hardware register and a mismatch makes all of them
-// leave with ctl[1] = 2 before anything is written - the host then runs the launch-per-kernel panel.
-template <class T, bool ONE_XCD>
-__global__ void __launch_bounds__(256, 1)
-    k_trd_persistent(Args<T> a, T* wt0, T* wt1, T* sp0, T* sp1, int NSC, int NSR, unsigned* ctl) {
-  int nwg = gridDim.x, wg = blockIdx.x;
-  unsigned epoch = 0;
-  if (ONE_XCD) {
-    if ((blockIdx.x & 7u) != 0u) return;
-    nwg >>= 3;
-    wg >>= 3;
-    if (threadIdx.x == 0) {
-      const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xfu;  // HW_REG_XCC_ID[3:0]
-      __hip_atomic_fetch_min(ctl + 2, xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_fetch_max(ctl + 3, xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (!trd_grid_barrier<ONE_XCD>(ctl, nwg, epoch)) return;
-    if (__hip_atomic_load(ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != __hip_atomic_load(ctl + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-      if (threadIdx.x == 0) __hip_atomic_store(ctl + 1, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      return;
-    }
-  }
-  const int n = a.n;
-  T* wt[2] = {wt0, wt1};
-  T* sp[2] = {sp0, sp1};
-  int cur = 0;
-  for (int j0 = 0; j0 < n; j0 += NB) {
-    const int jend = j0 + NB < n ? j0 + NB : n;
-    a.j0 = j0;
-    for (int j = j0; j < jend; ++j) {
-      a.j = j;
-      const int S0 = (j + 1) / TS, K = NSC - S0, ntiles = j < n - 1 ? K * (K + 1) / 2 : 0;
-      a.wtmp = wt[cur];
-      a.spart = sp[cur];
-      a.wtmp_prev = wt[cur ^ 1];
-      a.spart_prev = sp[cur ^ 1];
-      a.ndot = (n - j + RD - 1) / RD;
-      a.make_base = j + 1 < jend;
-      for (int vb = wg; vb < ntiles + a.ndot; vb += nwg) {
-        trd_hemv2_body<T>(a, S0, ntiles, vb);
-        __syncthreads();
-      }
-      if (!trd_grid_barrier<ONE_XCD>(ctl, nwg, epoch)) return;
-      if (j < n - 1) {
-        for (int vb = wg; vb < a.nrowblocks; vb += nwg) {
-          trd_finish2_body<T>(a, S0, NSR, vb);
-          __syncthreads();
-        }
-        if (!trd_grid_barrier<ONE_XCD>(ctl, nwg, epoch)) return;
-        cur ^= 1;
-      }
-    }
-    const int jl = jend - 1 < n - 2 ? jend - 1 : n - 2, n2 = n - jend;
-    if (n2 > 0) {
-      Args<T> ae = a;  // the last finished column wrote the buffers that are "previous" now
-      ae.wtmp = wt[cur ^ 1];
-      ae.spart = sp[cur ^ 1];
-      for (int vb = wg; vb < (n + 255) / 256; vb += nwg) {
-        trd_panel_end_body<T>(ae, jl, vb);
-        __syncthreads();
-      }
-      if (!trd_grid_barrier<ONE_XCD>(ctl, nwg, epoch)) return;
-      const int ut = (n2 + UT - 1) / UT;
-      for (int vb = wg; vb < ut * (ut + 1) / 2; vb += nwg) {
-        trd_rank2k_body<T>(a.A, a.lda, a.W, (long)n, n, j0, jend - j0, jend, vb);
-        __syncthreads();
-      }
-      if (!trd_grid_barrier<ONE_XCD>(ctl, nwg, epoch)) return;
-    }
-    if (jl >= j0 && wg == 0 && (int)threadIdx.x < jl - j0 + 1)
-      a.A[(long)(j0 + threadIdx.x + 1) + (long)(j0 + threadIdx.x) * a.lda] = make_<T>(a.e[j0 + threadIdx.x], 0.0);
-    if (jend < n && !trd_grid_barrier<ONE_XCD>(ctl, nwg, epoch)) return;
-  }
-}
-
 // ---- back-transformation  C <- Q C,  Q = H_0 H_1 ... H_{n-2}  (zunmtr / dormtr, left, lower, no transpose) --------------
 // In blocks of KBQ reflectors: H_{j0} ... H_{j0+kb-1} = I - V T V^H with T^-1 = striu(V^H V) + diag(1 / tau), so a block is
 // two large GEMMs (W = V^H C, C -= V X) around one kb x kb triangular solve (T^-1 X = W) - no sequential larft, and the

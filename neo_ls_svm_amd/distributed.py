@@ -36,47 +36,65 @@ def row_shard(n: int, rank: int, world: int) -> tuple[int, int]:
 
 def _rendezvous_files(key: str | None) -> tuple[Path, Path | None]:
     """(primary, secondary).  Primary: keyed on the launcher's pid - all ranks of one launch are children of one launcher
-    process - and the rendezvous port.  Secondary (only without an explicit key): keyed on the port alone, for a launcher
-    that puts an intermediate process between itself and the ranks; it carries a timestamp and is accepted only while fresh."""
+    process - the rendezvous port, the run id and the elastic restart count (a restarted group never reads the previous
+    attempt's file).  Secondary (only without an explicit key): keyed on the port alone, for a launcher that puts an
+    intermediate process between itself and the ranks.  Both payloads carry a timestamp and are accepted only while fresh."""
     base = Path(os.environ.get("NLS_RENDEZVOUS_DIR", "/tmp"))
     if key is not None:
         return base / f"nls_rccl_id_{key}", None
     port, run = os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none")
-    return base / f"nls_rccl_id_{os.getppid()}_{port}_{run}", base / f"nls_rccl_id_port{port}_{run}"
+    attempt = os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")
+    return base / f"nls_rccl_id_{os.getppid()}_{port}_{run}_{attempt}", base / f"nls_rccl_id_port{port}_{run}_{attempt}"
 
 
-_FRESH_SECONDS = 900.0
+_FRESH_SECONDS = float(os.environ.get("NLS_RENDEZVOUS_FRESH_SECONDS", "600"))
+
+
+def _publish(path: Path, payload: bytes) -> None:
+    """Atomic publish: a private temporary file (O_EXCL | O_NOFOLLOW, mode 0600: never through a planted symlink), then rename."""
+    tmp = path.with_suffix(f".tmp{os.getpid()}")
+    try:
+        os.unlink(tmp)
+    except FileNotFoundError:
+        pass
+    fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, "O_NOFOLLOW", 0), 0o600)
+    try:
+        os.write(fd, payload)
+    finally:
+        os.close(fd)
+    os.replace(tmp, path)
+
+
+def _read_fresh(path: Path) -> bytes | None:
+    """The 128-byte id of a payload `id || repr(time)` that is younger than ``_FRESH_SECONDS``; None otherwise (a file left
+    behind by a launch that died between publishing and the post-barrier unlink is ignored, not joined)."""
+    try:
+        raw = path.read_bytes()
+        if len(raw) > 128 and abs(time.time() - float(raw[128:].decode())) < _FRESH_SECONDS:
+            return raw[:128]
+    except (FileNotFoundError, ValueError):
+        pass
+    return None
 
 
 def exchange_unique_id(ctx, rank: int, world: int, key: str | None = None, timeout: float = 300.0) -> bytes:
-    """Rank 0 creates the communicator id and publishes it (atomic rename); the other ranks wait for the file."""
+    """Rank 0 creates the communicator id and publishes it (atomic rename); the other ranks wait for a FRESH file."""
     primary, secondary = _rendezvous_files(key)
     if rank == 0:
         uid = ctx.comm_unique_id()
-        for path, payload in ((primary, uid), (secondary, uid + repr(time.time()).encode())):
-            if path is None:
-                continue
-            tmp = path.with_suffix(f".tmp{os.getpid()}")
-            tmp.write_bytes(payload)
-            os.replace(tmp, path)
+        for path in (primary, secondary):
+            if path is not None:
+                _publish(path, uid + repr(time.time()).encode())
         return uid
     t0 = time.monotonic()
     while True:
-        try:
-            uid = primary.read_bytes()
-            if len(uid) == 128:
-                return uid
-        except FileNotFoundError:
-            pass
-        if secondary is not None and time.monotonic() - t0 > 15.0:  # the parent-pid key found nothing: try the port key
-            try:
-                raw = secondary.read_bytes()
-                if len(raw) > 128 and abs(time.time() - float(raw[128:].decode())) < _FRESH_SECONDS:
-                    return raw[:128]
-            except (FileNotFoundError, ValueError):
-                pass
+        uid = _read_fresh(primary)
+        if uid is None and secondary is not None and time.monotonic() - t0 > 15.0:  # the parent-pid key found nothing: try the port key
+            uid = _read_fresh(secondary)
+        if uid is not None:
+            return uid
         if time.monotonic() - t0 > timeout:
-            raise TimeoutError(f"rank {rank}: no communicator id at {primary} after {timeout:.0f} s")
+            raise TimeoutError(f"rank {rank}: no fresh communicator id at {primary} after {timeout:.0f} s")
         time.sleep(0.02)
 
 

@@ -339,9 +339,14 @@ def primal_fit_sigma_grid(
 
     Default gammas: the 32-point grid ``gamma_grid(1024)[::33]`` (exactly a sub-grid of the reference's 1024 points).
     Multi-GPU: sigmas are dealt round-robin over ``world`` ranks, every rank holding all rows (no collective in the
-    data path); ``allreduce_sum(array) -> array`` (e.g. ``Context.comm_allreduce`` on a communicator context) merges the
-    small tables - every sigma is owned by one rank, the others contribute zeros.
+    data path); ``allreduce_sum(array) -> array`` merges the small tables - every sigma is owned by one rank, the others
+    contribute zeros.  The communicator behind ``allreduce_sum`` must live on a SEPARATE context (as ``bench.py`` does): a
+    fitting context that has joined a communicator turns every ``primal_fit`` into a row-sharded collective fit, and ranks
+    that hold different sigmas would then all-reduce unrelated Gram matrices or deadlock - so this is refused below.
     """
+    if world > 1 and ctx is not None and getattr(ctx, "comm_world", 1) > 1:
+        raise ValueError("primal_fit_sigma_grid shards sigmas, not rows: the fitting context must not be in a communicator "
+                         "(put the communicator used by allreduce_sum on a second Context)")  # fmt: skip
     sigmas = np.asarray(sigmas, dtype=np.float64)
     gammas = gamma_grid(1024)[::33] if gammas is None else np.ascontiguousarray(gammas, dtype=np.float64)
     B = np.ascontiguousarray(B, dtype=np.float64)
@@ -358,6 +363,8 @@ def primal_fit_sigma_grid(
         for name, v in r["timings"].items():
             timings[name] = timings.get(name, 0.0) + v
         score = r["objective"][r["opt"]]
+        # (finish_below is strict: a sigma that only TIES the incumbent is not finished; the selection below resolves exact
+        # ties towards the finished incumbent, so "best" is never lost to a tie)
         if r["finished"] and (best is None or score < best[0]):
             best = (score, k, r)
     if allreduce_sum is not None and world > 1:
@@ -369,7 +376,9 @@ def primal_fit_sigma_grid(
         owned[rank::world] = True
         table[~owned], objective[~owned] = np.nan, np.nan
     col_min = np.where(owned, np.nanmin(np.where(owned[:, None], objective, np.inf), axis=1), np.inf)
-    k_opt = int(np.argmin(col_min))  # first minimum: ties go to the smaller sigma index
+    k_opt = int(np.argmin(col_min))  # first minimum: ties go to the smaller sigma index ...
+    if best is not None and col_min[best[1]] == col_min[k_opt]:
+        k_opt = best[1]  # ... unless this rank's finished incumbent is among the tied: it carries the full result
     g_opt = int(np.argmin(objective[k_opt]))
     return {
         "sigmas": sigmas,

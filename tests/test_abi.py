@@ -178,7 +178,13 @@ def test_rendezvous_file_exchange(tmp_path, monkeypatch):
     monkeypatch.setenv("MASTER_PORT", "34567")
     assert distributed.exchange_unique_id(Ctx(), 0, 2) == bytes(range(128))
     prim, sec = distributed._rendezvous_files(None)
-    assert prim.read_bytes() == bytes(range(128)) and sec.read_bytes()[:128] == bytes(range(128))
+    assert prim.read_bytes()[:128] == bytes(range(128)) and sec.read_bytes()[:128] == bytes(range(128))
+    assert (prim.stat().st_mode & 0o777) == 0o600
+    # a file left behind by a launch that died after publishing is stale: it is not joined
+    stale = bytes(range(128)) + repr(distributed.time.time() - 10 * distributed._FRESH_SECONDS).encode()
+    (tmp_path / "nls_rccl_id_old").write_bytes(stale)
+    with pytest.raises(TimeoutError):
+        distributed.exchange_unique_id(Ctx(), 1, 2, key="old", timeout=0.2)
     prim.unlink()  # a rank whose parent pid differs would not find the primary: after 15 s it takes the fresh secondary
     monkeypatch.setattr(distributed.time, "monotonic", iter([0.0, 16.0, 17.0, 18.0]).__next__)
     assert distributed.exchange_unique_id(Ctx(), 1, 2, timeout=100) == bytes(range(128))

@@ -134,26 +134,3 @@ def test_rank2k_rocblas_knob(hp, monkeypatch):
     monkeypatch.setenv("NLS_TRD_RANK2K", "rocblas")
     d1, e1, _, _ = hp.tridiagonalize(A)
     assert np.max(np.abs(d0 - d1)) <= 1e-12 * 260 and np.max(np.abs(e0 - e1)) <= 1e-12 * 260
-
-
-@pytest.mark.parametrize("cplx", [True, False])
-def test_persistent_panel_is_bit_identical_to_the_launch_per_kernel_panel(cplx, hp, monkeypatch):
-    """Up to n = 1536 the whole tridiagonalisation is ONE persistent launch on one XCD (k_trd_persistent: the same phases as
-    virtual blocks between barriers; L2 shared, only the L1 is invalidated); it must reproduce the two-kernels-per-column
-    panel bit for bit, for any number of workgroups - a stale read anywhere would show.  Same for the chip-wide variant."""
-    for n in (64, 65, 200, 517, 1025, 1500):
-        A = _hermitian(n, cplx, 500 + n)
-        monkeypatch.setenv("NLS_TRD_PERSIST_MAX", "0")
-        ref = hp.tridiagonalize(A)
-        monkeypatch.setenv("NLS_TRD_PERSIST_MAX", "1536")
-        for xcd, wg in (("1", "32"), ("1", "5"), ("0", "64"), ("0", "7")):
-            monkeypatch.setenv("NLS_TRD_PERSIST_XCD", xcd)
-            monkeypatch.setenv("NLS_TRD_PERSIST_WG", wg)
-            for _ in range(2):
-                got = hp.tridiagonalize(A)
-                assert all(np.array_equal(x, y) for x, y in zip(ref, got)), (n, xcd, wg)
-        monkeypatch.delenv("NLS_TRD_PERSIST_WG")
-        monkeypatch.delenv("NLS_TRD_PERSIST_XCD")
-        monkeypatch.delenv("NLS_TRD_PERSIST_MAX")
-    lam, Q = hp.eigh(_hermitian(700, cplx, 3, spd=True))
-    assert np.max(np.abs(Q.conj().T @ Q - np.eye(700))) <= 1e-11

@@ -50,6 +50,30 @@ def test_featuremap_ragged_shapes(hp):
     assert relerr(phi, ref) < 1e-9
 
 
+def test_fused_decision_function_with_arguments_straddling_the_short_sincos_range(hp):
+    """k_featuremap_gemv picks the short or the library sincos per WAVE: one outlier row whose arguments lie on both sides
+    of 2^30 (and one with |t| far beyond it) must not disturb the 16-lane reduction of the rows that share its wave."""
+    rng = np.random.default_rng(12)
+    n, d, D = 300, 3, 200
+    X = rng.standard_normal((n, d))
+    B = rng.standard_normal((d, D))
+    B[0, ::2] *= 1e-3  # the outlier row's arguments: ~1e6 in the even columns, ~1e9-1e10 (>= 2^30) in the odd ones
+    X[17, 0] = 3.0e9
+    X[211] = (-7.0e12, 2.5e11, 1.0e10)
+    beta = rng.standard_normal(D + 1) + 1j * rng.standard_normal(D + 1)
+    shift, scale = np.zeros(d), np.ones(d)
+    t17 = np.abs(X[17] @ B)
+    assert t17.min() < 2.0**30 < t17.max()
+    yhat, _ = hp.primal_predict(X, shift, scale, B, beta=beta)
+    phi = hp.featuremap(X, shift, scale, B)  # the unfused kernel (per-thread choice, no cross-lane step)
+    ref = np.real(phi @ beta)
+    ok = np.ones(n, bool)
+    ok[[17, 211]] = False
+    assert relerr(yhat[ok], ref[ok]) < 1e-13
+    assert relerr(yhat[ok], np.real(orc.feature_map(X[ok], shift, scale, B) @ beta)) < 1e-12
+    assert np.max(np.abs(yhat[~ok] - ref[~ok])) < 1e-9 * np.sqrt(D)  # huge arguments: same library sincos in both kernels
+
+
 @pytest.mark.parametrize("name", PRIMAL_CASES)
 def test_gram_matches_oracle(name, golden_loader, hp):
     g = golden_loader(name)

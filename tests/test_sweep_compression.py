@@ -31,6 +31,14 @@ def test_reference_grid_is_reproduced_to_rounding():
     R = 1.0 / (gam[None, :] + lam[:, None])
     Rn = 1.0 / (nodes[None, :] + lam[:, None])
     assert np.max(np.abs(Rn @ W - R) / R) < 1e-14
+    # rounding-negative eigenvalues: exact to rounding down to -gamma_min / 8, which is the library's threshold for keeping the
+    # compressed products (nls_lib.hip); beyond it the pole approaches the first piece and the direct products are taken
+    neg = -gam[0] * np.array([1e-6, 1e-3, 1 / 64, 1 / 16, 1 / 8])
+    Rneg = 1.0 / (gam[None, :] + neg[:, None])
+    assert np.max(np.abs((1.0 / (nodes[None, :] + neg[:, None])) @ W - Rneg) / Rneg) < 1e-14
+    half = np.array([-gam[0] / 2])
+    Rh = 1.0 / (gam[None, :] + half[:, None])
+    assert 1e-12 < np.max(np.abs((1.0 / (nodes[None, :] + half[:, None])) @ W - Rh) / Rh) < 1e-8  # why the threshold is not 1/2
 
 
 @pytest.mark.parametrize("name", ["primal_reg_n3000_d20_D256", "primal_clf_n3000_d16_D256_wz"])

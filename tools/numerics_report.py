@@ -35,3 +35,15 @@ for name in ["primal_reg_n400_d8_D192_exactC", "primal_clf_n300_d6_D128_exactC"]
     r = hp.primal_fit(g["X"], y, g["s"], g["shift"], g["scale"], g["B"], clf, complexity_matrix=g["C"])
     e = [relerr(r[k], g[k]) for k in ("loo_errors_gammas", "beta", "loo_residuals", "loo_leverage", "loo_std", "residuals")]
     print(f"{name:34s} {'same' if r['opt'] == int(g['opt']) else 'DIFF':>7s} {'':>9s} " + " ".join(f"{v:9.1e}" for v in e))
+
+# c1 end to end on THIS box (tests/test_gpu_baseline_sizes.py::test_c1_ames_shaped_estimator_matches_reference): does the
+# package's own pre-step reproduce the reference's separator matrix here (it does wherever the host BLAS rounds the tied
+# nearest-neighbour distances of _affine_separator.py:24-29 like the fixture's host did), and the outcome either way.
+g = load_golden("primal_reg_ames_n2930_d301_D512")
+m = hp.NeoLSSVM().fit(g["X"], g["y"])
+shift, scale, B = m.primal_feature_map_.map_params
+same_A = relerr(B, g["B"]) < 1e-9
+print(f"\nc1 ames-shaped NeoLSSVM().fit on this box: separator matrix identical to the fixture's: {same_A}; shift/scale relerr "
+      f"{relerr(shift, g['shift']):.1e}/{relerr(scale, g['scale']):.1e}; gamma {m.γ_:.6g} vs {float(g['gamma']):.6g}; loo_score {m.loo_score_:.6f} vs "
+      f"{float(g['loo_score']):.6f}" + (f"; beta relerr {relerr(m.β̂_, g['beta']):.1e}, loo_residuals relerr {relerr(m.loo_residuals_, g['loo_residuals']):.1e}" if same_A else
+                                          "; functional check only (tied distances resolved differently by this host's BLAS)"))

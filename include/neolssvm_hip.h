@@ -137,6 +137,17 @@ int nls_rotate_only(nls_ctx* ctx, const double* X, int64_t n, int d, const doubl
  *   environment selects rocSOLVER's zheevd / dsyevd for every eigendecomposition of the library. */
 int nls_tridiag_only(nls_ctx* ctx, void* A, int n, int is_complex, double* d, double* e, void* tau);
 int nls_eigh_only(nls_ctx* ctx, void* A, int n, int is_complex, double* lam);
+/* The eigendecompositions above take a TWO-STAGE reduction for larger matrices (dense -> band of width bw -> tridiagonal, two
+ * back-transformations; csrc/nls_sb.h, nls_chase.h, nls_q2.h): NLS_EVD=twostage / onestage forces / forbids it, NLS_TWOSTAGE_MIN
+ * moves the size rule, NLS_SB_BW = 32 / 64 the band width.  nls_twostage_stage runs ONE stage of it on host data (tests, profiling):
+ *   stage 1: A (n x n column-major, lower) -> band in its bw sub-diagonals + block reflectors below; aux = tau1[n]; info = {failure flag
+ *            (a panel that could not be orthogonalised: the library then falls back to the one-stage panel), columns reduced};
+ *   stage 2: the band held in A's bw sub-diagonals -> d[n], e[n-1]; aux = the chase reflectors V2 (n x n); info[0] != 0: time-out;
+ *   stage 3: aux (n x ncols, column-major) <- Q2 aux with the chase reflectors V2 handed in as A.
+ * nls_twostage_fallbacks: eigendecompositions of this context that fell back from the two-stage to the one-stage reduction. */
+int nls_twostage_stage(nls_ctx* ctx, int stage, void* A, int n, int is_complex, int bw, void* aux, double* d, double* e, int ncols,
+                       int* info);
+long nls_twostage_fallbacks(const nls_ctx* ctx);
 
 /* ---- primal fit ------------------------------------------------------------------------------- */
 typedef struct nls_primal_fit_args {

@@ -19,6 +19,7 @@ from .hotpath import (  # noqa: F401
     primal_predict,
     rotate,
     tridiagonalize,
+    twostage_stage,
 )
 
 from .estimator import AffineSeparator, NeoLSSVM, OrthogonalRandomFourierFeatures  # noqa: E402,F401
@@ -45,4 +46,5 @@ __all__ = [
     "exact_complexity_matrix",
     "eigh",
     "tridiagonalize",
+    "twostage_stage",
 ]

@@ -4,6 +4,9 @@
 // NLS_EVD=rocsolver selects the all-rocSOLVER zheevd / dsyevd instead.
 #include "nls_host.h"
 #include "nls_trd.h"
+#include "nls_sb.h"
+#include "nls_chase.h"
+#include "nls_q2.h"
 
 namespace nls {
 
@@ -166,11 +169,12 @@ static inline rocblas_status bt_trsm(rocblas_handle h, int m, int n, const doubl
 static inline rocblas_operation bt_op_h(const trd::Z*) { return rocblas_operation_conjugate_transpose; }
 static inline rocblas_operation bt_op_h(const double*) { return rocblas_operation_transpose; }
 
-// C (n x ncols, column-major, ldc) <- Q C with the reflectors of trd_fused in A / tau (nls_trd.h, "back-transformation").
+// C (n x ncols, column-major, ldc) <- Q C with Q = H_0 H_1 ... H_{nrefl-1}, reflector j stored in column j of A below its unit entry at
+// row j + off (off = 1: the reflectors of trd_fused; off = B: the panels of the band reduction, nls_sb.h) - "back-transformation".
 template <class T>
-static int apply_q_blocked(nls_ctx* ctx, const T* A, long lda, int n, const T* tau, T* C, long ldc, int ncols) {
+static int apply_q_blocked(nls_ctx* ctx, const T* A, long lda, int n, const T* tau, T* C, long ldc, int ncols, int off = 1, int nrefl = -1) {
   using namespace trd;
-  const int nrefl = n - 1;
+  if (nrefl < 0) nrefl = n - off;
   if (nrefl <= 0 || ncols <= 0) return NLS_OK;
   T *Vw = nullptr, *S = nullptr, *W = nullptr;
   NLSCHK(ws_get_t(ctx, "bt.V", (size_t)n * KBQ, &Vw));
@@ -178,8 +182,8 @@ static int apply_q_blocked(nls_ctx* ctx, const T* A, long lda, int n, const T* t
   NLSCHK(ws_get_t(ctx, "bt.W", (size_t)KBQ * ncols, &W));
   BLASCHK(ctx, rocblas_set_stream(ctx->blas, ctx->stream));
   for (int j0 = ((nrefl - 1) / KBQ) * KBQ; j0 >= 0; j0 -= KBQ) {
-    const int kb = std::min(KBQ, nrefl - j0), r0 = j0 + 1, m = n - r0;
-    hipLaunchKernelGGL(k_trd_copy_v<T>, dim3((unsigned)(((long)m * kb + 255) / 256)), dim3(256), 0, ctx->stream, A, lda, n, j0, kb, Vw);
+    const int kb = std::min(KBQ, nrefl - j0), r0 = j0 + off, m = n - r0;
+    hipLaunchKernelGGL(k_trd_copy_v<T>, dim3((unsigned)(((long)m * kb + 255) / 256)), dim3(256), 0, ctx->stream, A, lda, n, j0, kb, Vw, off);
     BLASCHK(ctx, bt_gemm(ctx->blas, bt_op_h(A), rocblas_operation_none, kb, kb, m, 1.0, Vw, m, Vw, m, 0.0, S, kb));
     hipLaunchKernelGGL(k_trd_tinv<T>, dim3((unsigned)((kb * kb + 255) / 256)), dim3(256), 0, ctx->stream, S, kb, tau, j0);
     HIPCHK(ctx, hipGetLastError());
@@ -188,6 +192,192 @@ static int apply_q_blocked(nls_ctx* ctx, const T* A, long lda, int n, const T* t
     BLASCHK(ctx, bt_gemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, m, ncols, kb, -1.0, Vw, m, W, kb, 1.0, C + r0, ldc));
   }
   return NLS_OK;
+}
+
+// ================================================================================================================
+// Two-stage reduction: dense -> band (nls_sb.h) -> tridiagonal (nls_chase.h), two back-transformations (nls_q2.h and
+// apply_q_blocked with off = B).
+// ================================================================================================================
+template <class T>
+struct TwoStageBw;  // default band width per arithmetic
+template <>
+struct TwoStageBw<double> {
+  static constexpr int B = 64;
+};
+template <>
+struct TwoStageBw<trd::Z> {
+  static constexpr int B = 32;
+};
+
+template <class F>
+static int sb_lds_optin(nls_ctx* ctx, F f, size_t bytes, const char* name) {
+  if (bytes > 65536) {
+    const hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (r != hipSuccess) return fail(ctx, NLS_ERR_HIP, "dynamic LDS opt-in (%zu bytes) for %s failed: %s", bytes, name, hipGetErrorString(r));
+  }
+  return NLS_OK;
+}
+
+// Stage 1.  A: n x n column-major (lda), lower triangle in; out: band in the B sub-diagonals, block reflectors below it, tau1[n].
+// flag (device int): raised when a panel could not be orthogonalised (see nls_sb.h); the caller falls back.
+template <class T, int B>
+static int sy2sb(nls_ctx* ctx, T* A, int n, long lda, T* tau1, int* dflag, int* ncols_reduced) {
+  using namespace sb;
+  *ncols_reduced = 0;
+  HIPCHK(ctx, hipMemsetAsync(tau1, 0, sizeof(T) * (size_t)n, ctx->stream));
+  if (n - B < 2) return NLS_OK;
+  const int nch_max = (n + RW - 1) / RW, nrb_max = (n + RC - 1) / RC;
+  const int split_max = 16;
+  T *Yb = nullptr, *Zb = nullptr, *Wb = nullptr, *Gp = nullptr, *Wp = nullptr, *Mp = nullptr;
+  PanelSmall<T, B>* ps = nullptr;
+  NLSCHK(ws_get_t(ctx, "sb.Y", (size_t)n * B, &Yb));
+  NLSCHK(ws_get_t(ctx, "sb.Z", (size_t)n * B, &Zb));
+  NLSCHK(ws_get_t(ctx, "sb.W", (size_t)n * B, &Wb));
+  NLSCHK(ws_get_t(ctx, "sb.Gp", (size_t)nch_max * B * B, &Gp));
+  NLSCHK(ws_get_t(ctx, "sb.Mp", (size_t)nrb_max * B * B, &Mp));
+  NLSCHK(ws_get_t(ctx, "sb.Wp", (size_t)split_max * n * B, &Wp));
+  NLSCHK(ws_get_t(ctx, "sb.ps", (size_t)1, &ps));
+  const size_t mat = sb_mat_bytes<T, B>(B), tile = sb_mat_bytes<T, B>(64);
+  const size_t lds_chol = 2 * mat, lds_recon = 3 * mat, lds_apply = mat + tile, lds_finish = mat + tile, lds_reduce = 2 * tile, lds_x = tile + mat;
+  NLSCHK(sb_lds_optin(ctx, k_sb_small_chol<T, B>, lds_chol, "k_sb_small_chol"));
+  NLSCHK(sb_lds_optin(ctx, k_sb_small_recon<T, B>, lds_recon, "k_sb_small_recon"));
+  NLSCHK(sb_lds_optin(ctx, k_sb_apply<T, B>, lds_apply, "k_sb_apply"));
+  NLSCHK(sb_lds_optin(ctx, k_sb_finish<T, B>, lds_finish, "k_sb_finish"));
+  NLSCHK(sb_lds_optin(ctx, k_sb_hemm_reduce<T, B>, lds_reduce, "k_sb_hemm_reduce"));
+  NLSCHK(sb_lds_optin(ctx, k_sb_x<T, B>, lds_x, "k_sb_x"));
+  hipStream_t st = ctx->stream;
+  const dim3 red_grid((B * B + 255) / 256);
+  int j = 0;
+  for (;;) {
+    const int m = n - j - B;            // rows below the band in column j
+    const int kb = std::min(B, m - 1);  // columns with something to annihilate (the last panel may be narrower)
+    if (kb <= 0) break;
+    const int zh = B - kb, mh = m + zh;  // zero rows on top of Y for the two-sided update of A[j+kb:, j+kb:]
+    if (zh > 0) {
+      HIPCHK(ctx, hipMemsetAsync(Yb, 0, sizeof(T) * (size_t)n * B, st));
+      HIPCHK(ctx, hipMemsetAsync(Zb, 0, sizeof(T) * (size_t)n * B, st));
+    }
+    T* P = A + (long)(j + B) + (long)j * lda;
+    const int nch = (m + RW - 1) / RW;
+    hipLaunchKernelGGL((k_sb_gram<T, B>), dim3(nch), dim3(256), 0, st, P, lda, m, kb, Gp);
+    hipLaunchKernelGGL((k_sb_reduce<T>), red_grid, dim3(256), 0, st, Gp, nch, B * B, ps->G);
+    hipLaunchKernelGGL((k_sb_small_chol<T, B>), dim3(1), dim3(256), lds_chol, st, kb, m, 0, ps, dflag);
+    hipLaunchKernelGGL((k_sb_apply<T, B>), dim3(nch), dim3(256), lds_apply, st, P, lda, m, kb, ps, Yb + zh, (long)n, Gp);
+    hipLaunchKernelGGL((k_sb_reduce<T>), red_grid, dim3(256), 0, st, Gp, nch, B * B, ps->G);
+    hipLaunchKernelGGL((k_sb_small_chol<T, B>), dim3(1), dim3(256), lds_chol, st, kb, m, 1, ps, dflag);
+    hipLaunchKernelGGL((k_sb_apply<T, B>), dim3(nch), dim3(256), lds_apply, st, Yb + zh, (long)n, m, kb, ps, Yb + zh, (long)n, Gp);
+    hipLaunchKernelGGL((k_sb_reduce<T>), red_grid, dim3(256), 0, st, Gp, nch, B * B, ps->G);
+    hipLaunchKernelGGL((k_sb_small_recon<T, B>), dim3(1), dim3(256), lds_recon, st, kb, Yb + zh, (long)n, ps, P, lda, tau1 + j, dflag);
+    hipLaunchKernelGGL((k_sb_finish<T, B>), dim3(nch), dim3(256), lds_finish, st, Yb, (long)n, m, kb, ps, Zb, P, lda);
+    HIPCHK(ctx, hipGetLastError());
+    T* A22 = A + (long)(j + kb) + (long)(j + kb) * lda;
+    const int NT = (mh + HT - 1) / HT, nrb = (mh + RC - 1) / RC;
+    const int split = std::max(1, std::min({split_max, NT, (2 * ctx->cus + NT - 1) / NT}));
+    hipLaunchKernelGGL((k_sb_hemm<T, B>), dim3(NT, split), dim3(256), 0, st, A22, lda, mh, Zb, (long)n, kb, split, Wp);
+    hipLaunchKernelGGL((k_sb_hemm_reduce<T, B>), dim3(nrb), dim3(256), lds_reduce, st, Wp, split, mh, kb, Zb, Wb, (long)n, Mp);
+    hipLaunchKernelGGL((k_sb_reduce<T>), red_grid, dim3(256), 0, st, Mp, nrb, B * B, ps->G);
+    hipLaunchKernelGGL((k_sb_x<T, B>), dim3(nrb), dim3(256), lds_x, st, Wb, Yb, (long)n, mh, kb, ps);
+    hipLaunchKernelGGL((k_sb_her2k<T>), dim3(NT * (NT + 1) / 2), dim3(256), 0, st, A22, lda, mh, Wb, Yb, (long)n, kb);
+    HIPCHK(ctx, hipGetLastError());
+    j += kb;
+  }
+  *ncols_reduced = j;
+  return NLS_OK;
+}
+
+// Stage 2.  Band part of A (lower, bandwidth B) -> d[n], e[n-1], chase reflectors V2 (n x n).  ctl[1] != 0 afterwards: a workgroup timed out.
+template <class T, int B>
+static int sb2st(nls_ctx* ctx, const T* A, int n, long lda, double* d, double* e, T* V2, unsigned** ctl_out) {
+  using namespace chase;
+  const int ldab = 2 * B + 1;
+  T* AB = nullptr;
+  unsigned* ctl = nullptr;
+  NLSCHK(ws_get_t(ctx, "chase.AB", (size_t)n * ldab, &AB));
+  NLSCHK(ws_get_t(ctx, "chase.ctl", (size_t)n + 16, &ctl));  // [0] next sweep, [1] error, [16 ..] done[s]
+  HIPCHK(ctx, hipMemsetAsync(ctl, 0, sizeof(unsigned) * ((size_t)n + 16), ctx->stream));
+  hipLaunchKernelGGL((sb::k_sb_to_band<T>), dim3((unsigned)(((long)n * ldab + 255) / 256)), dim3(256), 0, ctx->stream, A, lda, n, B, AB, ldab);
+  const size_t lds = std::max(sizeof(ChaseLds<T, B>), (size_t)84 << 10);  // > 80 KiB: one workgroup per CU (hand-off protocol)
+  NLSCHK(sb_lds_optin(ctx, k_chase<T, B>, lds, "k_chase"));
+  int W = n / (2 * B) + 4;
+  if (const char* ew = std::getenv("NLS_CHASE_WG")) W = std::atoi(ew);
+  W = std::max(1, std::min(W, ctx->cus));
+  if (n >= 2) hipLaunchKernelGGL((k_chase<T, B>), dim3(W), dim3(256), lds, ctx->stream, AB, ldab, n, V2, (long)n, d, e, ctl, ctl + 16);
+  HIPCHK(ctx, hipGetLastError());
+  *ctl_out = ctl;
+  return NLS_OK;
+}
+
+// C (n x ncols, column-major ldc) <- Q2 C with the chase reflectors in V2.
+template <class T, int B>
+static int apply_q2(nls_ctx* ctx, const T* V2, int n, T* C, long ldc, int ncols) {
+  using namespace q2;
+  constexpr int NC = 16;
+  if (n < 2 || ncols <= 0) return NLS_OK;
+  const int ngroups = (n - 1 + B - 1) / B;
+  std::vector<int> off((size_t)ngroups + 1, 0);
+  for (int S = 0; S < ngroups; ++S) off[S + 1] = off[S] + q2_nblocks(n, B, S);
+  const int nblocks = off[ngroups];
+  int* doff = nullptr;
+  T* Tb = nullptr;
+  NLSCHK(ws_get_t(ctx, "q2.off", (size_t)ngroups + 1, &doff));
+  NLSCHK(ws_get_t(ctx, "q2.T", (size_t)nblocks * B * B, &Tb));
+  HIPCHK(ctx, hipMemcpyAsync(doff, off.data(), sizeof(int) * off.size(), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // off is a local
+  const size_t mat = (sizeof(T) * B * (B + 1) + 15) & ~(size_t)15, wmat = (sizeof(T) * B * (NC + 1) + 15) & ~(size_t)15;
+  const size_t lds_t = 2 * sizeof(T) * B * (B + 1);
+  NLSCHK(sb_lds_optin(ctx, k_q2_tfactor<T, B>, lds_t, "k_q2_tfactor"));
+  hipLaunchKernelGGL((k_q2_tfactor<T, B>), dim3(nblocks), dim3(256), lds_t, ctx->stream, V2, (long)n, n, doff, ngroups, Tb);
+  // groups per pass: as many as the LDS ring allows (2 G block rows of the slab), at most 8
+  int G = 8;
+  if (const char* eg = std::getenv("NLS_Q2_GROUPS")) G = std::max(1, std::atoi(eg));
+  static const bool valu = [] { const char* m = std::getenv("NLS_Q2_VALU"); return m && m[0] == '1'; }();  // the VALU form (reference; tests)
+  constexpr bool can_mfma = !(sizeof(T) == 16 && B == 64);
+  if (!valu && can_mfma) {
+    if constexpr (can_mfma) {
+      using M = Q2M<T, B>;
+      while (G > 1 && M::lds_bytes(G) > ((size_t)158 << 10)) --G;
+      G = std::min(G, ngroups);
+      NLSCHK(sb_lds_optin(ctx, k_q2_apply_mfma<T, B>, M::lds_bytes(G), "k_q2_apply_mfma"));
+      hipLaunchKernelGGL((k_q2_apply_mfma<T, B>), dim3((unsigned)((ncols + NC - 1) / NC)), dim3(256), M::lds_bytes(G), ctx->stream, V2, (long)n, n, doff, ngroups, Tb,
+                         C, ldc, ncols, G);
+      HIPCHK(ctx, hipGetLastError());
+    }
+    return NLS_OK;
+  }
+  auto lds_apply = [&](int g) { return ((sizeof(T) * (size_t)(2 * g) * B * (NC + 1) + 15) & ~(size_t)15) + 2 * mat + 2 * wmat; };
+  while (G > 1 && lds_apply(G) > ((size_t)158 << 10)) --G;
+  if (lds_apply(G) > ((size_t)158 << 10)) return fail(ctx, NLS_ERR_ARG, "second back-transformation: complex blocks of %d do not fit the LDS", B);
+  G = std::min(G, ngroups);
+  NLSCHK(sb_lds_optin(ctx, k_q2_apply<T, B, NC>, lds_apply(G), "k_q2_apply"));
+  hipLaunchKernelGGL((k_q2_apply<T, B, NC>), dim3((unsigned)((ncols + NC - 1) / NC)), dim3(256), lds_apply(G), ctx->stream, V2, (long)n, n, doff, ngroups, Tb, C,
+                     ldc, ncols, G);
+  HIPCHK(ctx, hipGetLastError());
+  return NLS_OK;
+}
+
+__global__ void k_real_to_complex(const double* src, long n_elems, double2* dst) {
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i < n_elems) dst[i] = make_double2(src[i], 0.0);
+}
+
+// Band width of the two-stage reduction: NLS_SB_BW = 32 / 64 overrides the default of the arithmetic (TwoStageBw).
+static int evd_bw(bool cplx) {
+  if (cplx) return TwoStageBw<trd::Z>::B;  // complex blocks of 64 do not fit the LDS of the second back-transformation
+  if (const char* e = std::getenv("NLS_SB_BW")) {
+    const int b = std::atoi(e);
+    if (b == 32 || b == 64) return b;
+  }
+  return TwoStageBw<double>::B;
+}
+
+// When to take the two-stage reduction: NLS_EVD=twostage / onestage forces it; otherwise by size (NLS_TWOSTAGE_MIN, default below).
+static bool evd_use_two_stage(int n, bool cplx) {
+  const char* m = std::getenv("NLS_EVD");
+  if (m && std::string(m) == "twostage") return n >= 4;
+  if (m && std::string(m) == "onestage") return false;
+  int nmin = cplx ? 768 : 1536;
+  if (const char* e = std::getenv("NLS_TWOSTAGE_MIN")) nmin = std::atoi(e);
+  return n >= nmin && n >= 4;
 }
 
 static bool evd_rocsolver_backtransform() {  // NLS_EVD_UNMTR=rocsolver: zunmtr / dormtr instead of apply_q_blocked (diagnostic)
@@ -257,6 +447,119 @@ static int evd_unscale(nls_ctx* ctx, double* lam, int n, double factor) {
   return NLS_OK;
 }
 
+// stedc on the (real) tridiagonal matrix.  collective: rank 0 computes, everybody receives (lam, Cr) - the ranks then pair the same
+// eigenvalues with the same basis whatever stedc does on clustered spectra.  A failure on rank 0 (API error or info != 0) travels to all
+// ranks through the broadcast flag instead of leaving them blocked in the collective.
+static int stedc_real(nls_ctx* ctx, int n, double* lam, double* e_work, double* Cr, rocblas_int* dinfo, bool collective) {
+  if (!(collective && multi_rank(ctx))) {
+    BLASCHK(ctx, rocsolver_dstedc(ctx->blas, rocblas_evect_tridiagonal, n, lam, e_work, Cr, n, dinfo));
+    return check_info(ctx, dinfo, "rocsolver_dstedc");
+  }
+  double* flag = nullptr;
+  NLSCHK(ws_get_t(ctx, "evd.flag", 2, &flag));
+  double hflag = 0.0;
+  if (ctx->rank == 0) {
+    const rocblas_status st = rocsolver_dstedc(ctx->blas, rocblas_evect_tridiagonal, n, lam, e_work, Cr, n, dinfo);
+    rocblas_int info = 0;
+    const hipError_t h1 = hipMemcpyAsync(&info, dinfo, sizeof(info), hipMemcpyDeviceToHost, ctx->stream);
+    const hipError_t h2 = hipStreamSynchronize(ctx->stream);
+    hflag = st != rocblas_status_success ? -1.0 : ((h1 != hipSuccess || h2 != hipSuccess) ? -2.0 : (double)info);
+  }
+  HIPCHK(ctx, hipMemcpyAsync(flag, &hflag, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  NLSCHK(do_broadcast(ctx, flag, 1, 0));
+  HIPCHK(ctx, hipMemcpyAsync(&hflag, flag, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (hflag != 0.0)
+    return fail(ctx, NLS_ERR_LINALG, "rocsolver_dstedc on rank 0: %s (code %d)", hflag > 0 ? "no convergence" : "API failure", (int)hflag);
+  NLSCHK(do_broadcast(ctx, lam, (size_t)n, 0));
+  NLSCHK(do_broadcast(ctx, Cr, (size_t)n * n, 0));
+  return NLS_OK;
+}
+
+// Eigendecomposition through the two-stage reduction.  A (n x n, lower) is destroyed; eigenvectors in C (n x n, distinct from A).
+// *used = false: the band reduction met a panel it could not orthogonalise (exactly dependent / zero columns); A has been restored
+// and the caller takes the one-stage path.  collective: see evd_hermitian_core.
+template <class T, int B>
+static int evd_two_stage(nls_ctx* ctx, T* A, int n, double* lam, double* e_work, rocblas_int* dinfo, T* C, bool collective, bool* used) {
+  constexpr bool CPLX = sizeof(T) == 16;
+  *used = false;
+  T *Acopy = nullptr, *tau1 = nullptr, *V2 = nullptr;
+  int* dflag = nullptr;
+  NLSCHK(ws_get_t(ctx, CPLX ? "evd2.Acopy" : "evd2.Acopy_r", (size_t)n * n, &Acopy));
+  NLSCHK(ws_get_t(ctx, CPLX ? "evd2.tau1" : "evd2.tau1_r", (size_t)n, &tau1));
+  NLSCHK(ws_get_t(ctx, CPLX ? "evd2.V2" : "evd2.V2_r", (size_t)n * n, &V2));
+  NLSCHK(ws_get_t(ctx, "evd2.flag", 4, &dflag));
+  HIPCHK(ctx, hipMemcpyAsync(Acopy, A, sizeof(T) * (size_t)n * n, hipMemcpyDeviceToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(dflag, 0, 4 * sizeof(int), ctx->stream));
+  int nred = 0;
+  unsigned* ctl = nullptr;
+  // NLS_EVD_PROFILE=1: stage times (HIP events, one line on stderr per eigendecomposition)
+  static const bool prof = [] { const char* m = std::getenv("NLS_EVD_PROFILE"); return m && m[0] == '1'; }();
+  hipEvent_t ev[6] = {};
+  auto mark = [&](int i) {
+    if (prof) {
+      if (!ev[i]) (void)hipEventCreate(&ev[i]);
+      (void)hipEventRecord(ev[i], ctx->stream);
+    }
+  };
+  mark(0);
+  NLSCHK((sy2sb<T, B>(ctx, A, n, n, tau1, dflag, &nred)));
+  mark(1);
+  NLSCHK((sb2st<T, B>(ctx, A, n, n, lam, e_work, V2, &ctl)));
+  mark(2);
+  int hflag = 0;
+  unsigned hctl[2] = {0, 0};
+  HIPCHK(ctx, hipMemcpyAsync(&hflag, dflag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(hctl, ctl, sizeof(hctl), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (hflag != 0) {
+    HIPCHK(ctx, hipMemcpyAsync(A, Acopy, sizeof(T) * (size_t)n * n, hipMemcpyDeviceToDevice, ctx->stream));
+    ctx->twostage_fallbacks++;
+    return NLS_OK;
+  }
+  if (hctl[1] != 0) return fail(ctx, NLS_ERR_HIP, "band -> tridiagonal chase: a workgroup timed out waiting for its predecessor (n = %d)", n);
+  double* Cr = nullptr;
+  if (CPLX)
+    NLSCHK(ws_get_t(ctx, "evd2.Cr", (size_t)n * n, &Cr));
+  else
+    Cr = reinterpret_cast<double*>(C);
+  NLSCHK(stedc_real(ctx, n, lam, e_work, Cr, dinfo, collective));
+  mark(3);
+  long c0 = 0, c1 = n;
+  const bool split = collective && multi_rank(ctx);
+  if (split) {
+    c0 = (long)n * ctx->rank / ctx->world;
+    c1 = (long)n * (ctx->rank + 1) / ctx->world;
+  }
+  if (CPLX && c1 > c0) {
+    const long cnt = (c1 - c0) * n;
+    hipLaunchKernelGGL(k_real_to_complex, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream, Cr + c0 * n, cnt,
+                       reinterpret_cast<double2*>(C) + c0 * n);
+    HIPCHK(ctx, hipGetLastError());
+  }
+  NLSCHK((apply_q2<T, B>(ctx, V2, n, C + c0 * n, n, (int)(c1 - c0))));
+  mark(4);
+  NLSCHK(apply_q_blocked<T>(ctx, A, n, n, tau1, C + c0 * n, n, (int)(c1 - c0), B, nred));
+  mark(5);
+  if (prof) {
+    (void)hipStreamSynchronize(ctx->stream);
+    float t[5] = {0, 0, 0, 0, 0};
+    for (int i = 0; i < 5; ++i) (void)hipEventElapsedTime(&t[i], ev[i], ev[i + 1]);
+    std::fprintf(stderr, "[nls evd two-stage] n=%d %s bw=%d cols=%ld: band %.3f ms, chase %.3f, stedc %.3f, Q2 %.3f, Q1 %.3f, total %.3f\n", n,
+                 CPLX ? "complex" : "real", B, c1 - c0, t[0], t[1], t[2], t[3], t[4], t[0] + t[1] + t[2] + t[3] + t[4]);
+    for (auto& e : ev)
+      if (e) (void)hipEventDestroy(e);
+  }
+  if (split) {
+    std::vector<size_t> offs((size_t)ctx->world + 1);
+    const size_t comps = CPLX ? 2 : 1;
+    for (int r = 0; r <= ctx->world; ++r) offs[r] = comps * n * (size_t)((long)n * r / ctx->world);
+    NLSCHK(do_allgather_blocks(ctx, reinterpret_cast<double*>(C), offs));
+  }
+  *used = true;
+  return NLS_OK;
+}
+
 // Hermitian: A (n x n complex column-major, lower) is destroyed; eigenvalues ascending in lam, eigenvectors
 // (columns) in *Q, which is either A itself (rocSOLVER path) or the workspace "evd.C".
 // collective = true (nls_primal_fit, where every rank holds the same all-reduced matrix): stedc on rank 0 + broadcast,
@@ -274,6 +577,14 @@ static int evd_hermitian_core(nls_ctx* ctx, double2* A, int n, double* lam, doub
   double2* C = nullptr;
   NLSCHK(ws_get_t(ctx, "evd.tau", (size_t)n, &tau));
   NLSCHK(ws_get_t(ctx, "evd.C", (size_t)n * n, &C));
+  if (evd_use_two_stage(n, true)) {
+    bool used = false;
+    NLSCHK((evd_two_stage<trd::Z, 32>(ctx, reinterpret_cast<trd::Z*>(A), n, lam, e_work, dinfo, reinterpret_cast<trd::Z*>(C), collective, &used)));
+    if (used) {
+      *Q = C;
+      return NLS_OK;
+    }
+  }
   NLSCHK(trd_fused<trd::Z>(ctx, reinterpret_cast<trd::Z*>(A), n, n, lam, e_work, tau));
   if (collective && multi_rank(ctx) && n >= 64) {
     // Every rank holds the same all-reduced matrix and the tridiagonalisation is bit-reproducible, so the reflectors are
@@ -334,6 +645,17 @@ static int evd_symmetric_core(nls_ctx* ctx, double* A, int n, double* lam, doubl
   double *tau = nullptr, *C = nullptr;
   NLSCHK(ws_get_t(ctx, "evd.taur", (size_t)n, &tau));
   NLSCHK(ws_get_t(ctx, "evd.Cr", (size_t)n * n, &C));
+  if (evd_use_two_stage(n, false)) {
+    bool used = false;
+    if (evd_bw(false) == 32)
+      NLSCHK((evd_two_stage<double, 32>(ctx, A, n, lam, e_work, dinfo, C, false, &used)));
+    else
+      NLSCHK((evd_two_stage<double, 64>(ctx, A, n, lam, e_work, dinfo, C, false, &used)));
+    if (used) {
+      *Q = C;
+      return NLS_OK;
+    }
+  }
   NLSCHK(trd_fused<double>(ctx, A, n, n, lam, e_work, tau));
   BLASCHK(ctx, rocsolver_dstedc(ctx->blas, rocblas_evect_tridiagonal, n, lam, e_work, C, n, dinfo));
   NLSCHK(check_info(ctx, dinfo, "rocsolver_dstedc"));
@@ -418,3 +740,72 @@ extern "C" int nls_eigh_only(nls_ctx* ctx, void* A, int n, int is_complex, doubl
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return NLS_OK;
 }
+
+// ---- stage hooks of the two-stage reduction (tests / profiling) ------------------------------------------------------------------
+template <class T>
+static int twostage_stage_impl(nls_ctx* ctx, int stage, void* A, int n, int bw, void* aux, double* d, double* e, int ncols, int* info) {
+  const size_t esz = sizeof(T);
+  T *dA = nullptr, *daux = nullptr;
+  double *dd = nullptr, *de = nullptr;
+  int* dflag = nullptr;
+  NLSCHK(ws_get_t(ctx, "hook.A", (size_t)n * n * (esz / 8), reinterpret_cast<double**>(&dA)));
+  NLSCHK(ws_get_t(ctx, "hook2.aux", (size_t)n * std::max(n, ncols) * (esz / 8), reinterpret_cast<double**>(&daux)));
+  NLSCHK(ws_get_t(ctx, "hook.d", (size_t)n, &dd));
+  NLSCHK(ws_get_t(ctx, "hook.e", (size_t)n, &de));
+  NLSCHK(ws_get_t(ctx, "evd2.flag", 4, &dflag));
+  HIPCHK(ctx, hipMemcpyAsync(dA, A, esz * (size_t)n * n, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(dflag, 0, 4 * sizeof(int), ctx->stream));
+  constexpr bool CPLX = sizeof(T) == 16;
+  if (CPLX && bw != 32) return fail(ctx, NLS_ERR_ARG, "nls_twostage_stage: complex matrices take band width 32 only");
+  if (stage == 1) {  // dense -> band: A in/out (band + block reflectors), aux = tau1[n] out, info = {flag, columns reduced}
+    int nred = 0;
+    if (bw == 32)
+      NLSCHK((sy2sb<T, 32>(ctx, dA, n, n, daux, dflag, &nred)));
+    else if constexpr (!CPLX)
+      NLSCHK((sy2sb<T, 64>(ctx, dA, n, n, daux, dflag, &nred)));
+    HIPCHK(ctx, hipMemcpyAsync(A, dA, esz * (size_t)n * n, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(aux, daux, esz * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(info, dflag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    info[1] = nred;
+  } else if (stage == 2) {  // band (the lower bw sub-diagonals of A) -> d, e; aux = V2 (n x n) out; info[0] = chase error word
+    unsigned* ctl = nullptr;
+    HIPCHK(ctx, hipMemsetAsync(daux, 0, esz * (size_t)n * n, ctx->stream));
+    if (bw == 32)
+      NLSCHK((sb2st<T, 32>(ctx, dA, n, n, dd, de, daux, &ctl)));
+    else if constexpr (!CPLX)
+      NLSCHK((sb2st<T, 64>(ctx, dA, n, n, dd, de, daux, &ctl)));
+    unsigned hctl[2] = {0, 0};
+    HIPCHK(ctx, hipMemcpyAsync(hctl, ctl, sizeof(hctl), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(aux, daux, esz * (size_t)n * n, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(d, dd, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+    if (n > 1) HIPCHK(ctx, hipMemcpyAsync(e, de, sizeof(double) * (n - 1), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    info[0] = (int)hctl[1];
+    info[1] = (int)hctl[0];
+  } else if (stage == 3) {  // aux (n x ncols) <- Q2 aux with the chase reflectors V2 = A
+    HIPCHK(ctx, hipMemcpyAsync(daux, aux, esz * (size_t)n * ncols, hipMemcpyHostToDevice, ctx->stream));
+    if (bw == 32)
+      NLSCHK((apply_q2<T, 32>(ctx, dA, n, daux, n, ncols)));
+    else if constexpr (!CPLX)
+      NLSCHK((apply_q2<T, 64>(ctx, dA, n, daux, n, ncols)));
+    HIPCHK(ctx, hipMemcpyAsync(aux, daux, esz * (size_t)n * ncols, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  } else {
+    return fail(ctx, NLS_ERR_ARG, "nls_twostage_stage: stage must be 1, 2 or 3");
+  }
+  return NLS_OK;
+}
+
+extern "C" int nls_twostage_stage(nls_ctx* ctx, int stage, void* A, int n, int is_complex, int bw, void* aux, double* d, double* e, int ncols,
+                                  int* info) {
+  if (!ctx) return NLS_ERR_ARG;
+  if (!A || !aux || !info || n < 1 || (bw != 32 && bw != 64)) return fail(ctx, NLS_ERR_ARG, "nls_twostage_stage: null pointer, n < 1 or bw not in {32, 64}");
+  if (stage == 2 && (!d || !e)) return fail(ctx, NLS_ERR_ARG, "nls_twostage_stage: stage 2 needs d and e");
+  if (stage == 3 && ncols < 1) return fail(ctx, NLS_ERR_ARG, "nls_twostage_stage: stage 3 needs ncols >= 1");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  return is_complex ? twostage_stage_impl<trd::Z>(ctx, stage, A, n, bw, aux, d, e, ncols, info)
+                    : twostage_stage_impl<double>(ctx, stage, A, n, bw, aux, d, e, ncols, info);
+}
+
+extern "C" long nls_twostage_fallbacks(const nls_ctx* ctx) { return ctx ? ctx->twostage_fallbacks : -1; }

@@ -61,6 +61,7 @@ struct nls_ctx {
   ncclComm_t comm = nullptr;  // native RCCL communicator (nls_comm_init_rank); takes precedence over the hook
   double* comm_scratch = nullptr;  // a few doubles on the device for nls_comm_allreduce
   size_t ws_bytes = 0;        // bytes currently held by the workspace arena
+  long twostage_fallbacks = 0;  // eigendecompositions whose band reduction met a degenerate panel and fell back to the one-stage panel
   std::vector<nls_factor*> factors;
   // XCD patch shape of k_rotate3 (NLS_ROT_PATCH=RxC; 0x0 = plain order, the default: patches raise the L2 hit rate
   // from 0.57 to 0.78 and halve the fabric traffic but run 1-4 % slower, profiles/r01_pmc_summary.md)
@@ -257,10 +258,13 @@ static int do_allgather_blocks(nls_ctx* ctx, double* dbuf, const std::vector<siz
   if (ctx->comm) {
     const RcclApi* api = rccl_api(nullptr);
     RCCLCHK(ctx, api, api->GroupStart());
-    for (int r = 0; r < ctx->world; ++r)
+    ncclResult_t first_bad = ncclSuccess;
+    for (int r = 0; r < ctx->world && first_bad == ncclSuccess; ++r)
       if (offs[r + 1] > offs[r])
-        RCCLCHK(ctx, api, api->Broadcast(dbuf + offs[r], dbuf + offs[r], offs[r + 1] - offs[r], ncclDouble, r, ctx->comm, ctx->stream));
-    RCCLCHK(ctx, api, api->GroupEnd());
+        first_bad = api->Broadcast(dbuf + offs[r], dbuf + offs[r], offs[r + 1] - offs[r], ncclDouble, r, ctx->comm, ctx->stream);
+    const ncclResult_t end = api->GroupEnd();  // always: a failed call must not leave the group open
+    if (first_bad != ncclSuccess) return fail(ctx, NLS_ERR_COMM, "ncclBroadcast (all-gather of blocks) failed: %s", api->GetErrorString(first_bad));
+    if (end != ncclSuccess) return fail(ctx, NLS_ERR_COMM, "ncclGroupEnd failed: %s", api->GetErrorString(end));
     return NLS_OK;
   }
   const size_t lo = offs[ctx->rank], hi = offs[ctx->rank + 1], tot = offs[ctx->world];

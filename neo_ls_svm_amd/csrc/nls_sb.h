@@ -1,0 +1,776 @@
+// Two-stage tridiagonalisation, stage 1: Hermitian / real symmetric dense -> band (lower bandwidth B), in place, by panels
+// of B columns (P4: eigh(A / c), _neo_ls_svm.py:120; D2: eigh(sn K sn), :265 - the reference calls LAPACK there; the
+// algorithm below is this library's own).
+//
+// Why: the one-stage panel (nls_trd.h) pays one matrix-vector product per COLUMN - two dependent kernel launches per column
+// at n <= 6144 (latency bound: 23 us x 4097 columns at c3) and one sweep over the whole lower triangle per column beyond
+// (HBM bound: 1.33 TB at real n = 1e4).  Here a PANEL of B columns costs a dozen launches and the trailing matrix is
+// read three times per panel by matrix-matrix kernels.
+//
+// One panel (columns j .. j+kb-1, P = A[j+B:, j:j+kb], m x kb, m = n - j - B, kb = min(B, m - 1)):
+//   1. orthogonal factor of P by shifted CholeskyQR3 (three Gram / Cholesky / triangular-multiply passes; the shift of the
+//      first pass, 11 (m kb + kb (kb+1)) u trace(G), keeps its Cholesky alive up to kappa(P) ~ 1/u): k_sb_gram,
+//      k_sb_small_chol, k_sb_apply;
+//   2. Householder reconstruction (Ballard et al., "Reconstructing Householder vectors from TSQR", 2014): a modified LU
+//      of the orthonormal factor gives Y (unit lower trapezoidal) and T (upper triangular) with Q = I - Y T Y^H and
+//      P = Q[:, :kb] R: k_sb_small_recon, k_sb_finish;
+//   3. two-sided update of A22 = A[j+kb:, j+kb:] (the block of Y zero-padded by B - kb rows on top, so that the narrower LAST
+//      panel also transforms the panel columns it does not factor): Z = Y T, W = A22 Z (k_sb_hemm + k_sb_hemm_reduce),
+//      M = Z^H W (k_sb_small_m), X = W - Y M / 2 (k_sb_x), A22 -= X Y^H + Y X^H (k_sb_her2k).
+// Y stays below the band in A (LAPACK layout: unit diagonal implied at row j + B + c of column j + c), tau1[j + c] = T[c][c]
+// (the block is a product of kb elementary reflectors, so the blocked back-transformation of nls_evd.hip rebuilds its
+// T^-1 = striu(Y^H Y) + diag(1 / tau) from Y and tau1 alone).
+//
+// Failure: a Cholesky pivot <= 0 / NaN or a second-pass Gram matrix further than 1e-6 from I (kappa(P) beyond ~1e15:
+// exactly dependent or zero panel columns, e.g. a diagonal matrix) raises flag[0]; the driver then reduces the saved copy of
+// the matrix with the one-stage panel instead.  All reductions run over per-block partials in a fixed order: bit-reproducible.
+#pragma once
+#include "nls_trd.h"
+
+namespace nls {
+namespace sb {
+using namespace trd;
+
+constexpr int RC = 64;  // rows per workgroup of the panel kernels
+
+// Dynamic LDS (several kernels need more than the 64 KiB a static allocation may take; the driver opts in with hipFuncSetAttribute).
+extern __shared__ __attribute__((aligned(16))) unsigned char sb_smem[];
+template <class T, int COLS>
+__device__ __forceinline__ T (*sb_carve(int rows, size_t& off))[COLS] {
+  T(*p)[COLS] = reinterpret_cast<T(*)[COLS]>(sb_smem + off);
+  off += (((size_t)rows * COLS * sizeof(T)) + 15) & ~(size_t)15;
+  return p;
+}
+template <class T, int B>
+constexpr size_t sb_mat_bytes(int rows) {
+  return (((size_t)rows * (B + 1) * sizeof(T)) + 15) & ~(size_t)15;
+}
+
+template <class T>
+__device__ __forceinline__ T zero_() {
+  return make_<T>(0.0, 0.0);
+}
+template <class T>
+__device__ __forceinline__ T one_() {
+  return make_<T>(1.0, 0.0);
+}
+__device__ __forceinline__ Z neg_(Z a) { return {-a.re, -a.im}; }
+__device__ __forceinline__ double neg_(double a) { return -a; }
+__device__ __forceinline__ bool finite_(Z a) { return isfinite(a.re) && isfinite(a.im); }
+__device__ __forceinline__ bool finite_(double a) { return isfinite(a); }
+
+// ================================================================================================================
+// Panel kernels.  Rows are handled 256 per workgroup (thread = row for the triangular solves), Gram matrices are
+// accumulated over four 64-row LDS tiles per workgroup, partial Gram matrices are summed by an element-parallel kernel
+// (k_sb_reduce) in a fixed order, and the B x B factorisations keep their matrix in registers (thread (r, cg) owns row r,
+// columns cg + TPR q) with ONE barrier per elimination step (the pivot column / row travels through a double-buffered
+// LDS vector).  No explicit inverses: Q = P R^-1 is a row-wise back substitution with R in LDS (uniform reads).
+// ================================================================================================================
+constexpr int RW = 256;  // rows per workgroup of the panel kernels
+
+template <int B>
+struct Small {
+  static constexpr int TPR = 256 / B;  // threads per row
+  static constexpr int CPT = B / TPR;  // columns per thread
+};
+
+// Per-panel small state in global memory
+template <class T, int B>
+struct PanelSmall {
+  T G[B * B];      // reduced Gram matrix / M = Z^H W (input of the small kernels), i + B j
+  T Rs[B * B];     // upper triangular matrix of the next row solve (R1, R2, then M = U R3), identity outside the leading block
+  T Racc[B * B];   // R3 R2 R1 so far (upper triangular)
+  T Tm[B * B];     // T of the block reflector (upper triangular)
+  T Y1[B * B];     // top block of Y (unit lower triangular), explicit
+};
+
+// out[e] = sum_p part[p * count + e] in index order (bit-reproducible), 8 loads in flight per thread
+template <class T>
+__global__ void __launch_bounds__(256) k_sb_reduce(const T* part, int nparts, int count, T* out) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= count) return;
+  T s = zero_<T>();
+  int p = 0;
+  for (; p + 8 <= nparts; p += 8) {
+    T v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = part[(long)(p + q) * count + e];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s = s + v[q];
+  }
+  for (; p < nparts; ++p) s = s + part[(long)p * count + e];
+  out[e] = s;
+}
+
+// Gram of the rows held in a 64 x B LDS tile, accumulated into acc (thread (ti, tj): entries (ti + 16 x, tj + 16 y))
+template <class T, int B>
+__device__ __forceinline__ void gram_tile_accumulate(T (*Ps)[B + 1], T (&acc)[B / 16][B / 16]) {
+  constexpr int TI = B / 16;
+  const int ti = threadIdx.x % 16, tj = threadIdx.x / 16;
+#pragma unroll 4
+  for (int r = 0; r < 64; ++r) {
+    T a[TI], b[TI];
+#pragma unroll
+    for (int x = 0; x < TI; ++x) {
+      a[x] = conj_(Ps[r][ti + 16 * x]);
+      b[x] = Ps[r][tj + 16 * x];
+    }
+#pragma unroll
+    for (int x = 0; x < TI; ++x)
+#pragma unroll
+      for (int y = 0; y < TI; ++y) acc[x][y] = acc[x][y] + a[x] * b[y];
+  }
+}
+template <class T, int B>
+__device__ __forceinline__ void gram_store(const T (&acc)[B / 16][B / 16], T* out) {
+  constexpr int TI = B / 16;
+  const int ti = threadIdx.x % 16, tj = threadIdx.x / 16;
+#pragma unroll
+  for (int x = 0; x < TI; ++x)
+#pragma unroll
+    for (int y = 0; y < TI; ++y) out[(ti + 16 * x) + B * (tj + 16 * y)] = acc[x][y];
+}
+
+// ---- panel Gram partials: Gp[block][i + B j] = sum over the block's 256 rows of conj(P[r][i]) P[r][j] ------------------
+template <class T, int B>
+__global__ void __launch_bounds__(256) k_sb_gram(const T* P, long ldp, int m, int kb, T* Gp) {
+  constexpr int TI = B / 16;
+  __shared__ T Ps[64][B + 1];
+  T acc[TI][TI];
+#pragma unroll
+  for (int x = 0; x < TI; ++x)
+#pragma unroll
+    for (int y = 0; y < TI; ++y) acc[x][y] = zero_<T>();
+  for (int sub = 0; sub < RW / 64; ++sub) {
+    const int r0 = blockIdx.x * RW + sub * 64;
+    if (r0 >= m) break;  // uniform
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 64 * B; idx += 256) {
+      const int r = idx % 64, c = idx / 64;
+      Ps[r][c] = (r0 + r < m && c < kb) ? P[(long)(r0 + r) + (long)c * ldp] : zero_<T>();
+    }
+    __syncthreads();
+    gram_tile_accumulate<T, B>(Ps, acc);
+  }
+  gram_store<T, B>(acc, Gp + (long)blockIdx.x * B * B);
+}
+
+// In-register Cholesky of the leading k x k block: thread (r, cg) holds a[q] = A[r][cg + TPR q] (lower triangle meaningful) and leaves
+// L there.  col: double-buffered LDS vector [2][B].  Returns false (uniformly) when a pivot is <= 0 or not finite (the factor is then
+// garbage but finite control flow is kept).
+template <class T, int B>
+__device__ __forceinline__ bool reg_cholesky(T (&a)[Small<B>::CPT], int k, T (*col)[B]) {
+  using S = Small<B>;
+  const int r = threadIdx.x / S::TPR, cg = threadIdx.x % S::TPR;
+  bool ok = true;
+#pragma unroll
+  for (int p = 0; p < B; ++p) {
+    if (p < k) {  // uniform
+      if (cg == p % S::TPR) col[p & 1][r] = a[p / S::TPR];
+      __syncthreads();
+      double d = real_(col[p & 1][p]);
+      if (!(d > 0.0) || !isfinite(d)) {
+        ok = false;
+        d = 1.0;
+      }
+      const double sq = sqrt(d), inv = 1.0 / sq;
+      const T lr = inv * col[p & 1][r];
+#pragma unroll
+      for (int q = 0; q < S::CPT; ++q) {
+        const int c = cg + S::TPR * q;
+        if (c > p && c <= r && r < k) {
+          T v = a[q] - lr * conj_(inv * col[p & 1][c]);
+          if (c == r) v = make_<T>(real_(v), 0.0);
+          a[q] = v;
+        }
+      }
+      if (cg == p % S::TPR && r >= p && r < k) a[p / S::TPR] = r == p ? make_<T>(sq, 0.0) : lr;
+    }
+  }
+  return ok;
+}
+
+// q R = p for one row per thread: R (upper triangular, identity outside the leading block) in LDS, dinv[j] = 1 / R[j][j].  In place.
+template <class T, int B, bool UNIT>
+__device__ __forceinline__ void row_solve_upper(T (&x)[B], T (*R)[B + 1], const T* dinv) {
+#pragma unroll
+  for (int j = 0; j < B; ++j) {
+    if (!UNIT) x[j] = x[j] * dinv[j];
+    const T xj = x[j];
+#pragma unroll
+    for (int c = j + 1; c < B; ++c) x[c] = x[c] - xj * R[j][c];
+  }
+}
+
+// Row i of X (LDS, B x B) solved in place against the upper triangular R (LDS): x R = x_old.  Own function (not inlined) so that its B
+// registers do not add to the caller's live set.
+template <class T, int B, bool UNIT>
+__device__ __attribute__((noinline)) void lds_row_solve_upper(T (*X)[B + 1], int i, T (*R)[B + 1], const T* dinv) {
+  T x[B];
+#pragma unroll
+  for (int c = 0; c < B; ++c) x[c] = X[i][c];
+  row_solve_upper<T, B, UNIT>(x, R, dinv);
+#pragma unroll
+  for (int c = 0; c < B; ++c) X[i][c] = x[c];
+}
+
+// ---- small kernel of passes 1 and 2:  G (+ shift) = R^H R;  ps->Rs = R;  Racc = R Racc -----------------------------------------
+template <class T, int B>
+__global__ void __launch_bounds__(256) k_sb_small_chol(int kb, int m, int pass, PanelSmall<T, B>* ps, int* flag) {
+  using S = Small<B>;
+  size_t off = 0;
+  T(*R)[B + 1] = sb_carve<T, B + 1>(B, off);
+  T(*Ra)[B + 1] = sb_carve<T, B + 1>(B, off);
+  __shared__ T col[2][B];
+  __shared__ double sc[1];
+  const int r = threadIdx.x / S::TPR, cg = threadIdx.x % S::TPR;
+  T a[S::CPT];
+#pragma unroll
+  for (int q = 0; q < S::CPT; ++q) a[q] = ps->G[r + B * (cg + S::TPR * q)];
+  if (pass == 0) {
+    // trace through LDS: the diagonal entry of row r is held by the thread with cg == r % TPR (static register index: compare per q)
+#pragma unroll
+    for (int q = 0; q < S::CPT; ++q)
+      if (cg + S::TPR * q == r) col[0][r] = r < kb ? a[q] : zero_<T>();
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      double tr = 0.0;
+      for (int i = threadIdx.x; i < B; i += 64) tr += real_(col[0][i]);
+      tr = wave_sum(tr);
+      if (threadIdx.x == 0) sc[0] = 11.0 * ((double)m * kb + (double)kb * (kb + 1)) * 1.1102230246251565e-16 * tr + 1e-300;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < S::CPT; ++q)
+      if (cg + S::TPR * q == r && r < kb) a[q] = a[q] + make_<T>(sc[0], 0.0);
+    __syncthreads();
+  }
+  const bool ok = reg_cholesky<T, B>(a, kb, col);
+  if (!ok && threadIdx.x == 0) flag[0] = 1;
+  // R = L^H (upper; identity outside the leading block)
+#pragma unroll
+  for (int q = 0; q < S::CPT; ++q) {
+    const int c = cg + S::TPR * q;
+    const bool in = r < kb && c < kb;
+    if (in && c <= r) R[c][r] = conj_(a[q]);
+    if (in && c < r) R[r][c] = zero_<T>();
+    if (!in) R[r][c] = r == c ? one_<T>() : zero_<T>();
+    Ra[r][c] = pass == 0 ? (r == c ? one_<T>() : zero_<T>()) : ps->Racc[r + B * c];
+  }
+  __syncthreads();
+  T acc[S::CPT];
+#pragma unroll
+  for (int q = 0; q < S::CPT; ++q) acc[q] = zero_<T>();
+#pragma unroll 2
+  for (int t = 0; t < B; ++t) {
+    const T x = R[r][t];
+#pragma unroll
+    for (int q = 0; q < S::CPT; ++q) acc[q] = acc[q] + x * Ra[t][cg + S::TPR * q];
+  }
+#pragma unroll
+  for (int q = 0; q < S::CPT; ++q) {
+    const int c = cg + S::TPR * q;
+    ps->Racc[r + B * c] = acc[q];
+    ps->Rs[r + B * c] = R[r][c];
+  }
+}
+
+// ---- apply pass: rows of Q = rows of P solved against R (ps->Rs), written to dst; Gram partials of the result -----------------------
+template <class T, int B>
+__global__ void __launch_bounds__(256) k_sb_apply(const T* src, long lds_, int m, int kb, const PanelSmall<T, B>* ps, T* dst, long ldd, T* Gp) {
+  constexpr int TI = B / 16;
+  size_t off = 0;
+  T(*Rs)[B + 1] = sb_carve<T, B + 1>(B, off);
+  T(*Ps)[B + 1] = sb_carve<T, B + 1>(64, off);
+  __shared__ T dinv[B];
+  for (int e = threadIdx.x; e < B * B; e += 256) Rs[e % B][e / B] = ps->Rs[e];
+  if (threadIdx.x < B) dinv[threadIdx.x] = inv_(ps->Rs[threadIdx.x + B * threadIdx.x]);
+  const long row = (long)blockIdx.x * RW + threadIdx.x;
+  T x[B];
+#pragma unroll
+  for (int c = 0; c < B; ++c) x[c] = (row < m && c < kb) ? src[row + (long)c * lds_] : zero_<T>();
+  __syncthreads();
+  row_solve_upper<T, B, false>(x, Rs, dinv);
+  if (row < m) {
+#pragma unroll
+    for (int c = 0; c < B; ++c)
+      if (c < kb) dst[row + (long)c * ldd] = x[c];
+  }
+  T acc[TI][TI];
+#pragma unroll
+  for (int a = 0; a < TI; ++a)
+#pragma unroll
+    for (int b = 0; b < TI; ++b) acc[a][b] = zero_<T>();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int sub = 0; sub < RW / 64; ++sub) {
+    if ((long)blockIdx.x * RW + sub * 64 >= m) break;  // uniform
+    __syncthreads();
+    if (wave == sub) {
+#pragma unroll
+      for (int c = 0; c < B; ++c) Ps[lane][c] = x[c];
+    }
+    __syncthreads();
+    gram_tile_accumulate<T, B>(Ps, acc);
+  }
+  gram_store<T, B>(acc, Gp + (long)blockIdx.x * B * B);
+}
+
+// ---- small kernel of pass 3 + Householder reconstruction ----------------------------------------------------------------
+// In: ps->G = Q2^H Q2 (Q2 = the twice-orthogonalised panel in Yb), Yb's top kb x kb block.  Out: ps->Rs = M = U R3 (rows of Q2 below the top
+// block become rows of Y by one solve against M), ps->Y1, ps->Tm, the kb x kb R factor S R3 R2 R1 written into the band block of A
+// (upper triangle; zeros below), tau1.
+template <class T, int B>
+__global__ void __launch_bounds__(256, 1) k_sb_small_recon(int kb, const T* Ytop, long ldy, PanelSmall<T, B>* ps, T* Aband, long lda, T* tau1, int* flag) {
+  using S = Small<B>;
+  size_t off = 0;
+  T(*R3)[B + 1] = sb_carve<T, B + 1>(B, off);   // R3, later U
+  T(*X)[B + 1] = sb_carve<T, B + 1>(B, off);    // Racc, later Y1^H
+  T(*Q)[B + 1] = sb_carve<T, B + 1>(B, off);    // Qtop rows (after the solve), later -U S^-1 rows -> T
+  __shared__ T col[2][B], Sd[B], dinv[B];
+  __shared__ int bad;
+  const int r = threadIdx.x / S::TPR, cg = threadIdx.x % S::TPR;
+  if (threadIdx.x == 0) bad = 0;
+  T a[S::CPT];
+#pragma unroll
+  for (int q = 0; q < S::CPT; ++q) a[q] = ps->G[r + B * (cg + S::TPR * q)];
+  __syncthreads();
+  {  // orthogonality after the second pass: |G3 - I| < 1e-6, else the third pass cannot finish the job
+    double dev = 0.0;
+#pragma unroll
+    for (int q = 0; q < S::CPT; ++q) {
+      const int c = cg + S::TPR * q;
+      if (r < kb && c < kb) {
+        const double x = abs2_(a[q] - (r == c ? one_<T>() : zero_<T>()));
+        dev = (x > dev || !(x == x)) ? x : dev;
+      }
+    }
+    if (!(dev < 1e-12)) bad = 1;
+  }
+  __syncthreads();
+  bool ok = bad == 0;
+  ok = reg_cholesky<T, B>(a, kb, col) && ok;
+  if (!ok && threadIdx.x == 0) flag[0] = 1;
+#pragma unroll
+  for (int q = 0; q < S::CPT; ++q) {
+    const int c = cg + S::TPR * q;
+    const bool in = r < kb && c < kb;
+    if (in && c <= r) R3[c][r] = conj_(a[q]);
+    if (in && c < r) R3[r][c] = zero_<T>();
+    if (!in) R3[r][c] = r == c ? one_<T>() : zero_<T>();
+    X[r][c] = ps->Racc[r + B * c];
+  }
+  __syncthreads();
+  if (threadIdx.x < B) dinv[threadIdx.x] = inv_(R3[threadIdx.x][threadIdx.x]);
+  // Rtot = R3 Racc (kept in registers: rtot[q] = Rtot[r][c])
+  T rtot[S::CPT];
+#pragma unroll
+  for (int q = 0; q < S::CPT; ++q) rtot[q] = zero_<T>();
+#pragma unroll 2
+  for (int t = 0; t < B; ++t) {
+    const T x = R3[r][t];
+#pragma unroll
+    for (int q = 0; q < S::CPT; ++q) rtot[q] = rtot[q] + x * X[t][cg + S::TPR * q];
+  }
+  __syncthreads();
+  // Qtop = Q2top R3^-1: thread i < B solves row i
+  for (int e = threadIdx.x; e < B * B; e += 256) {
+    const int i = e % B, c = e / B;
+    Q[i][c] = (i < kb && c < kb) ? Ytop[(long)i + (long)c * ldy] : zero_<T>();
+  }
+  __syncthreads();
+  if (threadIdx.x < B) lds_row_solve_upper<T, B, false>(Q, threadIdx.x, R3, dinv);
+  __syncthreads();
+  // Modified LU of Qtop - S, in place in the LDS matrix Q (a plain loop: two barriers per step; unrolled in registers it spills)
+  for (int p = 0; p < kb; ++p) {
+    const T d = Q[p][p];
+    const double ad = sqrt(abs2_(d));
+    const T s = ad > 0.0 ? (-1.0 / ad) * d : make_<T>(-1.0, 0.0);
+    const T piv = d - s;  // |piv| = |d| + 1: no pivoting needed
+    const T mult = r > p && r < kb ? Q[r][p] * inv_(piv) : zero_<T>();
+    T upd[S::CPT];
+#pragma unroll
+    for (int q = 0; q < S::CPT; ++q) {
+      const int c = cg + S::TPR * q;
+      upd[q] = (c > p && c < kb) ? mult * Q[p][c] : zero_<T>();
+    }
+    __syncthreads();
+    if (r > p && r < kb) {
+#pragma unroll
+      for (int q = 0; q < S::CPT; ++q) {
+        const int c = cg + S::TPR * q;
+        if (c > p && c < kb) Q[r][c] = Q[r][c] - upd[q];
+      }
+      if (cg == p % S::TPR) Q[r][p] = mult;
+    }
+    if (threadIdx.x == 0) {
+      Q[p][p] = piv;
+      Sd[p] = s;
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int q = 0; q < S::CPT; ++q) a[q] = Q[r][cg + S::TPR * q];
+  __syncthreads();
+  // a now holds L (strict lower, unit diagonal implied) and U (upper incl. diagonal).
+  // R factor of the Householder QR: diag(S) Rtot into the band block (upper triangle; zeros below: k_sb_finish puts Y there)
+#pragma unroll
+  for (int q = 0; q < S::CPT; ++q) {
+    const int c = cg + S::TPR * q;
+    if (r < kb && c < kb) Aband[(long)r + (long)c * lda] = r <= c ? Sd[r] * rtot[q] : zero_<T>();
+  }
+  // Y1 (unit lower) -> ps->Y1 and X := Y1^H (unit upper, identity outside);  Q := U -> later M = U R3
+#pragma unroll
+  for (int q = 0; q < S::CPT; ++q) {
+    const int c = cg + S::TPR * q;
+    const bool in = r < kb && c < kb;
+    const T y = in ? (r > c ? a[q] : (r == c ? one_<T>() : zero_<T>())) : (r == c ? one_<T>() : zero_<T>());
+    ps->Y1[r + B * c] = y;
+    X[c][r] = conj_(y);
+    Q[r][c] = in ? (r <= c ? a[q] : zero_<T>()) : (r == c ? one_<T>() : zero_<T>());
+  }
+  __syncthreads();
+  // M = U R3 (upper triangular) -> ps->Rs
+  {
+    T acc[S::CPT];
+#pragma unroll
+    for (int q = 0; q < S::CPT; ++q) acc[q] = zero_<T>();
+#pragma unroll 2
+    for (int t = 0; t < B; ++t) {
+      const T x = Q[r][t];
+#pragma unroll
+      for (int q = 0; q < S::CPT; ++q) acc[q] = acc[q] + x * R3[t][cg + S::TPR * q];
+    }
+#pragma unroll
+    for (int q = 0; q < S::CPT; ++q) ps->Rs[r + B * (cg + S::TPR * q)] = acc[q];
+  }
+  // T Y1^H = -U S^-1: thread i < B solves row i of T against the unit upper triangular X = Y1^H (right-hand sides in Q, in place)
+  __syncthreads();
+  for (int e = threadIdx.x; e < B * B; e += 256) {
+    const int i = e % B, c = e / B;
+    Q[i][c] = (i < kb && c < kb && c >= i) ? neg_(Q[i][c] * conj_(Sd[c])) : zero_<T>();
+  }
+  __syncthreads();
+  if (threadIdx.x < B) lds_row_solve_upper<T, B, true>(Q, threadIdx.x, X, dinv);
+  __syncthreads();
+  for (int e = threadIdx.x; e < B * B; e += 256) {
+    const int i = e % B, c = e / B;
+    const T t = (i < kb && c < kb && c >= i) ? Q[i][c] : zero_<T>();
+    ps->Tm[i + B * c] = t;
+    if (c == i && i < kb) tau1[i] = t;
+  }
+}
+
+// ---- finish: Y (explicit, m x kb) and Z = Y T into the panel buffers, Y's strictly-lower part into A below the band -----------------
+// Row r < kb of Y comes from Y1, rows >= kb are the rows of Q2 solved against M = U R3 (ps->Rs).  Yb / Zb have zh = B - kb zero rows on top.
+template <class T, int B>
+__global__ void __launch_bounds__(256) k_sb_finish(T* Yb, long ldy, int m, int kb, const PanelSmall<T, B>* ps, T* Zb, T* Apanel, long lda) {
+  size_t off = 0;
+  T(*Ms)[B + 1] = sb_carve<T, B + 1>(B, off);  // M, later T
+  T(*Ps)[B + 1] = sb_carve<T, B + 1>(64, off);
+  __shared__ T dinv[B];
+  const int zh = B - kb;
+  for (int e = threadIdx.x; e < B * B; e += 256) Ms[e % B][e / B] = ps->Rs[e];
+  if (threadIdx.x < B) dinv[threadIdx.x] = inv_(ps->Rs[threadIdx.x + B * threadIdx.x]);
+  const long row = (long)blockIdx.x * RW + threadIdx.x;
+  T x[B];
+  if (row < kb) {
+#pragma unroll
+    for (int c = 0; c < B; ++c) x[c] = ps->Y1[row + B * c];
+  } else {
+#pragma unroll
+    for (int c = 0; c < B; ++c) x[c] = (row < m && c < kb) ? Yb[(row + zh) + (long)c * ldy] : zero_<T>();
+  }
+  __syncthreads();
+  if (row >= kb) row_solve_upper<T, B, false>(x, Ms, dinv);
+  if (row < m) {
+#pragma unroll
+    for (int c = 0; c < B; ++c)
+      if (c < kb) {
+        Yb[(row + zh) + (long)c * ldy] = x[c];
+        if (row > c) Apanel[row + (long)c * lda] = x[c];  // below the unit diagonal of Y: below the band of A
+      }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < B * B; e += 256) Ms[e % B][e / B] = ps->Tm[e];
+  // Z = Y T through 64-row tiles: thread (row = tid / 4, quarter = tid % 4)
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  constexpr int CQ = B / 4;
+  for (int sub = 0; sub < RW / 64; ++sub) {
+    const long r0 = (long)blockIdx.x * RW + sub * 64;
+    if (r0 >= m) break;  // uniform
+    __syncthreads();
+    if (wave == sub) {
+#pragma unroll
+      for (int c = 0; c < B; ++c) Ps[lane][c] = (c < kb) ? x[c] : zero_<T>();
+    }
+    __syncthreads();
+    const int rr = threadIdx.x / 4, q4 = threadIdx.x % 4;
+    T z[CQ];
+#pragma unroll
+    for (int c = 0; c < CQ; ++c) z[c] = zero_<T>();
+#pragma unroll 2
+    for (int t = 0; t < B; ++t) {
+      const T y = Ps[rr][t];
+#pragma unroll
+      for (int c = 0; c < CQ; ++c) z[c] = z[c] + y * Ms[t][q4 + 4 * c];
+    }
+    if (r0 + rr < m) {
+#pragma unroll
+      for (int c = 0; c < CQ; ++c)
+        if (q4 + 4 * c < kb) Zb[(r0 + rr + zh) + (long)(q4 + 4 * c) * ldy] = z[c];
+    }
+  }
+}
+
+// ---- W = A22 Z for the Hermitian A22 stored in the lower triangle ----------------------------------------------------------
+// Row block I (64 rows) of the result needs the tiles A[I][J] (J < I), the Hermitian diagonal tile and A[K][I]^H (K > I): NT = mh / 64
+// tiles in all, every row block the same number - the lower triangle is read twice per product, all workgroups do equal work.  The
+// tiles of a row block are dealt round-robin to SPLIT workgroups (blockIdx.y) whose partial results k_sb_hemm_reduce adds in a fixed order.
+constexpr int HT = 64;   // tile edge
+constexpr int HK = 16;   // K slice held in LDS
+template <class T, int B>
+__global__ void __launch_bounds__(256) k_sb_hemm(const T* A, long lda, int mh, const T* Zb, long ldz, int kb, int split, T* Wp) {
+  constexpr int TC = B / 16;  // columns per thread (thread = 4 rows x TC columns)
+  __shared__ T As[HK][HT + 1], Zs[HK][B + 1];
+  const int I = blockIdx.x, part = blockIdx.y;
+  const int NT = (mh + HT - 1) / HT;
+  const int ty = threadIdx.x / 16, tx = threadIdx.x % 16;
+  T acc[4][TC];
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int y = 0; y < TC; ++y) acc[x][y] = zero_<T>();
+  for (int t = part; t < NT; t += split) {
+    // tile t of the cross of row block I: t < I: A[I][t];  t == I: diagonal;  t > I: A[t][I]^H
+    const bool trans = t > I;
+    const long trow = (long)(trans ? t : I) * HT, tcol = (long)(trans ? I : t) * HT;  // stored tile: rows trow.., cols tcol..
+    for (int k0 = 0; k0 < HT; k0 += HK) {
+      __syncthreads();
+      // As[k][r] = Atile_effective[r][k0 + k]:  effective = stored tile (t < I), its conjugate transpose (t > I), Hermitian fill (t == I)
+      for (int idx = threadIdx.x; idx < HK * HT; idx += 256) {
+        int r, k;
+        T v;
+        if (!trans) {
+          r = idx % HT;
+          k = idx / HT;  // coalesced along the rows of a stored column
+          const long gr = trow + r, gc = tcol + k0 + k;
+          if (gr < mh && gc < mh) {
+            if (t == I && gc > gr)
+              v = conj_(A[gc + gr * lda]);  // upper part of the diagonal tile from its mirror
+            else
+              v = A[gr + gc * lda];
+            if (t == I && gc == gr) v = make_<T>(real_(v), 0.0);
+          } else {
+            v = zero_<T>();
+          }
+        } else {
+          k = idx % HK;
+          r = idx / HK;  // effective[r][k0 + k] = conj(stored[k0 + k][r]): coalesced along stored rows k0.. of column r
+          const long gr = trow + k0 + k, gc = tcol + r;
+          v = (gr < mh && gc < mh) ? conj_(A[gr + gc * lda]) : zero_<T>();
+        }
+        As[k][r] = v;
+      }
+      // Zs[k][c] = Z[(column block of the effective tile) * 64 + k0 + k][c]
+      {
+        const long zr0 = (long)t * HT + k0;
+        for (int idx = threadIdx.x; idx < HK * B; idx += 256) {
+          const int k = idx % HK, c = idx / HK;
+          Zs[k][c] = (zr0 + k < mh && c < kb) ? Zb[(zr0 + k) + (long)c * ldz] : zero_<T>();
+        }
+      }
+      __syncthreads();
+#pragma unroll 4
+      for (int k = 0; k < HK; ++k) {
+        T a[4], z[TC];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) a[x] = As[k][4 * ty + x];
+#pragma unroll
+        for (int y = 0; y < TC; ++y) z[y] = Zs[k][tx + 16 * y];
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+          for (int y = 0; y < TC; ++y) acc[x][y] = acc[x][y] + a[x] * z[y];
+      }
+    }
+  }
+  T* out = Wp + ((long)part * mh) * B;  // partial p: [mh][B] row-major
+#pragma unroll
+  for (int x = 0; x < 4; ++x) {
+    const long gr = (long)I * HT + 4 * ty + x;
+    if (gr < mh) {
+#pragma unroll
+      for (int y = 0; y < TC; ++y) out[gr * B + tx + 16 * y] = acc[x][y];
+    }
+  }
+}
+
+// W = sum of the partials (fixed order) -> Wb (column-major, ld);  per row block the partial of M = Z^H W
+template <class T, int B>
+__global__ void __launch_bounds__(256) k_sb_hemm_reduce(const T* Wp, int split, int mh, int kb, const T* Zb, T* Wb, long ld, T* Mp) {
+  constexpr int TI = B / 16;
+  size_t off = 0;
+  T(*Ws)[B + 1] = sb_carve<T, B + 1>(RC, off);
+  T(*Zs)[B + 1] = sb_carve<T, B + 1>(RC, off);
+  const int r0 = blockIdx.x * RC;
+  for (int idx = threadIdx.x; idx < RC * B; idx += 256) {
+    const int c = idx % B, r = idx / B;  // partials are row-major
+    T s = zero_<T>();
+    if (r0 + r < mh && c < kb)
+      for (int p = 0; p < split; ++p) s = s + Wp[((long)p * mh + r0 + r) * B + c];
+    Ws[r][c] = s;
+  }
+  for (int idx = threadIdx.x; idx < RC * B; idx += 256) {
+    const int r = idx % RC, c = idx / RC;
+    Zs[r][c] = (r0 + r < mh && c < kb) ? Zb[(long)(r0 + r) + (long)c * ld] : zero_<T>();
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < RC * B; idx += 256) {
+    const int r = idx % RC, c = idx / RC;
+    if (r0 + r < mh && c < kb) Wb[(long)(r0 + r) + (long)c * ld] = Ws[r][c];
+  }
+  const int ti = threadIdx.x % 16, tj = threadIdx.x / 16;
+  T acc[TI][TI];
+#pragma unroll
+  for (int x = 0; x < TI; ++x)
+#pragma unroll
+    for (int y = 0; y < TI; ++y) acc[x][y] = zero_<T>();
+#pragma unroll 4
+  for (int r = 0; r < RC; ++r) {
+    T a[TI], b[TI];
+#pragma unroll
+    for (int x = 0; x < TI; ++x) {
+      a[x] = conj_(Zs[r][ti + 16 * x]);
+      b[x] = Ws[r][tj + 16 * x];
+    }
+#pragma unroll
+    for (int x = 0; x < TI; ++x)
+#pragma unroll
+      for (int y = 0; y < TI; ++y) acc[x][y] = acc[x][y] + a[x] * b[y];
+  }
+  T* out = Mp + (long)blockIdx.x * B * B;
+#pragma unroll
+  for (int x = 0; x < TI; ++x)
+#pragma unroll
+    for (int y = 0; y < TI; ++y) out[(ti + 16 * x) + B * (tj + 16 * y)] = acc[x][y];
+}
+
+// X = W - Y M / 2  (in place over Wb), M = the symmetrised reduced sum of the Z^H W partials
+template <class T, int B>
+__global__ void __launch_bounds__(256) k_sb_x(T* Wb, const T* Yb, long ld, int mh, int kb, const PanelSmall<T, B>* ps) {
+  size_t off = 0;
+  T(*Ys)[B + 1] = sb_carve<T, B + 1>(RC, off);
+  T(*Ms)[B + 1] = sb_carve<T, B + 1>(B, off);
+  const int r0 = blockIdx.x * RC;
+  for (int idx = threadIdx.x; idx < RC * B; idx += 256) {
+    const int r = idx % RC, c = idx / RC;
+    Ys[r][c] = (r0 + r < mh && c < kb) ? Yb[(long)(r0 + r) + (long)c * ld] : zero_<T>();
+  }
+  // M = Z^H A22 Z is Hermitian; the reduced sum (ps->G) is symmetrised here (rounding makes its two triangles differ in the last bit)
+  for (int e = threadIdx.x; e < B * B; e += 256) {
+    const int i = e % B, j = e / B;
+    T v = 0.5 * (ps->G[i + B * j] + conj_(ps->G[j + B * i]));
+    if (i == j) v = make_<T>(real_(v), 0.0);
+    Ms[i][j] = v;
+  }
+  __syncthreads();
+  constexpr int CQ = B / 4;
+  const int r = threadIdx.x / 4, q4 = threadIdx.x % 4;
+  T acc[CQ];
+#pragma unroll
+  for (int c = 0; c < CQ; ++c) acc[c] = zero_<T>();
+#pragma unroll 2
+  for (int t = 0; t < B; ++t) {
+    const T a = Ys[r][t];
+#pragma unroll
+    for (int c = 0; c < CQ; ++c) acc[c] = acc[c] + a * Ms[t][q4 + 4 * c];
+  }
+  if (r0 + r < mh) {
+#pragma unroll
+    for (int c = 0; c < CQ; ++c) {
+      const int col = q4 + 4 * c;
+      if (col < kb) {
+        const long o = (long)(r0 + r) + (long)col * ld;
+        Wb[o] = Wb[o] - 0.5 * acc[c];
+      }
+    }
+  }
+}
+
+// A22 -= X Y^H + Y X^H on the lower triangle (64 x 64 tiles R >= C; 4 x 4 register blocks; the structure of k_trd_rank2k with both
+// operand panels in buffers)
+template <class T>
+__global__ void __launch_bounds__(256) k_sb_her2k(T* A, long lda, int mh, const T* Xb, const T* Yb, long ld, int kb) {
+  constexpr int UT = 64, UK = 16;
+  __shared__ T Xr[UK][UT], Yr[UK][UT], Xc[UK][UT], Yc[UK][UT];
+  int t = blockIdx.x, R = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+  while ((R + 1) * (R + 2) / 2 <= t) ++R;
+  while (R * (R + 1) / 2 > t) --R;
+  const int C = t - R * (R + 1) / 2;
+  const int tx = threadIdx.x % 16, ty = threadIdx.x / 16;
+  const long r0 = (long)R * UT, c0 = (long)C * UT;
+  T acc[4][4];
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int y = 0; y < 4; ++y) acc[x][y] = make_<T>(0.0, 0.0);
+  for (int k0 = 0; k0 < kb; k0 += UK) {
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < UK * UT / 256; ++it) {
+      const int row = threadIdx.x % UT, k = threadIdx.x / UT + (256 / UT) * it;
+      const bool kin = k0 + k < kb;
+      const long rr = r0 + row, cc = c0 + row;
+      Xr[k][row] = kin && rr < mh ? Xb[rr + (long)(k0 + k) * ld] : make_<T>(0.0, 0.0);
+      Yr[k][row] = kin && rr < mh ? Yb[rr + (long)(k0 + k) * ld] : make_<T>(0.0, 0.0);
+      Xc[k][row] = kin && cc < mh ? conj_(Xb[cc + (long)(k0 + k) * ld]) : make_<T>(0.0, 0.0);
+      Yc[k][row] = kin && cc < mh ? conj_(Yb[cc + (long)(k0 + k) * ld]) : make_<T>(0.0, 0.0);
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int k = 0; k < UK; ++k) {
+      T xr[4], yr[4], xc[4], yc[4];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        xr[x] = Xr[k][tx + 16 * x];
+        yr[x] = Yr[k][tx + 16 * x];
+        xc[x] = Xc[k][ty + 16 * x];
+        yc[x] = Yc[k][ty + 16 * x];
+      }
+#pragma unroll
+      for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) acc[x][y] = acc[x][y] + xr[x] * yc[y] + yr[x] * xc[y];
+    }
+  }
+#pragma unroll
+  for (int y = 0; y < 4; ++y)
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      const long r = r0 + tx + 16 * x, c = c0 + ty + 16 * y;
+      if (r < mh && c < mh && r >= c) {
+        T v = A[r + c * lda] - acc[x][y];
+        if (r == c) v = make_<T>(real_(v), 0.0);
+        A[r + c * lda] = v;
+      }
+    }
+}
+
+// ---- dense (lower, bandwidth B) -> band storage AB[(i - j) + j * ldab], rows 0 .. 2B (the rows beyond B: room for the bulges, zero) ----
+template <class T>
+__global__ void k_sb_to_band(const T* A, long lda, int n, int B, T* AB, int ldab) {
+  const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (idx >= (long)n * ldab) return;
+  const int o = (int)(idx % ldab);
+  const long j = idx / ldab;
+  const long i = j + o;
+  T v = make_<T>(0.0, 0.0);
+  if (o <= B && i < n) {
+    v = A[i + j * lda];
+    if (o == 0) v = make_<T>(real_(v), 0.0);
+  }
+  AB[idx] = v;
+}
+
+}  // namespace sb
+}  // namespace nls

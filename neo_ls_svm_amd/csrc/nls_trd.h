@@ -816,15 +816,17 @@ __global__ void k_trd_restore_subdiag(T* A, long lda, const double* e, int j0, i
 // two large GEMMs (W = V^H C, C -= V X) around one kb x kb triangular solve (T^-1 X = W) - no sequential larft, and the
 // first GEMM has 512 rows instead of rocSOLVER's 64 (65 workgroups = a quarter of the CUs at n = 4097).
 constexpr int KBQ = 512;  // 256: 146.8 ms, 512: 143.9 ms, 1024: 143.7 ms per EVD at n = 4097
-// Vw[q][p] (column-major m x kb): reflector j0 + p restricted to rows r0 = j0 + 1 .. n-1: 0 above its unit entry
+// Vw[q][p] (column-major m x kb): reflector j0 + p restricted to rows r0 = j0 + off .. n-1: 0 above its unit entry.  off = 1: the
+// one-stage reflectors (unit entry on the first sub-diagonal); off = B: the block reflectors of the band reduction (nls_sb.h: unit
+// entry on the B-th sub-diagonal, the band itself lies above it and is not read).
 template <class T>
-__global__ void k_trd_copy_v(const T* A, long lda, int n, int j0, int kb, T* Vw) {
-  const long m = n - (j0 + 1);
+__global__ void k_trd_copy_v(const T* A, long lda, int n, int j0, int kb, T* Vw, int off) {
+  const long m = n - (j0 + off);
   const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
   if (idx >= m * kb) return;
   const long q = idx % m;
   const int p = (int)(idx / m);
-  Vw[idx] = q < p ? make_<T>(0.0, 0.0) : (q == p ? make_<T>(1.0, 0.0) : A[(j0 + 1 + q) + (long)(j0 + p) * lda]);
+  Vw[idx] = q < p ? make_<T>(0.0, 0.0) : (q == p ? make_<T>(1.0, 0.0) : A[(j0 + off + q) + (long)(j0 + p) * lda]);
 }
 // S (kb x kb, = V^H V) -> T^-1 = striu(S) + diag(1 / tau); tau = 0 (H = I) gets a huge diagonal, i.e. a zero row of X
 template <class T>

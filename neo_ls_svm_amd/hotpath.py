@@ -196,6 +196,31 @@ def eigh(A, ctx: Context | None = None):
     return lam, Af
 
 
+def twostage_stage(stage: int, A, bw: int, aux=None, ctx: Context | None = None):
+    """One stage of the two-stage reduction behind ``eigh`` on host data (test / profiling hook, ``nls_twostage_stage``):
+    1: dense -> band ``(A_out, tau1, failed, columns_reduced)``; 2: band -> tridiagonal ``(d, e, V2, timed_out)``;
+    3: ``aux <- Q2 aux`` with the chase reflectors ``A`` = V2."""
+    ctx = ctx or default_context()
+    A = np.asarray(A)
+    cplx = np.iscomplexobj(A)
+    dt = np.complex128 if cplx else np.float64
+    Af = np.asfortranarray(A, dtype=dt).copy(order="F")
+    n = Af.shape[0]
+    info = np.zeros(2, dtype=np.int32)
+    if stage == 1:
+        tau1 = np.zeros(n, dtype=dt)
+        ctx._check(ctx.lib.nls_twostage_stage(ctx.handle, 1, Af.ctypes.data, n, int(cplx), bw, tau1.ctypes.data, None, None, 0, info.ctypes.data))
+        return Af, tau1, bool(info[0]), int(info[1])
+    if stage == 2:
+        V2 = np.zeros((n, n), dtype=dt, order="F")
+        d, e = np.empty(n), np.zeros(max(n - 1, 1))
+        ctx._check(ctx.lib.nls_twostage_stage(ctx.handle, 2, Af.ctypes.data, n, int(cplx), bw, V2.ctypes.data, d.ctypes.data, e.ctypes.data, 0, info.ctypes.data))
+        return d, e[: n - 1], V2, bool(info[0])
+    Cm = np.asfortranarray(aux, dtype=dt).copy(order="F")
+    ctx._check(ctx.lib.nls_twostage_stage(ctx.handle, 3, Af.ctypes.data, n, int(cplx), bw, Cm.ctypes.data, None, None, Cm.shape[1], info.ctypes.data))
+    return Cm
+
+
 def bin_stats(X, labels, sample_weight=None, ctx: Context | None = None):
     """(centers, spreads), each nbins x d: per class bin the weighted median and weighted mean absolute deviation of
     every input column (``_affine_normalizer.py:72-79``) on the GPU (segmented radix sort + one scan per segment)."""

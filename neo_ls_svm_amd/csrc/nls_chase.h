@@ -45,23 +45,84 @@ __device__ __forceinline__ void st_sc1(Z* p, Z v) {
 
 __host__ __device__ inline int chase_nstages(int n, int B, int s) { return s <= n - 2 ? (n - 2 - s) / B + 1 : 0; }
 
+typedef unsigned int chase_u4 __attribute__((ext_vector_type(4)));
+typedef unsigned int chase_u2 __attribute__((ext_vector_type(2)));
+constexpr int CHASE_SC1 = 16;               // aux bit of the raw buffer builtins: sc1
+constexpr unsigned CHASE_OOB = 0x7ffffff0u;  // beyond num_records: loads return 0, stores are dropped
+
+// Band element I/O through a buffer descriptor: agent-scope (sc1) accesses the compiler treats as ordinary loads / stores (they
+// stay in flight together; __hip_atomic_load is waited for one by one), out-of-range elements through the descriptor's bounds check.
+__device__ __forceinline__ double chase_ld(__amdgpu_buffer_rsrc_t rs, unsigned off, double) {
+  const chase_u2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)off, 0, CHASE_SC1);
+  return __hiloint2double((int)v.y, (int)v.x);
+}
+__device__ __forceinline__ Z chase_ld(__amdgpu_buffer_rsrc_t rs, unsigned off, Z) {
+  const chase_u4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, CHASE_SC1);
+  return {__hiloint2double((int)v.y, (int)v.x), __hiloint2double((int)v.w, (int)v.z)};
+}
+__device__ __forceinline__ void chase_st(__amdgpu_buffer_rsrc_t rs, unsigned off, double x) {
+  chase_u2 v;
+  v.x = (unsigned)__double2loint(x);
+  v.y = (unsigned)__double2hiint(x);
+  __builtin_amdgcn_raw_buffer_store_b64(v, rs, (int)off, 0, CHASE_SC1);
+}
+__device__ __forceinline__ void chase_st(__amdgpu_buffer_rsrc_t rs, unsigned off, Z x) {
+  chase_u4 v;
+  v.x = (unsigned)__double2loint(x.re);
+  v.y = (unsigned)__double2hiint(x.re);
+  v.z = (unsigned)__double2loint(x.im);
+  v.w = (unsigned)__double2hiint(x.im);
+  __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)off, 0, CHASE_SC1);
+}
+
+// LDS-only barrier: __syncthreads() also drains the vector-memory counter, which would wait for the prefetch loads and the stores
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <class T, int B>
 struct ChaseLds {
   T Bs[B][B + 1];
   T Ds[B][B + 1];
   T v[B], vn[B], w[B], u[B], pv[B];
-  T sc_t[4];        // tau (current), taun, c
+  T sc_t[4];        // [1] taun, [2] c = vn^H w
   double sc_d[2];   // betan
   int sweep;
   int abort;
+  int pre_ok;
 };
 
-template <int TPRV, class T>
-__device__ __forceinline__ T row_group_sum(T v) {  // sum over TPRV adjacent lanes (same value in all of them)
-#pragma unroll
-  for (int m = 1; m < TPRV; m <<= 1) v = v + shfl_xor_(v, m);
+// Cross-lane sums on the DPP path (quad_perm / row_half_mirror / row_mirror inside a row of 16 lanes, v_readlane across rows): a
+// __shfl_xor goes through ds_bpermute (an LDS round trip per step and 32-bit half), which made the reductions half of a stage.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ Z dpp_mov(Z v) {
+  return {dpp_mov<CTRL>(v.re), dpp_mov<CTRL>(v.im)};
+}
+// sum over the 16 lanes of a DPP row, the same value in all of them
+template <class T>
+__device__ __forceinline__ T row16_sum(T v) {
+  v = v + dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]: lane ^ 1
+  v = v + dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]: lane ^ 2
+  v = v + dpp_mov<0x141>(v);  // row_half_mirror: the other quad of the 8
+  v = v + dpp_mov<0x140>(v);  // row_mirror: the other half of the 16
   return v;
 }
+template <int TPRV, class T>
+__device__ __forceinline__ T row_group_sum(T v) {  // sum over TPRV (4 or 8) adjacent lanes, the same value in all of them
+  v = v + dpp_mov<0xB1>(v);
+  v = v + dpp_mov<0x4E>(v);
+  if (TPRV == 8) v = v + dpp_mov<0x141>(v);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+  v = row16_sum(v);
+  return lane_bcast(v, 0) + lane_bcast(v, 16) + lane_bcast(v, 32) + lane_bcast(v, 48);
+}
+__device__ __forceinline__ Z wave_sum_dpp(Z v) { return {wave_sum_dpp(v.re), wave_sum_dpp(v.im)}; }
 
 // wait until done[sp] >= need (one lane polls; everybody leaves together).  Returns false on timeout / abort.
 __device__ __forceinline__ bool chase_wait(const unsigned* done, int sp, unsigned need, unsigned* ctl, int* abort_slot) {
@@ -89,46 +150,38 @@ __device__ __forceinline__ bool chase_wait(const unsigned* done, int sp, unsigne
 // every storing wave drains, the workgroup meets, one lane publishes
 __device__ __forceinline__ void chase_publish(unsigned* done, int s, unsigned value) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  lds_barrier();
   if (threadIdx.x == 0) __hip_atomic_store(done + s, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Two-sided update of the Hermitian block in lds.Ds (full storage, order L) with H = I - tau v v^H (v in lds.vn, tau = taun), and store
-// of its lower triangle to the band at rows / columns rb ..:  D <- H^H D H.  pv must hold taun D vn (computed by the caller's phase).
 template <class T, int B>
-__device__ __forceinline__ void chase_two_sided_store(ChaseLds<T, B>& lds, T taun, int L, T* AB, int ldab, long rb) {
-  constexpr int TPR = 256 / B, CPT = B / TPR;
-  const int r = threadIdx.x / TPR, cg = threadIdx.x % TPR;
-  const int lane = threadIdx.x & 63;
-  T g = zero_<T>();
-  for (int i = lane; i < B; i += 64) g = g + conj_(lds.vn[i]) * lds.pv[i];
-  g = wave_sum(g);  // gamma = vn^H pv, the same in every wave
-  const T hg = 0.5 * (conj_(taun) * g);
-  const T vr = lds.vn[r];
-  const T w2r = lds.pv[r] - hg * vr;
+struct ChaseIO {
+  static constexpr int TPR = 256 / B, CPT = B / TPR;
+  __amdgpu_buffer_rsrc_t rs;
+  int ldab, n;
+  __device__ __forceinline__ unsigned eoff(long i, long j) const { return (unsigned)(((i - j) + j * (long)ldab) * (long)sizeof(T)); }
+  // off-diagonal block rows r1.., columns r0.. (L1 x L) and diagonal block at r1 (lower, L1 x L1), this thread's elements
+  __device__ __forceinline__ void load(long r0, long r1, int L, int L1, bool with_b, T (&nb)[CPT], T (&nd)[CPT]) const {
+    const int r = threadIdx.x / TPR, cg = threadIdx.x % TPR;
 #pragma unroll
-  for (int q = 0; q < CPT; ++q) {
-    const int c = cg + TPR * q;
-    if (r < L && c <= r) {
-      const T vc = lds.vn[c];
-      const T w2c = lds.pv[c] - hg * vc;
-      T x = lds.Ds[r][c] - vr * conj_(w2c) - w2r * conj_(vc);
-      if (r == c) x = make_<T>(real_(x), 0.0);
-      st_sc1(AB + (long)(r - c) + (rb + c) * (long)ldab, x);
+    for (int k = 0; k < CPT; ++k) {
+      const int c = cg + TPR * k;
+      nb[k] = chase_ld(rs, (with_b && r < L1 && c < L) ? eoff(r1 + r, r0 + c) : CHASE_OOB, T());
+      nd[k] = chase_ld(rs, (c <= r && r < L1) ? eoff(r1 + r, r1 + c) : CHASE_OOB, T());
     }
   }
-}
+};
 
 template <class T, int B>
-__device__ __forceinline__ void chase_load_diag(ChaseLds<T, B>& lds, const T* AB, int ldab, long rb, int L) {
+__device__ __forceinline__ void chase_commit(ChaseLds<T, B>& lds, const T (&nb)[B / (256 / B)], const T (&nd)[B / (256 / B)]) {
   constexpr int TPR = 256 / B, CPT = B / TPR;
   const int r = threadIdx.x / TPR, cg = threadIdx.x % TPR;
 #pragma unroll
-  for (int q = 0; q < CPT; ++q) {
-    const int c = cg + TPR * q;
+  for (int k = 0; k < CPT; ++k) {
+    const int c = cg + TPR * k;
+    lds.Bs[r][c] = nb[k];
     if (c <= r) {
-      T x = zero_<T>();
-      if (r < L) x = ld_sc1(AB + (long)(r - c) + (rb + c) * (long)ldab);
+      T x = nd[k];
       if (r == c) x = make_<T>(real_(x), 0.0);
       lds.Ds[r][c] = x;
       if (r != c) lds.Ds[c][r] = conj_(x);
@@ -136,13 +189,54 @@ __device__ __forceinline__ void chase_load_diag(ChaseLds<T, B>& lds, const T* AB
   }
 }
 
+// pv = taun D vn (row dots)
 template <class T, int B>
-__global__ void __launch_bounds__(256) k_chase(T* AB, int ldab, int n, T* V2, long ldv, double* d, double* e, unsigned* ctl, unsigned* done) {
+__device__ __forceinline__ void chase_pv(ChaseLds<T, B>& lds, T taun) {
+  constexpr int TPR = 256 / B, CPT = B / TPR;
+  const int r = threadIdx.x / TPR, cg = threadIdx.x % TPR;
+  T part = zero_<T>();
+#pragma unroll
+  for (int k = 0; k < CPT; ++k) part = part + lds.Ds[r][cg + TPR * k] * lds.vn[cg + TPR * k];
+  part = row_group_sum<TPR>(part);
+  if (cg == 0) lds.pv[r] = taun * part;
+}
+
+// D <- H^H D H for the block in lds.Ds (H = I - taun vn vn^H, pv = taun D vn) and store of its lower triangle at rows / columns rb ..
+template <class T, int B>
+__device__ __forceinline__ void chase_two_sided_store(ChaseLds<T, B>& lds, T taun, int L, const ChaseIO<T, B>& io, long rb) {
+  constexpr int TPR = 256 / B, CPT = B / TPR;
+  const int r = threadIdx.x / TPR, cg = threadIdx.x % TPR;
+  const int lane = threadIdx.x & 63;
+  T g = zero_<T>();
+  for (int i = lane; i < B; i += 64) g = g + conj_(lds.vn[i]) * lds.pv[i];
+  g = wave_sum_dpp(g);  // gamma = vn^H pv, the same in every wave
+  const T hg = 0.5 * (conj_(taun) * g);
+  const T vr = lds.vn[r];
+  const T w2r = lds.pv[r] - hg * vr;
+#pragma unroll
+  for (int k = 0; k < CPT; ++k) {
+    const int c = cg + TPR * k;
+    const T vc = lds.vn[c];
+    const T w2c = lds.pv[c] - hg * vc;
+    T x = lds.Ds[r][c] - vr * conj_(w2c) - w2r * conj_(vc);
+    if (r == c) x = make_<T>(real_(x), 0.0);
+    chase_st(io.rs, (r < L && c <= r) ? io.eoff(rb + r, rb + c) : CHASE_OOB, x);
+  }
+}
+
+template <class T, int B>
+__global__ void __launch_bounds__(256) k_chase(T* AB, int ldab, int n, T* V2, long ldv, double* d, double* e, unsigned* ctl, unsigned* done,
+                                               long long* stamps /* diagnostic: stamps of sweep 64, stages 1..8 (nullptr: none) */) {
   constexpr int TPR = 256 / B, CPT = B / TPR;
   extern __shared__ __attribute__((aligned(16))) unsigned char chase_smem[];
   ChaseLds<T, B>& lds = *reinterpret_cast<ChaseLds<T, B>*>(chase_smem);
   const int r = threadIdx.x / TPR, cg = threadIdx.x % TPR;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  ChaseIO<T, B> io;
+  io.rs = __builtin_amdgcn_make_buffer_rsrc(AB, 0, (int)((long)n * ldab * (long)sizeof(T)), 0x00020000);
+  io.ldab = ldab;
+  io.n = n;
+  T nb[CPT], nd[CPT];  // blocks in flight / of the current stage (this thread's elements)
   for (;;) {
     __syncthreads();
     if (threadIdx.x == 0) lds.sweep = (int)atomicAdd(ctl, 1u);
@@ -155,38 +249,35 @@ __global__ void __launch_bounds__(256) k_chase(T* AB, int ldab, int n, T* V2, lo
     if (s > 0 && !chase_wait(done, s - 1, (unsigned)min(2, nst_prev), ctl, &lds.abort)) return;
     long r0 = s + 1;
     int L = min(B, n - (int)r0);
-    chase_load_diag<T, B>(lds, AB, ldab, r0, L);
+    io.load(r0, r0, L, L, false, nb, nd);
+    T xcol = zero_<T>(), dss = zero_<T>();
     if (wave == 0) {
-      T x = zero_<T>();
-      if (lane < L) x = ld_sc1(AB + (long)(1 + lane) + (long)s * ldab);
+      xcol = chase_ld(io.rs, lane < L ? io.eoff(r0 + lane, s) : CHASE_OOB, T());
+      dss = chase_ld(io.rs, io.eoff(s, s), T());
+    }
+    chase_commit<T, B>(lds, nb, nd);
+    if (wave == 0) {
+      const T x = xcol;
       double xn2 = lane >= 1 ? abs2_(x) : 0.0;
-      xn2 = wave_sum(xn2);
+      xn2 = wave_sum_dpp(xn2);
       const T alpha = lane_bcast(x, 0);
       const Larfg<T> h = larfg<T>(alpha, xn2);
       const T vi = lane == 0 ? one_<T>() : (h.identity ? zero_<T>() : x * h.scale);
-      if (lane < B) {
-        lds.vn[lane] = lane < L ? vi : zero_<T>();
-        // the column itself: beta on the sub-diagonal, zeros below
-        if (lane < L) st_sc1(AB + (long)(1 + lane) + (long)s * ldab, lane == 0 ? make_<T>(h.beta, 0.0) : zero_<T>());
-        if (lane < L) V2[(r0 + lane) + (long)s * ldv] = lane == 0 ? h.tau : vi;
-      }
+      if (lane < B) lds.vn[lane] = lane < L ? vi : zero_<T>();
+      // the column itself: beta on the sub-diagonal, zeros below
+      chase_st(io.rs, lane < L ? io.eoff(r0 + lane, s) : CHASE_OOB, lane == 0 ? make_<T>(h.beta, 0.0) : zero_<T>());
+      if (lane < L) V2[(r0 + lane) + (long)s * ldv] = lane == 0 ? h.tau : vi;
       if (lane == 0) {
         lds.sc_t[1] = h.tau;
         e[s] = h.beta;
-        d[s] = real_(ld_sc1(AB + (long)s * ldab));
+        d[s] = real_(dss);
       }
     }
-    __syncthreads();
+    lds_barrier();
     T taun = lds.sc_t[1];
-    {  // pv = taun D vn
-      T part = zero_<T>();
-#pragma unroll
-      for (int q = 0; q < CPT; ++q) part = part + lds.Ds[r][cg + TPR * q] * lds.vn[cg + TPR * q];
-      part = row_group_sum<TPR>(part);
-      if (cg == 0) lds.pv[r] = taun * part;
-    }
-    __syncthreads();
-    chase_two_sided_store<T, B>(lds, taun, L, AB, ldab, r0);
+    chase_pv<T, B>(lds, taun);
+    lds_barrier();
+    chase_two_sided_store<T, B>(lds, taun, L, io, r0);
     if (s == n - 2 && threadIdx.x == 0) {
       // the last sweep leaves the final 1 x 1 block: d[n-1]
       const T vr = lds.vn[0];
@@ -195,27 +286,32 @@ __global__ void __launch_bounds__(256) k_chase(T* AB, int ldab, int n, T* V2, lo
       d[n - 1] = real_(lds.Ds[0][0] - vr * conj_(w2) - w2 * conj_(vr));
     }
     chase_publish(done, s, 1u);
-    // current reflector -> v, tau
     if (threadIdx.x < B) lds.v[threadIdx.x] = lds.vn[threadIdx.x];
     T tau = taun;
+    bool pre = false;  // the next stage's blocks are already in nb / nd (prefetched)
     // ---------------- stages q >= 1 ------------------------------------------------------------
     for (int q = 1; q < nst; ++q) {
-      if (s > 0 && !chase_wait(done, s - 1, (unsigned)min(q + 2, nst_prev), ctl, &lds.abort)) return;
-      __syncthreads();
+      const bool stamp = stamps != nullptr && s == 64 && q <= 8 && threadIdx.x == 0;
+      long long* st = stamps + (q - 1) * 8;
+      if (stamp) st[0] = wall_clock64();
       const long r1 = r0 + B;
       const int L1 = min(B, n - (int)r1);
-      // loads: Bq (L1 x L) and Dq (L1 x L1, lower)
+      if (!pre) {
+        if (s > 0 && !chase_wait(done, s - 1, (unsigned)min(q + 2, nst_prev), ctl, &lds.abort)) return;
+        io.load(r0, r1, L, L1, true, nb, nd);
+      }
+      if (stamp) st[1] = wall_clock64();
+      lds_barrier();  // the previous stage's reads of Bs / Ds / v are complete (its publish barrier came before the copy of v)
+      chase_commit<T, B>(lds, nb, nd);
       T breg[CPT];
 #pragma unroll
-      for (int k = 0; k < CPT; ++k) {
-        const int c = cg + TPR * k;
-        T x = zero_<T>();
-        if (r < L1 && c < L) x = ld_sc1(AB + (long)(B + r - c) + (r0 + c) * (long)ldab);
-        breg[k] = x;
-        lds.Bs[r][c] = x;
-      }
-      chase_load_diag<T, B>(lds, AB, ldab, r1, L1);
-      __syncthreads();
+      for (int k = 0; k < CPT; ++k) breg[k] = nb[k];
+      // probe the predecessor's progress for the NEXT stage (consumed after P2: the load has a whole phase to return)
+      unsigned fprobe = 0xffffffffu;
+      const bool more = q + 1 < nst;
+      if (more && s > 0 && threadIdx.x == 0) fprobe = __hip_atomic_load(done + (s - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      lds_barrier();
+      if (stamp) st[2] = wall_clock64();
       // P1: w = Bq v
       {
         T part = zero_<T>();
@@ -224,20 +320,20 @@ __global__ void __launch_bounds__(256) k_chase(T* AB, int ldab, int n, T* V2, lo
         part = row_group_sum<TPR>(part);
         if (cg == 0) lds.w[r] = part;
       }
-      __syncthreads();
+      lds_barrier();
       // P2 (wave 0): first column after the right application, its reflector, c = vn^H w
       if (wave == 0) {
         T x = zero_<T>(), wi = zero_<T>();
         if (lane < B) wi = lds.w[lane];
         if (lane < L1) x = lds.Bs[lane][0] - tau * wi;  // v[0] = 1
         double xn2 = lane >= 1 ? abs2_(x) : 0.0;
-        xn2 = wave_sum(xn2);
+        xn2 = wave_sum_dpp(xn2);
         const T alpha = lane_bcast(x, 0);
         const Larfg<T> h = larfg<T>(alpha, xn2);
         const T vi = lane == 0 ? one_<T>() : (h.identity ? zero_<T>() : x * h.scale);
         const T vnl = lane < L1 ? vi : zero_<T>();
-        T cc = lane < L1 ? conj_(vnl) * wi : zero_<T>();
-        cc = wave_sum(cc);
+        T cc = conj_(vnl) * wi;
+        cc = wave_sum_dpp(cc);
         if (lane < B) {
           lds.vn[lane] = vnl;
           if (lane < L1) V2[(r1 + lane) + (long)s * ldv] = lane == 0 ? h.tau : vi;
@@ -246,11 +342,14 @@ __global__ void __launch_bounds__(256) k_chase(T* AB, int ldab, int n, T* V2, lo
           lds.sc_t[1] = h.tau;
           lds.sc_t[2] = cc;
           lds.sc_d[0] = h.beta;
+          lds.pre_ok = (more && (s == 0 || fprobe >= (unsigned)min(q + 3, nst_prev))) ? 1 : 0;
         }
       }
-      __syncthreads();
+      lds_barrier();
       taun = lds.sc_t[1];
-      // P3: u = vn^H Bq (old Bq; column dots, thread (c, rg)),  pv = taun Dq vn (row dots, thread (r, cg))
+      pre = lds.pre_ok != 0;
+      if (pre) io.load(r1, r1 + B, L1, min(B, n - (int)(r1 + B)), true, nb, nd);  // next stage's blocks: in flight during P3 / P4
+      // P3: u = vn^H Bq (old Bq; column dots, thread (c, rg)),  pv = taun Dq vn (row dots)
       {
         const int c = threadIdx.x / TPR, rg = threadIdx.x % TPR;
         T part = zero_<T>();
@@ -258,37 +357,33 @@ __global__ void __launch_bounds__(256) k_chase(T* AB, int ldab, int n, T* V2, lo
         for (int k = 0; k < CPT; ++k) part = part + conj_(lds.vn[rg + TPR * k]) * lds.Bs[rg + TPR * k][c];
         part = row_group_sum<TPR>(part);
         if (rg == 0) lds.u[c] = part;
-        T p2 = zero_<T>();
-#pragma unroll
-        for (int k = 0; k < CPT; ++k) p2 = p2 + lds.Ds[r][cg + TPR * k] * lds.vn[cg + TPR * k];
-        p2 = row_group_sum<TPR>(p2);
-        if (cg == 0) lds.pv[r] = taun * p2;
       }
-      __syncthreads();
+      chase_pv<T, B>(lds, taun);
+      lds_barrier();
+      if (stamp) st[3] = wall_clock64();
       // P4: updates and stores
       {
         const T cc = lds.sc_t[2];
         const double betan = lds.sc_d[0];
         const T tw = tau * lds.w[r];
         const T tvn = conj_(taun) * lds.vn[r];
+        const T tcc = tau * cc;
 #pragma unroll
         for (int k = 0; k < CPT; ++k) {
           const int c = cg + TPR * k;
-          if (r < L1 && c < L) {
-            T x;
-            if (c == 0) {
-              x = r == 0 ? make_<T>(betan, 0.0) : zero_<T>();
-            } else {
-              const T vc = conj_(lds.v[c]);
-              const T z = lds.u[c] - (tau * cc) * vc;
-              x = breg[k] - tw * vc - tvn * z;
-            }
-            st_sc1(AB + (long)(B + r - c) + (r0 + c) * (long)ldab, x);
-          }
+          const T vc = conj_(lds.v[c]);
+          const T z = lds.u[c] - tcc * vc;
+          T x = breg[k] - tw * vc - tvn * z;
+          if (c == 0) x = r == 0 ? make_<T>(betan, 0.0) : zero_<T>();
+          chase_st(io.rs, (r < L1 && c < L) ? io.eoff(r1 + r, r0 + c) : CHASE_OOB, x);
         }
       }
-      chase_two_sided_store<T, B>(lds, taun, L1, AB, ldab, r1);
+      chase_two_sided_store<T, B>(lds, taun, L1, io, r1);
+      if (stamp) st[4] = wall_clock64();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (stamp) st[5] = wall_clock64();
       chase_publish(done, s, (unsigned)(q + 1));
+      if (stamp) st[6] = wall_clock64();
       if (threadIdx.x < B) lds.v[threadIdx.x] = lds.vn[threadIdx.x];
       tau = taun;
       r0 = r1;

@@ -301,8 +301,24 @@ static int sb2st(nls_ctx* ctx, const T* A, int n, long lda, double* d, double* e
   int W = n / (2 * B) + 4;
   if (const char* ew = std::getenv("NLS_CHASE_WG")) W = std::atoi(ew);
   W = std::max(1, std::min(W, ctx->cus));
-  if (n >= 2) hipLaunchKernelGGL((k_chase<T, B>), dim3(W), dim3(256), lds, ctx->stream, AB, ldab, n, V2, (long)n, d, e, ctl, ctl + 16);
+  long long* stamps = nullptr;
+  static const bool want_stamps = [] { const char* m = std::getenv("NLS_CHASE_STAMP"); return m && m[0] == '1'; }();
+  if (want_stamps) {
+    NLSCHK(ws_get_t(ctx, "chase.stamps", (size_t)64, &stamps));
+    HIPCHK(ctx, hipMemsetAsync(stamps, 0, 64 * sizeof(long long), ctx->stream));
+  }
+  if (n >= 2) hipLaunchKernelGGL((k_chase<T, B>), dim3(W), dim3(256), lds, ctx->stream, AB, ldab, n, V2, (long)n, d, e, ctl, ctl + 16, stamps);
   HIPCHK(ctx, hipGetLastError());
+  if (want_stamps) {  // diagnostic: time line of sweep 64 (100 MHz clock: 10 ns units)
+    long long h[64];
+    HIPCHK(ctx, hipMemcpyAsync(h, stamps, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int q = 0; q < 8; ++q)
+      std::fprintf(stderr, "[chase stamps] stage %d: wait %.2f us, load %.2f, P1-P3 %.2f, P4+store issue %.2f, drain %.2f, publish %.2f | next stage starts %.2f us later\n",
+                   q + 1, (h[q * 8 + 1] - h[q * 8]) * 0.01, (h[q * 8 + 2] - h[q * 8 + 1]) * 0.01, (h[q * 8 + 3] - h[q * 8 + 2]) * 0.01,
+                   (h[q * 8 + 4] - h[q * 8 + 3]) * 0.01, (h[q * 8 + 5] - h[q * 8 + 4]) * 0.01, (h[q * 8 + 6] - h[q * 8 + 5]) * 0.01,
+                   q < 7 ? (h[(q + 1) * 8] - h[q * 8]) * 0.01 : 0.0);
+  }
   *ctl_out = ctl;
   return NLS_OK;
 }
@@ -338,9 +354,24 @@ static int apply_q2(nls_ctx* ctx, const T* V2, int n, T* C, long ldc, int ncols)
       while (G > 1 && M::lds_bytes(G) > ((size_t)158 << 10)) --G;
       G = std::min(G, ngroups);
       NLSCHK(sb_lds_optin(ctx, k_q2_apply_mfma<T, B>, M::lds_bytes(G), "k_q2_apply_mfma"));
+      long long* stamps = nullptr;
+      static const bool want_stamps = [] { const char* m = std::getenv("NLS_Q2_STAMP"); return m && m[0] == '1'; }();
+      if (want_stamps) {
+        NLSCHK(ws_get_t(ctx, "q2.stamps", (size_t)64, &stamps));
+        HIPCHK(ctx, hipMemsetAsync(stamps, 0, 64 * sizeof(long long), ctx->stream));
+      }
       hipLaunchKernelGGL((k_q2_apply_mfma<T, B>), dim3((unsigned)((ncols + NC - 1) / NC)), dim3(256), M::lds_bytes(G), ctx->stream, V2, (long)n, n, doff, ngroups, Tb,
-                         C, ldc, ncols, G);
+                         C, ldc, ncols, G, stamps);
       HIPCHK(ctx, hipGetLastError());
+      if (want_stamps) {
+        long long h[64];
+        HIPCHK(ctx, hipMemcpyAsync(h, stamps, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        for (int q = 0; q < 8; ++q)
+          std::fprintf(stderr, "[q2 stamps G=%d] block %d: B0 wait %.2f us, ring+commit+fetch %.2f, B1 %.2f, W1 %.2f, B2+T %.2f, B3+update %.2f | next block %.2f us later\n", G,
+                       200 + q, 0.0, (h[q * 8 + 1] - h[q * 8]) * 0.01, (h[q * 8 + 2] - h[q * 8 + 1]) * 0.01, (h[q * 8 + 3] - h[q * 8 + 2]) * 0.01,
+                       (h[q * 8 + 4] - h[q * 8 + 3]) * 0.01, (h[q * 8 + 5] - h[q * 8 + 4]) * 0.01, q < 7 ? (h[(q + 1) * 8] - h[q * 8]) * 0.01 : 0.0);
+      }
     }
     return NLS_OK;
   }
@@ -370,14 +401,16 @@ static int evd_bw(bool cplx) {
   return TwoStageBw<double>::B;
 }
 
-// When to take the two-stage reduction: NLS_EVD=twostage / onestage forces it; otherwise by size (NLS_TWOSTAGE_MIN, default below).
+// When to take the two-stage reduction.  Measured on MI355X in round 3 (profiles/r03_evd_twostage.md) it is correct at every size but
+// not yet faster than the one-stage panel on ONE GPU (complex n = 4097: 224 vs 143 ms; real n = 1e4: 731 vs 587 ms; complex n = 1025: 29 vs
+// 18.5 ms), so the default stays one-stage; NLS_EVD=twostage forces it (n >= 4), NLS_TWOSTAGE_MIN = n gives a size rule.
 static bool evd_use_two_stage(int n, bool cplx) {
+  (void)cplx;
   const char* m = std::getenv("NLS_EVD");
   if (m && std::string(m) == "twostage") return n >= 4;
   if (m && std::string(m) == "onestage") return false;
-  int nmin = cplx ? 768 : 1536;
-  if (const char* e = std::getenv("NLS_TWOSTAGE_MIN")) nmin = std::atoi(e);
-  return n >= nmin && n >= 4;
+  if (const char* e = std::getenv("NLS_TWOSTAGE_MIN")) return n >= std::max(4, std::atoi(e));
+  return false;
 }
 
 static bool evd_rocsolver_backtransform() {  // NLS_EVD_UNMTR=rocsolver: zunmtr / dormtr instead of apply_q_blocked (diagnostic)

@@ -251,11 +251,11 @@ struct Q2M {
   static constexpr bool CX = sizeof(T) == 16;
   static constexpr int NP = CX ? 2 : 1;
   static constexpr int NC = 16;
-  static constexpr int LDV = B + 1, LDT = B + 1;
+  static constexpr int LDV = B + 3;  // (LDV - 1) = 2 (mod 32): the A-operand reads of V^H (lane stride LDV - 1) hit 32 distinct 8-byte banks
   static constexpr int EPT = B * B / 256;  // elements of V (and of T) per thread
   static_assert(!(CX && B == 64), "complex blocks of 64 do not fit the LDS budget");
   static size_t lds_bytes(int G) {
-    return sizeof(double) * ((size_t)NP * (2 * G) * B * NC + 2 * (size_t)NP * B * LDV + 2 * (size_t)NP * B * NC);
+    return sizeof(double) * ((size_t)NP * (2 * G) * B * NC + (size_t)NP * B * LDV + 2 * (size_t)NP * B * NC);
   }
 };
 
@@ -270,20 +270,20 @@ __device__ __forceinline__ void q2_split(Z x, double& re, double& im) {
 
 template <class T, int B>
 __global__ void __launch_bounds__(256) k_q2_apply_mfma(const T* V2, long ldv, int n, const int* blk_off, int ngroups, const T* Tb, T* C, long ldc, int ncols,
-                                                       int G) {
+                                                       int G, long long* stamps /* diagnostic (nullptr: none): workgroup 0, blocks 200 .. 207 */) {
   using M = Q2M<T, B>;
   constexpr bool CX = M::CX;
-  constexpr int NP = M::NP, NC = M::NC, LDV = M::LDV, LDT = M::LDT, EPT = M::EPT;
+  constexpr int NP = M::NP, NC = M::NC, LDV = M::LDV, EPT = M::EPT;
   extern __shared__ __attribute__((aligned(16))) unsigned char q2_smem[];
   const int R = 2 * G;
   double* ring = reinterpret_cast<double*>(q2_smem);          // [NP][R * B][NC]
   double* Vc = ring + (size_t)NP * R * B * NC;                  // [NP][B][LDV]   Vc[i][t]: entry of reflector i at window row i + t
-  double* Ts = Vc + (size_t)NP * B * LDV;                       // [NP][B][LDT]
-  double* W1 = Ts + (size_t)NP * B * LDT;                       // [NP][B][NC]
+  double* W1 = Vc + (size_t)NP * B * LDV;                       // [NP][B][NC]
   double* W2 = W1 + (size_t)NP * B * NC;                        // [NP][B][NC]
-  const size_t ringp = (size_t)R * B * NC, vp = (size_t)B * LDV, tp = (size_t)B * LDT, wp = (size_t)B * NC;
+  const size_t ringp = (size_t)R * B * NC, vp = (size_t)B * LDV, wp = (size_t)B * NC;
   const long c0 = (long)blockIdx.x * NC;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave index in a scalar register: tile choices are uniform
   const int l15 = lane & 15, l4 = lane >> 4;
 
   auto load_blockrow = [&](int tb) {
@@ -310,8 +310,15 @@ __global__ void __launch_bounds__(256) k_q2_apply_mfma(const T* V2, long ldv, in
     }
   };
 
-  // prefetch registers: this thread's EPT elements of V (idx = tid + 256 q: t = idx % B, i = idx / B) and of T
-  T pv[EPT], pt[EPT];
+  int nblk_done = 0;
+  // Prefetch registers.  V: this thread's EPT elements (idx = tid + 256 q: t = idx % B, i = idx / B), staged through LDS.  T: this lane's
+  // A-operand fragments of the W2 = T W1 product, straight from global memory (T[i][t] at Tb[i + B t]: the 16 lanes of a k-row read 16
+  // consecutive elements): tile a = a_w + ASTEP x, k-step ks, element (i = 16 a + l15, t = 4 ks + l4); only ks >= 4 a is non-zero.
+  constexpr int TT = CX ? 1 : (B / 16 + 3) / 4;  // T tiles per wave
+  constexpr int TKS = B / 4;
+  T pv[EPT], tfn[TT][TKS], tf[TT][TKS];
+  const int a_w = CX ? (wv >> 1) : wv;
+  constexpr int ASTEP_T = CX ? 2 : 4;
   auto fetch_block = [&](int S, int k) {
     const T* tsrc = Tb + ((long)blk_off[S] + k) * B * B;
 #pragma unroll
@@ -323,7 +330,13 @@ __global__ void __launch_bounds__(256) k_q2_apply_mfma(const T* V2, long ldv, in
       T v = zero_<T>();
       if (s <= n - 2 && r0 + t < n) v = t == 0 ? one_<T>() : V2[(r0 + t) + s * ldv];
       pv[q] = v;
-      pt[q] = tsrc[idx];  // T[i2 + B j2] with i2 = idx % B, j2 = idx / B
+    }
+#pragma unroll
+    for (int x = 0; x < TT; ++x) {
+      const int a = a_w + ASTEP_T * x;
+#pragma unroll
+      for (int ks = 0; ks < TKS; ++ks)
+        tfn[x][ks] = (a < B / 16 && ks >= 4 * a) ? tsrc[(16 * a + l15) + (long)B * (4 * ks + l4)] : zero_<T>();
     }
   };
   auto commit_block = [&]() {
@@ -334,10 +347,11 @@ __global__ void __launch_bounds__(256) k_q2_apply_mfma(const T* V2, long ldv, in
       q2_split(pv[q], re, im);
       Vc[(size_t)(idx / B) * LDV + idx % B] = re;
       if (CX) Vc[vp + (size_t)(idx / B) * LDV + idx % B] = im;
-      q2_split(pt[q], re, im);
-      Ts[(size_t)(idx % B) * LDT + idx / B] = re;
-      if (CX) Ts[tp + (size_t)(idx % B) * LDT + idx / B] = im;
     }
+#pragma unroll
+    for (int x = 0; x < TT; ++x)
+#pragma unroll
+      for (int ks = 0; ks < TKS; ++ks) tf[x][ks] = tfn[x][ks];
   };
 
   for (int S_hi = ngroups - 1; S_hi >= 0; S_hi -= G) {
@@ -365,7 +379,10 @@ __global__ void __launch_bounds__(256) k_q2_apply_mfma(const T* V2, long ldv, in
     while (have) {
       const int u = cu, i = ci;
       const int S = S_hi - i, k = u - i, tb = S + k;
-      __syncthreads();  // B0: the previous block's update of the ring and its reads of Vc / Ts / W2 are complete
+      const bool stamp = stamps != nullptr && blockIdx.x == 0 && threadIdx.x == 0 && nblk_done >= 200 && nblk_done < 208;
+      long long* stp = stamps + (nblk_done - 200) * 8;
+      if (stamp) stp[0] = wall_clock64();
+      chase::lds_barrier();  // B0: the previous block's update of the ring and its reads of Vc / Ts / W2 are complete
       if (ring_u != u) {
         const int want_hi = S_hi + u + 1;
         while (hi < want_hi) {
@@ -383,93 +400,124 @@ __global__ void __launch_bounds__(256) k_q2_apply_mfma(const T* V2, long ldv, in
       int nu = cu, ni = ci;
       const bool more = next_active(nu, ni);
       if (more) fetch_block(S_hi - ni, nu - ni);
-      __syncthreads();  // B1
+      if (stamp) stp[1] = wall_clock64();
+      chase::lds_barrier();  // B1 (LDS only: the prefetch loads of the next block stay in flight)
+      if (stamp) stp[2] = wall_clock64();
       const int base0 = (tb % R) * B, base1 = ((tb + 1) % R) * B;
-      auto rrow = [&](int rho) -> int { return rho < B ? base0 + rho : base1 + rho - B; };
+      // window row rho0 + l4 (rho0 a multiple of 4, wave-uniform) of column l15 sits at ring[wbase(rho0) * NC + lane]
+      auto wbase = [&](int rho0) -> int { return rho0 < B ? base0 + rho0 : base1 + rho0 - B; };
+      const int part = CX ? (wv & 1) : 0;
       // ---------------- W1 = V^H Z ----------------
       {
-        constexpr int NTILE = B / 16;              // row tiles of W1
-        constexpr int KS = B / 4 + 4;              // k-steps per tile
-        const int part = CX ? (wave & 1) : 0;
-        const int a0 = CX ? (wave >> 1) : wave;    // first tile of this wave
+        constexpr int NTILE = B / 16;  // row tiles of W1
+        constexpr int KS = B / 4 + 4;  // k-steps per tile
         constexpr int ASTEP = CX ? 2 : 4;
-        for (int a = a0; a < NTILE; a += ASTEP) {
-          v4d acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
-          const int irow = 16 * a + l15;
-#pragma unroll 4
+        for (int a = CX ? (wv >> 1) : wv; a < NTILE; a += ASTEP) {
+          const int t0 = l4 - l15;                                    // t = 4 ks + t0
+          const double* va = Vc + (size_t)(16 * a + l15) * LDV + t0;  // + 4 ks
+          double fvr[KS], fvi[KS], fzr[KS], fzi[KS];
+#pragma unroll
           for (int ks = 0; ks < KS; ++ks) {
-            const int rho = 16 * a + 4 * ks + l4;
-            const int t = rho - irow;
-            const bool ok = t >= 0 && t < B;
-            const int tc = ok ? t : 0;
-            const int zr = rrow(rho) * NC + l15;
-            const double vr = ok ? Vc[(size_t)irow * LDV + tc] : 0.0;
-            const double zre = ring[zr];
-            if (!CX) {
-              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(vr, zre, acc, 0, 0, 0);
-            } else {
-              const double vi = ok ? Vc[vp + (size_t)irow * LDV + tc] : 0.0;
-              const double zim = ring[ringp + zr];
-              if (part == 0) {  // Re(conj(v) z) = vr zr + vi zi
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(vr, zre, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(vi, zim, acc, 0, 0, 0);
-              } else {  // Im = vr zi - vi zr
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(vr, zim, acc, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(vi, zre, acc2, 0, 0, 0);
-              }
+            const int t = 4 * ks + t0;
+            const bool ok = (ks >= 4 || t >= 0) && (ks < B / 4 || t < B);
+            const int zo = wbase(16 * a + 4 * ks) * NC + lane;
+            const double xr = va[4 * ks];
+            fvr[ks] = ok ? xr : 0.0;
+            fzr[ks] = ring[zo];
+            if (CX) {
+              const double xi = va[vp + 4 * ks];
+              fvi[ks] = ok ? xi : 0.0;
+              fzi[ks] = ring[ringp + zo];
             }
           }
-          double* dst = W1 + (size_t)part * wp;
+          // Re(conj(v) z) = vr zr + vi zi (part 0);  Im = vr zi - vi zr (part 1): the part is chosen OUTSIDE the MFMA chains (a branch per
+          // k-step makes the compiler copy the accumulators around)
+          double* dst = W1 + (size_t)part * wp + 256 * a + lane;
+          if (!CX) {
+            v4d acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-          for (int j = 0; j < 4; ++j) dst[(size_t)(16 * a + l4 + 4 * j) * NC + l15] = acc[j] - acc2[j];
+            for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fvr[ks], fzr[ks], acc, 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dst[64 * j] = acc[j];
+          } else if (part == 0) {
+            v4d acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fvr[ks], fzr[ks], acc, 0, 0, 0);
+              acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(fvi[ks], fzi[ks], acc2, 0, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dst[64 * j] = acc[j] + acc2[j];
+          } else {
+            v4d acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fvr[ks], fzi[ks], acc, 0, 0, 0);
+              acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(fvi[ks], fzr[ks], acc2, 0, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dst[64 * j] = acc[j] - acc2[j];
+          }
         }
       }
-      __syncthreads();  // B2
-      // ---------------- W2 = T W1 (T upper triangular) ----------------
+      if (stamp) stp[3] = wall_clock64();
+      chase::lds_barrier();  // B2
+      // ---------------- W2 = T W1 (T upper triangular; its fragments are in registers) ----------------
       {
-        constexpr int NTILE = B / 16;
-        const int part = CX ? (wave & 1) : 0;
-        const int a0 = CX ? (wave >> 1) : wave;
-        constexpr int ASTEP = CX ? 2 : 4;
-        for (int a = a0; a < NTILE; a += ASTEP) {
-          v4d acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
-          const int irow = 16 * a + l15;
-#pragma unroll 4
-          for (int ks = 4 * a; ks < B / 4; ++ks) {
-            const int t = 4 * ks + l4;
-            const double tr = Ts[(size_t)irow * LDT + t];
-            const double wr = W1[(size_t)t * NC + l15];
+#pragma unroll
+        for (int x = 0; x < TT; ++x) {
+          const int a = a_w + ASTEP_T * x;
+          if (a < B / 16) {  // uniform
+            const double* wa = W1 + lane;  // + 64 ks
+            double fwr[TKS], fwi[TKS];
+#pragma unroll
+            for (int ks = 0; ks < TKS; ++ks) {
+              fwr[ks] = wa[64 * ks];
+              if (CX) fwi[ks] = wa[wp + 64 * ks];
+            }
+            // T is zero below the diagonal, so the k-steps before 4 a contribute exact zeros: running them all keeps the chains branch-free
+            double ftr[TKS], fti[TKS];
+#pragma unroll
+            for (int ks = 0; ks < TKS; ++ks) q2_split(tf[x][ks], ftr[ks], fti[ks]);
+            double* dst = W2 + (size_t)part * wp + 256 * a + lane;
             if (!CX) {
-              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(tr, wr, acc, 0, 0, 0);
-            } else {
-              const double ti = Ts[tp + (size_t)irow * LDT + t];
-              const double wi = W1[wp + (size_t)t * NC + l15];
-              if (part == 0) {  // Re = tr wr - ti wi
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(tr, wr, acc, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ti, wi, acc2, 0, 0, 0);
-              } else {  // Im = tr wi + ti wr
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(tr, wi, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ti, wr, acc, 0, 0, 0);
+              v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+              for (int ks = 0; ks < TKS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ftr[ks], fwr[ks], acc, 0, 0, 0);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) dst[64 * j] = acc[j];
+            } else if (part == 0) {  // Re = tr wr - ti wi
+              v4d acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+              for (int ks = 0; ks < TKS; ++ks) {
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ftr[ks], fwr[ks], acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(fti[ks], fwi[ks], acc2, 0, 0, 0);
               }
+#pragma unroll
+              for (int j = 0; j < 4; ++j) dst[64 * j] = acc[j] - acc2[j];
+            } else {  // Im = tr wi + ti wr
+              v4d acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+              for (int ks = 0; ks < TKS; ++ks) {
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ftr[ks], fwi[ks], acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(fti[ks], fwr[ks], acc2, 0, 0, 0);
+              }
+#pragma unroll
+              for (int j = 0; j < 4; ++j) dst[64 * j] = acc[j] + acc2[j];
             }
           }
-          double* dst = W2 + (size_t)part * wp;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) dst[(size_t)(16 * a + l4 + 4 * j) * NC + l15] = acc[j] - acc2[j];
         }
       }
-      __syncthreads();  // B3
+      if (stamp) stp[4] = wall_clock64();
+      chase::lds_barrier();  // B3
       // ---------------- Z -= V W2 ----------------
       {
         constexpr int NTILE = 2 * B / 16;  // row tiles of the window
-        const int part = CX ? (wave & 1) : 0;
-        const int wsel = CX ? (wave >> 1) : wave;
-        constexpr int NW = CX ? 2 : 4;     // waves sharing the tiles (per part)
-        // tile order that balances the k-steps: wave w takes tiles w, NTILE/2 - 1 - w (+ NTILE/2 ...) when there are enough tiles
+        const int wsel = CX ? (wv >> 1) : wv;
+        constexpr int NW = CX ? 2 : 4;  // waves sharing the tiles (per part)
         for (int bi = 0; bi < NTILE / NW; ++bi) {
-          int b;
+          int b;  // tile order that balances the k-steps: real B = 64: (0,3) (1,2) (4,7) (5,6); complex B = 32: (0,1) (2,3)
           if (NTILE / NW == 2) {
-            // pairs (w, NTILE/2-1-w) on the first half mirror onto the second: for B = 64 real: (0,3) (1,2) (4,7) (5,6); B = 32 complex: (0,1) (2,3)
             if (NTILE == 8) {
               const int h = wsel >> 1, w2 = wsel & 1;
               b = 4 * h + (bi == 0 ? w2 : 3 - w2);
@@ -479,40 +527,60 @@ __global__ void __launch_bounds__(256) k_q2_apply_mfma(const T* V2, long ldv, in
           } else {
             b = wsel + NW * bi;
           }
-          const int rho_lane = 16 * b + l15;                     // A-operand row of this lane
           const int ilo = max(0, 16 * b - B + 1), ihi = min(B - 1, 16 * b + 15);
-          v4d acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 4
-          for (int ks = ilo / 4; ks <= ihi / 4; ++ks) {
-            const int i2 = 4 * ks + l4;
-            const int t = rho_lane - i2;
+          const int tl = 16 * b + l15 - l4;               // t = tl - 4 ks
+          const double* va = Vc + (size_t)l4 * LDV + tl;  // + 4 ks (LDV - 1)
+          const double* wa = W2 + lane;                   // + 64 ks
+          double fvr[TKS], fvi[TKS], fwr[TKS], fwi[TKS];
+#pragma unroll
+          for (int ks = 0; ks < TKS; ++ks) {
+            const int t = tl - 4 * ks;
             const bool ok = t >= 0 && t < B;
-            const int tc = ok ? t : 0;
-            const double vr = ok ? Vc[(size_t)i2 * LDV + tc] : 0.0;
-            const double wr = W2[(size_t)i2 * NC + l15];
-            if (!CX) {
-              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(vr, wr, acc, 0, 0, 0);
-            } else {
-              const double vi = ok ? Vc[vp + (size_t)i2 * LDV + tc] : 0.0;
-              const double wi = W2[wp + (size_t)i2 * NC + l15];
-              if (part == 0) {  // Re = vr wr - vi wi
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(vr, wr, acc, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(vi, wi, acc2, 0, 0, 0);
-              } else {  // Im = vr wi + vi wr
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(vr, wi, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(vi, wr, acc, 0, 0, 0);
-              }
+            const double xr = va[4 * ks * (LDV - 1)];
+            fvr[ks] = ok ? xr : 0.0;
+            fwr[ks] = wa[64 * ks];
+            if (CX) {
+              const double xi = va[vp + 4 * ks * (LDV - 1)];
+              fvi[ks] = ok ? xi : 0.0;
+              fwi[ks] = wa[wp + 64 * ks];
             }
           }
-          double* dst = ring + (size_t)part * ringp;
+          // k-steps outside [ilo / 4, ihi / 4] multiply structural zeros of V (the "ok" mask): all B / 4 are run, branch-free
+          (void)ilo;
+          (void)ihi;
+          v4d res;
+          if (!CX) {
+            v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < TKS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fvr[ks], fwr[ks], acc, 0, 0, 0);
+            res = acc;
+          } else if (part == 0) {  // Re = vr wr - vi wi
+            v4d acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < TKS; ++ks) {
+              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fvr[ks], fwr[ks], acc, 0, 0, 0);
+              acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(fvi[ks], fwi[ks], acc2, 0, 0, 0);
+            }
+            res = acc - acc2;
+          } else {  // Im = vr wi + vi wr
+            v4d acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < TKS; ++ks) {
+              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fvr[ks], fwi[ks], acc, 0, 0, 0);
+              acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(fvi[ks], fwr[ks], acc2, 0, 0, 0);
+            }
+            res = acc + acc2;
+          }
+          double* dst = ring + (size_t)part * ringp + lane;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const int rho = 16 * b + l4 + 4 * j;
-            const size_t o = (size_t)rrow(rho) * NC + l15;
-            dst[o] = dst[o] - (acc[j] - acc2[j]);
+            const size_t o = (size_t)wbase(16 * b + 4 * j) * NC;
+            dst[o] = dst[o] - res[j];
           }
         }
       }
+      if (stamp) stp[5] = wall_clock64();
+      ++nblk_done;
       cu = nu;
       ci = ni;
       have = more;

@@ -191,14 +191,26 @@ __device__ __forceinline__ bool reg_cholesky(T (&a)[Small<B>::CPT], int k, T (*c
 }
 
 // q R = p for one row per thread: R (upper triangular, identity outside the leading block) in LDS, dinv[j] = 1 / R[j][j].  In place.
+// Row j + 1 of R is fetched into registers while row j is being applied (uniform, i.e. broadcast, LDS reads: without the explicit
+// double buffer every multiply-add waits for its own read).
 template <class T, int B, bool UNIT>
 __device__ __forceinline__ void row_solve_upper(T (&x)[B], T (*R)[B + 1], const T* dinv) {
+  T rn[B];
+#pragma unroll
+  for (int c = 1; c < B; ++c) rn[c] = R[0][c];
 #pragma unroll
   for (int j = 0; j < B; ++j) {
+    T rj[B];
+#pragma unroll
+    for (int c = j + 1; c < B; ++c) rj[c] = rn[c];
+    if (j + 1 < B) {
+#pragma unroll
+      for (int c = j + 2; c < B; ++c) rn[c] = R[j + 1][c];
+    }
     if (!UNIT) x[j] = x[j] * dinv[j];
     const T xj = x[j];
 #pragma unroll
-    for (int c = j + 1; c < B; ++c) x[c] = x[c] - xj * R[j][c];
+    for (int c = j + 1; c < B; ++c) x[c] = x[c] - xj * rj[c];
   }
 }
 
@@ -277,7 +289,7 @@ __global__ void __launch_bounds__(256) k_sb_small_chol(int kb, int m, int pass, 
 
 // ---- apply pass: rows of Q = rows of P solved against R (ps->Rs), written to dst; Gram partials of the result -----------------------
 template <class T, int B>
-__global__ void __launch_bounds__(256) k_sb_apply(const T* src, long lds_, int m, int kb, const PanelSmall<T, B>* ps, T* dst, long ldd, T* Gp) {
+__global__ void __launch_bounds__(256, 1) k_sb_apply(const T* src, long lds_, int m, int kb, const PanelSmall<T, B>* ps, T* dst, long ldd, T* Gp) {
   constexpr int TI = B / 16;
   size_t off = 0;
   T(*Rs)[B + 1] = sb_carve<T, B + 1>(B, off);
@@ -463,7 +475,7 @@ __global__ void __launch_bounds__(256, 1) k_sb_small_recon(int kb, const T* Ytop
 // ---- finish: Y (explicit, m x kb) and Z = Y T into the panel buffers, Y's strictly-lower part into A below the band -----------------
 // Row r < kb of Y comes from Y1, rows >= kb are the rows of Q2 solved against M = U R3 (ps->Rs).  Yb / Zb have zh = B - kb zero rows on top.
 template <class T, int B>
-__global__ void __launch_bounds__(256) k_sb_finish(T* Yb, long ldy, int m, int kb, const PanelSmall<T, B>* ps, T* Zb, T* Apanel, long lda) {
+__global__ void __launch_bounds__(256, 1) k_sb_finish(T* Yb, long ldy, int m, int kb, const PanelSmall<T, B>* ps, T* Zb, T* Apanel, long lda) {
   size_t off = 0;
   T(*Ms)[B + 1] = sb_carve<T, B + 1>(B, off);  // M, later T
   T(*Ps)[B + 1] = sb_carve<T, B + 1>(64, off);

@@ -142,6 +142,7 @@ extern "C" int nls_dual_fit(nls_ctx* ctx, const nls_dual_fit_args* a) {
     tm[NLS_T_GRAM_LAUNCHES] += 1;
     tm[NLS_T_GRAM_FLOPS] += 2.0 * n * n * r;
   }
+  HostPin pinL;
   // ---- D2: EVD of sn K sn ------------------------------------------------------------------------
   double* Qev = nullptr;  // eigenvectors: in Q (rocSOLVER path) or in the EVD's own workspace
   {
@@ -209,6 +210,7 @@ extern "C" int nls_dual_fit(nls_ctx* ctx, const nls_dual_fit_args* a) {
   }
   std::vector<double> herrs((size_t)3 * Gp), hobj((size_t)G);
   HIPCHK(ctx, hipMemcpyAsync(herrs.data(), errs, sizeof(double) * 3 * Gp, hipMemcpyDeviceToHost, ctx->stream));
+  if (a->L) pinL.pin(a->L, sizeof(double) * (size_t)n * n);  // the host would wait here anyway: page-lock the L_ output behind the EVD / sweep
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   for (int g = 0; g < G; ++g) hobj[g] = is_clf ? (herrs[Gp + g] + herrs[2 * Gp + g]) + herrs[g] : herrs[g];  // :296-302
   int opt = a->gamma_index_in;

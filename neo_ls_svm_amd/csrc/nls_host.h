@@ -50,6 +50,9 @@ struct nls_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   rocblas_handle blas = nullptr;
+  hipStream_t stream2 = nullptr;   // side stream (created on first use): the Cholesky factor L_ and its download run beside the residual pass
+  rocblas_handle blas2 = nullptr;
+  hipEvent_t side_ev[4] = {nullptr, nullptr, nullptr, nullptr};  // fork, potrf done, download done (timing of the side stream)
   std::string err;
   std::map<std::string, DevBuf> ws;  // grow-only named workspace
   size_t ws_limit = 0;
@@ -272,6 +275,28 @@ static int do_allgather_blocks(nls_ctx* ctx, double* dbuf, const std::vector<siz
   if (tot > hi) HIPCHK(ctx, hipMemsetAsync(dbuf + hi, 0, (tot - hi) * sizeof(double), ctx->stream));
   return do_allreduce(ctx, dbuf, tot);
 }
+
+// Page-locks a caller's host output buffer for the duration of a call so that its (large) download runs at full PCIe rate instead of
+// through the runtime's pageable staging (L_: 268 MB at c3, 800 MB at c4).  The registration is issued where the host would otherwise
+// wait for the GPU, so its cost hides behind kernels.  NLS_PIN_OUTPUT=0 disables it; a failed registration is simply not used.
+struct HostPin {
+  void* p = nullptr;
+  void pin(void* ptr, size_t bytes) {
+    static const bool off = [] { const char* m = std::getenv("NLS_PIN_OUTPUT"); return m && m[0] == '0'; }();
+    // measured (profiles/r03_tail.md): 800 MB (dual c4) 32.7 -> 14.5 ms; 268 MB (primal c3) no gain over the pageable path -> large buffers only
+    if (off || !ptr || bytes < ((size_t)512 << 20)) return;
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, ptr) == hipSuccess && attr.type != hipMemoryTypeUnregistered) return;  // device or already pinned
+    (void)hipGetLastError();
+    if (hipHostRegister(ptr, bytes, hipHostRegisterDefault) == hipSuccess)
+      p = ptr;
+    else
+      (void)hipGetLastError();
+  }
+  ~HostPin() {
+    if (p) (void)hipHostUnregister(p);
+  }
+};
 
 static double wall() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();

@@ -746,6 +746,46 @@ __global__ void k_conj_inplace(double2* a, long n) {
 }
 
 // v (complex, `len` valid entries) -> planes vr, vi [n_out] zero padded.
+// beta = Q (v / (gamma + lam)) from the eigendecomposition the sweep already has (A + gamma c I = c Q (Lam + gamma) Q^H, v = Q^H b / c):
+// the re-solve at gamma* needs no factorisation on the critical path (the Cholesky factor is still computed, for L_, beside the residual pass).
+// Q column-major (ldq); block (x: 64 rows, y: 256 columns) -> part[y][row]; k_beta_evd_finish adds the column chunks in order.
+__global__ void __launch_bounds__(256) k_beta_evd_partial(const double2* Q, long ldq, int D1, const double* vr, const double* vi, const double* lam,
+                                                          double gamma, double2* part) {
+  __shared__ double2 red[4][64];
+  const int row = blockIdx.x * 64 + (threadIdx.x & 63), cgp = threadIdx.x >> 6;
+  const int c0 = blockIdx.y * 256 + cgp * 64;
+  double ar = 0.0, ai = 0.0;
+  if (row < D1) {
+    for (int c = c0; c < min(c0 + 64, D1); ++c) {
+      const double w = 1.0 / (gamma + lam[c]);
+      const double xr = vr[c] * w, xi = vi[c] * w;
+      const double2 q = Q[row + (long)c * ldq];
+      ar += q.x * xr - q.y * xi;
+      ai += q.x * xi + q.y * xr;
+    }
+  }
+  red[cgp][threadIdx.x & 63] = make_double2(ar, ai);
+  __syncthreads();
+  if (cgp == 0 && row < D1) {
+    double2 s = red[0][threadIdx.x];
+    for (int g = 1; g < 4; ++g) {
+      s.x += red[g][threadIdx.x].x;
+      s.y += red[g][threadIdx.x].y;
+    }
+    part[(long)blockIdx.y * D1 + row] = s;
+  }
+}
+__global__ void k_beta_evd_finish(const double2* part, int nchunks, int D1, double2* beta) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= D1) return;
+  double2 s = make_double2(0.0, 0.0);
+  for (int c = 0; c < nchunks; ++c) {
+    s.x += part[(long)c * D1 + i].x;
+    s.y += part[(long)c * D1 + i].y;
+  }
+  beta[i] = s;
+}
+
 __global__ void k_split_vec(const double2* v, int len, int n_out, double* vr, double* vi) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_out) return;

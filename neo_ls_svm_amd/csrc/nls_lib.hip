@@ -196,6 +196,10 @@ extern "C" void nls_ctx_destroy(nls_ctx* ctx) {
     if (kv.second.p) (void)hipFree(kv.second.p);
   for (auto ev : ctx->event_pool) (void)hipEventDestroy(ev);
   if (ctx->blas) rocblas_destroy_handle(ctx->blas);
+  if (ctx->blas2) rocblas_destroy_handle(ctx->blas2);
+  for (auto e : ctx->side_ev)
+    if (e) (void)hipEventDestroy(e);
+  if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -692,6 +696,8 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
   NLSCHK(ws_get_t(ctx, "evd.e", (size_t)D1, &evd_e));
   NLSCHK(ws_get_t(ctx, "evd.info", 4, &dinfo));
   NLSCHK(rot_buffers(ctx, mp, &rb));
+  HostPin pinL;  // the Gram kernels are in flight: page-lock the L_ output now, behind them
+  if (a->L) pinL.pin(a->L, sizeof(double2) * (size_t)D1 * D1);
   std::vector<double> hnodes, hW;
   bool compressed = sweep_compression(a->gammas, G, Gp, hnodes, hW);  // final once the smallest eigenvalue is known (below)
   double* Wd = nullptr;
@@ -710,6 +716,7 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
   int Gr = Gp;  // columns of the matrix the U / Gm products run against: the 128 nodes when the sweep is compressed
   const double inv_c = general_C ? 1.0 : 1.0 / st.c;
   double2 *Cn = nullptr, *Lc = nullptr;
+  double2* Qev_keep = nullptr;  // the eigenvectors (column-major), also needed for the re-solve at gamma*
   {
     SpanGuard g(ctx, NLS_T_EVD);
     NLSCHK(assemble_A(ctx, st, 1.0, Acm, db));
@@ -746,6 +753,7 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
                                  reinterpret_cast<rocblas_double_complex*>(Qev), D1));
     }
     NLSCHK(build_rot_planes(ctx, mp, Qev, 1L, (long)D1, false, rb));  // column-major Q
+    Qev_keep = Qev;
     hipLaunchKernelGGL(k_compute_v, dim3((unsigned)Np), dim3(256), 0, ctx->stream, Qev, (long)D1, db, D1, inv_c, rb.vr, rb.vi);
     if (compressed) {
       // The interpolation identity needs every pole -lam_j well to the left of the grid: measured through nls_sweep_weights
@@ -884,26 +892,61 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
   double hsum[2];
   HIPCHK(ctx, hipMemcpyAsync(hsum, csum, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
 
-  // ---- P8: Cholesky re-solve at gamma* ---------------------------------------------------------
+  // ---- P8: re-solve at gamma* -------------------------------------------------------------------
+  // beta = Q (v / (gamma* + lam)) from the eigendecomposition (exactly (gamma* C + A)^-1 b: A + gamma c I = c Q (Lam + gamma) Q^H): no
+  // factorisation on the critical path.  The Cholesky factor (_neo_ls_svm.py:176-178) is only an OUTPUT (L_): when the caller asks for it,
+  // zpotrf and the 16 (D+1)^2-byte download run on a side stream beside the residual pass; a->L == NULL skips both.
   double2* dbeta = nullptr;
   double *br = nullptr, *bi = nullptr;
   NLSCHK(ws_get_t(ctx, "chol.beta", (size_t)D1, &dbeta));
   NLSCHK(ws_get_t(ctx, "chol.br", (size_t)Kf, &br));
   NLSCHK(ws_get_t(ctx, "chol.bi", (size_t)Kf, &bi));
-  {
-    SpanGuard g(ctx, NLS_T_CHOLESKY);
+  rocblas_int* dinfo2 = nullptr;
+  bool side = false;
+  struct SideJoin {  // an early (error) return must not leave the side stream writing into the caller's L
+    hipStream_t s = nullptr;
+    ~SideJoin() {
+      if (s) (void)hipStreamSynchronize(s);
+    }
+  } side_join;
+  if (a->L) {
+    if (!ctx->stream2) {
+      HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+      if (rocblas_create_handle(&ctx->blas2) != rocblas_status_success) return fail(ctx, NLS_ERR_HIP, "rocblas_create_handle (side stream) failed");
+      BLASCHK(ctx, rocblas_set_stream(ctx->blas2, ctx->stream2));
+      for (auto& e : ctx->side_ev) HIPCHK(ctx, hipEventCreate(&e));
+    }
+    NLSCHK(ws_get_t(ctx, "chol.info2", 4, &dinfo2));
+    side = true;
+    hipStream_t s2 = ctx->stream2;
+    side_join.s = s2;
+    HIPCHK(ctx, hipEventRecord(ctx->side_ev[0], ctx->stream));  // everything that produced Acm / gamma* is behind this point
+    HIPCHK(ctx, hipStreamWaitEvent(s2, ctx->side_ev[0], 0));
     if (general_C) {  // gamma* C + A (_neo_ls_svm.py:177)
       const long tot = (long)D1 * D1;
-      hipLaunchKernelGGL(k_axpy_z, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, Cn, gamma_opt, tot, Acm);
+      hipLaunchKernelGGL(k_axpy_z, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s2, Cn, gamma_opt, tot, Acm);
     } else {
-      hipLaunchKernelGGL(k_add_diag, dim3((unsigned)((D1 + 255) / 256)), dim3(256), 0, ctx->stream, Acm, (long)D1, D1, gamma_opt * st.c);
+      hipLaunchKernelGGL(k_add_diag, dim3((unsigned)((D1 + 255) / 256)), dim3(256), 0, s2, Acm, (long)D1, D1, gamma_opt * st.c);
     }
     HIPCHK(ctx, hipGetLastError());
-    BLASCHK(ctx, rocsolver_zpotrf(ctx->blas, rocblas_fill_lower, D1, reinterpret_cast<rocblas_double_complex*>(Acm), D1, dinfo));
-    NLSCHK(check_info(ctx, dinfo, "rocsolver_zpotrf"));
-    HIPCHK(ctx, hipMemcpyAsync(dbeta, db, sizeof(double2) * D1, hipMemcpyDeviceToDevice, ctx->stream));
-    BLASCHK(ctx, rocsolver_zpotrs(ctx->blas, rocblas_fill_lower, D1, 1, reinterpret_cast<rocblas_double_complex*>(Acm), D1,
-                                  reinterpret_cast<rocblas_double_complex*>(dbeta), D1));
+    BLASCHK(ctx, rocsolver_zpotrf(ctx->blas2, rocblas_fill_lower, D1, reinterpret_cast<rocblas_double_complex*>(Acm), D1, dinfo2));
+    HIPCHK(ctx, hipEventRecord(ctx->side_ev[1], s2));
+    // Column-major lower factor L (A = L L^H) is, byte for byte, the conjugate of the row-major upper factor U = L^H that scipy's
+    // cho_factor(lower=False) returns.
+    const long tot = (long)D1 * D1;
+    hipLaunchKernelGGL(k_conj_inplace, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s2, Acm, tot);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(a->L, Acm, sizeof(double2) * (size_t)D1 * D1, hipMemcpyDeviceToHost, s2));
+    HIPCHK(ctx, hipEventRecord(ctx->side_ev[2], s2));
+  }
+  {
+    SpanGuard g(ctx, NLS_T_RESIDUALS);
+    const int nchunks = (D1 + 255) / 256;
+    double2* bpart = nullptr;
+    NLSCHK(ws_get_t(ctx, "chol.bpart", (size_t)nchunks * D1, &bpart));
+    hipLaunchKernelGGL(k_beta_evd_partial, dim3((unsigned)((D1 + 63) / 64), (unsigned)nchunks), dim3(256), 0, ctx->stream, Qev_keep, (long)D1, D1, rb.vr, rb.vi,
+                       lam, gamma_opt, bpart);
+    hipLaunchKernelGGL(k_beta_evd_finish, dim3((unsigned)((D1 + 255) / 256)), dim3(256), 0, ctx->stream, bpart, nchunks, D1, dbeta);
     hipLaunchKernelGGL(k_split_vec, dim3((unsigned)((Kf + 255) / 256)), dim3(256), 0, ctx->stream, dbeta, D, Kf, br, bi);
     HIPCHK(ctx, hipGetLastError());
   }
@@ -939,14 +982,15 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
     NLSCHK(d2h(a->loo_leverage, loo_lev, sizeof(double) * n));
     NLSCHK(d2h(a->loo_std, loo_std, sizeof(double) * n));
     NLSCHK(d2h(a->residuals, res, sizeof(double) * n));
-    if (a->L) {
-      // Column-major lower factor L (A = L L^H) is, byte for byte, the conjugate of the row-major
-      // upper factor U = L^H that scipy's cho_factor(lower=False) returns.
-      const long tot = (long)D1 * D1;
-      hipLaunchKernelGGL(k_conj_inplace, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, Acm, tot);
-      HIPCHK(ctx, hipGetLastError());
-      NLSCHK(d2h(a->L, Acm, sizeof(double2) * (size_t)D1 * D1));
-    }
+  }
+  if (side) {  // join the side stream; its stage times go into the cholesky / download slots
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream2));
+    rocblas_int info2 = 0;
+    HIPCHK(ctx, hipMemcpy(&info2, dinfo2, sizeof(info2), hipMemcpyDeviceToHost));
+    if (info2 != 0) return fail(ctx, NLS_ERR_LINALG, "rocsolver_zpotrf: info = %d (matrix not positive definite / no convergence)", (int)info2);
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ctx->side_ev[0], ctx->side_ev[1]) == hipSuccess) tm[NLS_T_CHOLESKY] += ms * 1e-3;
+    if (hipEventElapsedTime(&ms, ctx->side_ev[1], ctx->side_ev[2]) == hipSuccess) tm[NLS_T_DOWNLOAD] += ms * 1e-3;
   }
   NLSCHK(spans_collect(ctx, tm));
   if (a->loo_errors) std::memcpy(a->loo_errors, herrs.data(), sizeof(double) * G);

@@ -159,7 +159,11 @@ struct ChaseIO {
   static constexpr int TPR = 256 / B, CPT = B / TPR;
   __amdgpu_buffer_rsrc_t rs;
   int ldab, n;
-  __device__ __forceinline__ unsigned eoff(long i, long j) const { return (unsigned)(((i - j) + j * (long)ldab) * (long)sizeof(T)); }
+  // byte offset of band element (i, j): 32-bit arithmetic (the whole band array is far below 4 GB; 64-bit multiplies per element were a
+  // visible part of the store phase)
+  __device__ __forceinline__ unsigned eoff(long i, long j) const {
+    return ((unsigned)((int)i - (int)j) + (unsigned)(int)j * (unsigned)ldab) * (unsigned)sizeof(T);
+  }
   // off-diagonal block rows r1.., columns r0.. (L1 x L) and diagonal block at r1 (lower, L1 x L1), this thread's elements
   __device__ __forceinline__ void load(long r0, long r1, int L, int L1, bool with_b, T (&nb)[CPT], T (&nd)[CPT]) const {
     const int r = threadIdx.x / TPR, cg = threadIdx.x % TPR;

@@ -285,11 +285,18 @@ static int sy2sb(nls_ctx* ctx, T* A, int n, long lda, T* tau1, int* dflag, int* 
   return NLS_OK;
 }
 
-// Stage 2.  Band part of A (lower, bandwidth B) -> d[n], e[n-1], chase reflectors V2 (n x n).  ctl[1] != 0 afterwards: a workgroup timed out.
+// The chase reflectors live in a zero-padded array: v2_ld(n, B) rows (B extra: a reflector's B rows never run past the column) and
+// v2_cols(n, B) columns (a whole number of sweep groups), so the second back-transformation loads whole blocks without bounds tests.
+static inline long v2_ld(int n, int B) { return (long)n + B; }
+static inline long v2_cols(int n, int B) { return (long)((n - 1 + B - 1) / B) * B + B; }
+
+// Stage 2.  Band part of A (lower, bandwidth B) -> d[n], e[n-1], chase reflectors V2 (v2_ld x v2_cols, zeroed here).  ctl[1] != 0 afterwards: a workgroup timed out.
 template <class T, int B>
 static int sb2st(nls_ctx* ctx, const T* A, int n, long lda, double* d, double* e, T* V2, unsigned** ctl_out) {
   using namespace chase;
   const int ldab = 2 * B + 1;
+  const long ldv = v2_ld(n, B);
+  HIPCHK(ctx, hipMemsetAsync(V2, 0, sizeof(T) * (size_t)ldv * v2_cols(n, B), ctx->stream));
   T* AB = nullptr;
   unsigned* ctl = nullptr;
   NLSCHK(ws_get_t(ctx, "chase.AB", (size_t)n * ldab, &AB));
@@ -307,7 +314,7 @@ static int sb2st(nls_ctx* ctx, const T* A, int n, long lda, double* d, double* e
     NLSCHK(ws_get_t(ctx, "chase.stamps", (size_t)64, &stamps));
     HIPCHK(ctx, hipMemsetAsync(stamps, 0, 64 * sizeof(long long), ctx->stream));
   }
-  if (n >= 2) hipLaunchKernelGGL((k_chase<T, B>), dim3(W), dim3(256), lds, ctx->stream, AB, ldab, n, V2, (long)n, d, e, ctl, ctl + 16, stamps);
+  if (n >= 2) hipLaunchKernelGGL((k_chase<T, B>), dim3(W), dim3(256), lds, ctx->stream, AB, ldab, n, V2, ldv, d, e, ctl, ctl + 16, stamps);
   HIPCHK(ctx, hipGetLastError());
   if (want_stamps) {  // diagnostic: time line of sweep 64 (100 MHz clock: 10 ns units)
     long long h[64];
@@ -328,6 +335,7 @@ template <class T, int B>
 static int apply_q2(nls_ctx* ctx, const T* V2, int n, T* C, long ldc, int ncols) {
   using namespace q2;
   constexpr int NC = 16;
+  const long ldv = v2_ld(n, B);
   if (n < 2 || ncols <= 0) return NLS_OK;
   const int ngroups = (n - 1 + B - 1) / B;
   std::vector<int> off((size_t)ngroups + 1, 0);
@@ -342,7 +350,7 @@ static int apply_q2(nls_ctx* ctx, const T* V2, int n, T* C, long ldc, int ncols)
   const size_t mat = (sizeof(T) * B * (B + 1) + 15) & ~(size_t)15, wmat = (sizeof(T) * B * (NC + 1) + 15) & ~(size_t)15;
   const size_t lds_t = 2 * sizeof(T) * B * (B + 1);
   NLSCHK(sb_lds_optin(ctx, k_q2_tfactor<T, B>, lds_t, "k_q2_tfactor"));
-  hipLaunchKernelGGL((k_q2_tfactor<T, B>), dim3(nblocks), dim3(256), lds_t, ctx->stream, V2, (long)n, n, doff, ngroups, Tb);
+  hipLaunchKernelGGL((k_q2_tfactor<T, B>), dim3(nblocks), dim3(256), lds_t, ctx->stream, V2, ldv, n, doff, ngroups, Tb);
   // groups per pass: as many as the LDS ring allows (2 G block rows of the slab), at most 8
   int G = 8;
   if (const char* eg = std::getenv("NLS_Q2_GROUPS")) G = std::max(1, std::atoi(eg));
@@ -360,7 +368,7 @@ static int apply_q2(nls_ctx* ctx, const T* V2, int n, T* C, long ldc, int ncols)
         NLSCHK(ws_get_t(ctx, "q2.stamps", (size_t)64, &stamps));
         HIPCHK(ctx, hipMemsetAsync(stamps, 0, 64 * sizeof(long long), ctx->stream));
       }
-      hipLaunchKernelGGL((k_q2_apply_mfma<T, B>), dim3((unsigned)((ncols + NC - 1) / NC)), dim3(256), M::lds_bytes(G), ctx->stream, V2, (long)n, n, doff, ngroups, Tb,
+      hipLaunchKernelGGL((k_q2_apply_mfma<T, B>), dim3((unsigned)((ncols + NC - 1) / NC)), dim3(256), M::lds_bytes(G), ctx->stream, V2, ldv, n, doff, ngroups, Tb,
                          C, ldc, ncols, G, stamps);
       HIPCHK(ctx, hipGetLastError());
       if (want_stamps) {
@@ -380,7 +388,7 @@ static int apply_q2(nls_ctx* ctx, const T* V2, int n, T* C, long ldc, int ncols)
   if (lds_apply(G) > ((size_t)158 << 10)) return fail(ctx, NLS_ERR_ARG, "second back-transformation: complex blocks of %d do not fit the LDS", B);
   G = std::min(G, ngroups);
   NLSCHK(sb_lds_optin(ctx, k_q2_apply<T, B, NC>, lds_apply(G), "k_q2_apply"));
-  hipLaunchKernelGGL((k_q2_apply<T, B, NC>), dim3((unsigned)((ncols + NC - 1) / NC)), dim3(256), lds_apply(G), ctx->stream, V2, (long)n, n, doff, ngroups, Tb, C,
+  hipLaunchKernelGGL((k_q2_apply<T, B, NC>), dim3((unsigned)((ncols + NC - 1) / NC)), dim3(256), lds_apply(G), ctx->stream, V2, ldv, n, doff, ngroups, Tb, C,
                      ldc, ncols, G);
   HIPCHK(ctx, hipGetLastError());
   return NLS_OK;
@@ -520,7 +528,7 @@ static int evd_two_stage(nls_ctx* ctx, T* A, int n, double* lam, double* e_work,
   int* dflag = nullptr;
   NLSCHK(ws_get_t(ctx, CPLX ? "evd2.Acopy" : "evd2.Acopy_r", (size_t)n * n, &Acopy));
   NLSCHK(ws_get_t(ctx, CPLX ? "evd2.tau1" : "evd2.tau1_r", (size_t)n, &tau1));
-  NLSCHK(ws_get_t(ctx, CPLX ? "evd2.V2" : "evd2.V2_r", (size_t)n * n, &V2));
+  NLSCHK(ws_get_t(ctx, CPLX ? "evd2.V2" : "evd2.V2_r", (size_t)v2_ld(n, B) * v2_cols(n, B), &V2));
   NLSCHK(ws_get_t(ctx, "evd2.flag", 4, &dflag));
   HIPCHK(ctx, hipMemcpyAsync(Acopy, A, sizeof(T) * (size_t)n * n, hipMemcpyDeviceToDevice, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(dflag, 0, 4 * sizeof(int), ctx->stream));
@@ -624,20 +632,24 @@ static int evd_hermitian_core(nls_ctx* ctx, double2* A, int n, double* lam, doub
     // replicated.  The tridiagonal eigensolver runs on rank 0 ONLY and (lam, C) are broadcast: all ranks then pair the
     // same eigenvalues with the same basis whatever rocSOLVER's stedc does on clustered spectra.  The back-transformation
     // is split by columns over the ranks and the blocks are all-gathered.
-    double* flag = e_work;  // e is dead once stedc has run
+    // A failure on rank 0 (API error or info != 0) travels to all ranks through the broadcast flag instead of leaving them blocked in
+    // the collective.
+    double* flag = nullptr;
+    NLSCHK(ws_get_t(ctx, "evd.flag", 2, &flag));
     double hflag = 0.0;
     if (ctx->rank == 0) {
-      BLASCHK(ctx, rocsolver_zstedc(ctx->blas, rocblas_evect_tridiagonal, n, lam, e_work, reinterpret_cast<rocblas_double_complex*>(C), n, dinfo));
+      const rocblas_status st = rocsolver_zstedc(ctx->blas, rocblas_evect_tridiagonal, n, lam, e_work, reinterpret_cast<rocblas_double_complex*>(C), n, dinfo);
       rocblas_int info = 0;
-      HIPCHK(ctx, hipMemcpyAsync(&info, dinfo, sizeof(info), hipMemcpyDeviceToHost, ctx->stream));
-      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-      hflag = (double)info;
+      const hipError_t h1 = hipMemcpyAsync(&info, dinfo, sizeof(info), hipMemcpyDeviceToHost, ctx->stream);
+      const hipError_t h2 = hipStreamSynchronize(ctx->stream);
+      hflag = st != rocblas_status_success ? -1.0 : ((h1 != hipSuccess || h2 != hipSuccess) ? -2.0 : (double)info);
     }
     HIPCHK(ctx, hipMemcpyAsync(flag, &hflag, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     NLSCHK(do_broadcast(ctx, flag, 1, 0));
     HIPCHK(ctx, hipMemcpyAsync(&hflag, flag, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    if (hflag != 0.0) return fail(ctx, NLS_ERR_LINALG, "rocsolver_zstedc (rank 0): info = %d (no convergence)", (int)hflag);
+    if (hflag != 0.0)
+      return fail(ctx, NLS_ERR_LINALG, "rocsolver_zstedc on rank 0: %s (code %d)", hflag > 0 ? "no convergence" : "API failure", (int)hflag);
     NLSCHK(do_broadcast(ctx, lam, (size_t)n, 0));
     NLSCHK(do_broadcast(ctx, reinterpret_cast<double*>(C), (size_t)2 * n * n, 0));
     std::vector<size_t> offs((size_t)ctx->world + 1);
@@ -783,6 +795,9 @@ static int twostage_stage_impl(nls_ctx* ctx, int stage, void* A, int n, int bw, 
   int* dflag = nullptr;
   NLSCHK(ws_get_t(ctx, "hook.A", (size_t)n * n * (esz / 8), reinterpret_cast<double**>(&dA)));
   NLSCHK(ws_get_t(ctx, "hook2.aux", (size_t)n * std::max(n, ncols) * (esz / 8), reinterpret_cast<double**>(&daux)));
+  T* dV2 = nullptr;  // the chase reflectors in the library's padded layout (stages 2 and 3)
+  const long ldv = v2_ld(n, bw), v2c = v2_cols(n, bw);
+  if (stage != 1) NLSCHK(ws_get_t(ctx, "hook2.V2", (size_t)ldv * v2c * (esz / 8), reinterpret_cast<double**>(&dV2)));
   NLSCHK(ws_get_t(ctx, "hook.d", (size_t)n, &dd));
   NLSCHK(ws_get_t(ctx, "hook.e", (size_t)n, &de));
   NLSCHK(ws_get_t(ctx, "evd2.flag", 4, &dflag));
@@ -803,14 +818,13 @@ static int twostage_stage_impl(nls_ctx* ctx, int stage, void* A, int n, int bw, 
     info[1] = nred;
   } else if (stage == 2) {  // band (the lower bw sub-diagonals of A) -> d, e; aux = V2 (n x n) out; info[0] = chase error word
     unsigned* ctl = nullptr;
-    HIPCHK(ctx, hipMemsetAsync(daux, 0, esz * (size_t)n * n, ctx->stream));
     if (bw == 32)
-      NLSCHK((sb2st<T, 32>(ctx, dA, n, n, dd, de, daux, &ctl)));
+      NLSCHK((sb2st<T, 32>(ctx, dA, n, n, dd, de, dV2, &ctl)));
     else if constexpr (!CPLX)
-      NLSCHK((sb2st<T, 64>(ctx, dA, n, n, dd, de, daux, &ctl)));
+      NLSCHK((sb2st<T, 64>(ctx, dA, n, n, dd, de, dV2, &ctl)));
     unsigned hctl[2] = {0, 0};
     HIPCHK(ctx, hipMemcpyAsync(hctl, ctl, sizeof(hctl), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(aux, daux, esz * (size_t)n * n, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpy2DAsync(aux, esz * (size_t)n, dV2, esz * (size_t)ldv, esz * (size_t)n, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(d, dd, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
     if (n > 1) HIPCHK(ctx, hipMemcpyAsync(e, de, sizeof(double) * (n - 1), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -818,10 +832,12 @@ static int twostage_stage_impl(nls_ctx* ctx, int stage, void* A, int n, int bw, 
     info[1] = (int)hctl[0];
   } else if (stage == 3) {  // aux (n x ncols) <- Q2 aux with the chase reflectors V2 = A
     HIPCHK(ctx, hipMemcpyAsync(daux, aux, esz * (size_t)n * ncols, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(dV2, 0, esz * (size_t)ldv * v2c, ctx->stream));
+    HIPCHK(ctx, hipMemcpy2DAsync(dV2, esz * (size_t)ldv, A, esz * (size_t)n, esz * (size_t)n, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
     if (bw == 32)
-      NLSCHK((apply_q2<T, 32>(ctx, dA, n, daux, n, ncols)));
+      NLSCHK((apply_q2<T, 32>(ctx, dV2, n, daux, n, ncols)));
     else if constexpr (!CPLX)
-      NLSCHK((apply_q2<T, 64>(ctx, dA, n, daux, n, ncols)));
+      NLSCHK((apply_q2<T, 64>(ctx, dV2, n, daux, n, ncols)));
     HIPCHK(ctx, hipMemcpyAsync(aux, daux, esz * (size_t)n * ncols, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   } else {

@@ -269,7 +269,7 @@ __device__ __forceinline__ void q2_split(Z x, double& re, double& im) {
 }
 
 template <class T, int B>
-__global__ void __launch_bounds__(256) k_q2_apply_mfma(const T* V2, long ldv, int n, const int* blk_off, int ngroups, const T* Tb, T* C, long ldc, int ncols,
+__global__ void __launch_bounds__(256, 1) k_q2_apply_mfma(const T* V2, long ldv, int n, const int* blk_off, int ngroups, const T* Tb, T* C, long ldc, int ncols,
                                                        int G, long long* stamps /* diagnostic (nullptr: none): workgroup 0, blocks 200 .. 207 */) {
   using M = Q2M<T, B>;
   constexpr bool CX = M::CX;
@@ -319,16 +319,23 @@ __global__ void __launch_bounds__(256) k_q2_apply_mfma(const T* V2, long ldv, in
   T pv[EPT], tfn[TT][TKS], tf[TT][TKS];
   const int a_w = CX ? (wv >> 1) : wv;
   constexpr int ASTEP_T = CX ? 2 : 4;
+  // V2 is zero-padded (ldv = n + B rows, whole groups of columns), so a block is loaded without bounds tests: element (i, t) of block
+  // (S, k) sits at V2[u + voff[q]] with the block-uniform u = S B (ldv + 1) + 1 + k B and the per-thread constant voff = i (ldv + 1) + t;
+  // only the leading entry (t = 0: it holds tau) is replaced by 1 where the reflector exists.
+  unsigned voff[EPT];
+#pragma unroll
+  for (int q = 0; q < EPT; ++q) {
+    const int idx = threadIdx.x + 256 * q;
+    voff[q] = (unsigned)((idx / B) * (ldv + 1) + idx % B);
+  }
   auto fetch_block = [&](int S, int k) {
     const T* tsrc = Tb + ((long)blk_off[S] + k) * B * B;
+    const T* vsrc = V2 + ((long)S * B * (ldv + 1) + 1 + (long)k * B);
 #pragma unroll
     for (int q = 0; q < EPT; ++q) {
       const int idx = threadIdx.x + 256 * q;
-      const int t = idx % B, i = idx / B;
-      const long s = (long)S * B + i;
-      const long r0 = s + 1 + (long)k * B;
-      T v = zero_<T>();
-      if (s <= n - 2 && r0 + t < n) v = t == 0 ? one_<T>() : V2[(r0 + t) + s * ldv];
+      T v = vsrc[voff[q]];
+      if (idx % B == 0) v = ((long)S * B + idx / B + 1 + (long)k * B < n) ? one_<T>() : zero_<T>();
       pv[q] = v;
     }
 #pragma unroll
@@ -508,43 +515,59 @@ __global__ void __launch_bounds__(256) k_q2_apply_mfma(const T* V2, long ldv, in
           }
         }
       }
+      // ---------------- Z -= V W2 ----------------
+      // The V operands of this product only depend on Vc, so they are fetched BEFORE the barrier that publishes W2 (the reads overlap the
+      // wait); tile order balancing the k-steps: real B = 64: (0,3) (1,2) (4,7) (5,6); complex B = 32: (0,1) (2,3).
+      constexpr int NTILE2 = 2 * B / 16;  // row tiles of the window
+      constexpr int NW2 = CX ? 2 : 4;     // waves sharing the tiles (per part)
+      constexpr int TPW = NTILE2 / NW2;   // tiles per wave
+      const int wsel = CX ? (wv >> 1) : wv;
+      int btile[TPW];
+      double gvr[TPW][TKS], gvi[TPW][TKS];
+#pragma unroll
+      for (int bi = 0; bi < TPW; ++bi) {
+        int b;
+        if (TPW == 2) {
+          if (NTILE2 == 8) {
+            const int h = wsel >> 1, w2 = wsel & 1;
+            b = 4 * h + (bi == 0 ? w2 : 3 - w2);
+          } else {
+            b = 2 * wsel + bi;
+          }
+        } else {
+          b = wsel + NW2 * bi;
+        }
+        btile[bi] = b;
+        const int tl = 16 * b + l15 - l4;               // t = tl - 4 ks
+        const double* va = Vc + (size_t)l4 * LDV + tl;  // + 4 ks (LDV - 1)
+#pragma unroll
+        for (int ks = 0; ks < TKS; ++ks) {
+          const int t = tl - 4 * ks;
+          const bool ok = t >= 0 && t < B;
+          const double xr = va[4 * ks * (LDV - 1)];
+          gvr[bi][ks] = ok ? xr : 0.0;
+          if (CX) {
+            const double xi = va[vp + 4 * ks * (LDV - 1)];
+            gvi[bi][ks] = ok ? xi : 0.0;
+          }
+        }
+      }
       if (stamp) stp[4] = wall_clock64();
       chase::lds_barrier();  // B3
-      // ---------------- Z -= V W2 ----------------
       {
-        constexpr int NTILE = 2 * B / 16;  // row tiles of the window
-        const int wsel = CX ? (wv >> 1) : wv;
-        constexpr int NW = CX ? 2 : 4;  // waves sharing the tiles (per part)
-        for (int bi = 0; bi < NTILE / NW; ++bi) {
-          int b;  // tile order that balances the k-steps: real B = 64: (0,3) (1,2) (4,7) (5,6); complex B = 32: (0,1) (2,3)
-          if (NTILE / NW == 2) {
-            if (NTILE == 8) {
-              const int h = wsel >> 1, w2 = wsel & 1;
-              b = 4 * h + (bi == 0 ? w2 : 3 - w2);
-            } else {
-              b = 2 * wsel + bi;
-            }
-          } else {
-            b = wsel + NW * bi;
-          }
-          const int ilo = max(0, 16 * b - B + 1), ihi = min(B - 1, 16 * b + 15);
-          const int tl = 16 * b + l15 - l4;               // t = tl - 4 ks
-          const double* va = Vc + (size_t)l4 * LDV + tl;  // + 4 ks (LDV - 1)
-          const double* wa = W2 + lane;                   // + 64 ks
-          double fvr[TKS], fvi[TKS], fwr[TKS], fwi[TKS];
+#pragma unroll
+        for (int bi = 0; bi < TPW; ++bi) {
+          const int b = btile[bi];
+          const double* wa = W2 + lane;  // + 64 ks
+          double fwr[TKS], fwi[TKS];
+          double (&fvr)[TKS] = gvr[bi];
+          double (&fvi)[TKS] = gvi[bi];
 #pragma unroll
           for (int ks = 0; ks < TKS; ++ks) {
-            const int t = tl - 4 * ks;
-            const bool ok = t >= 0 && t < B;
-            const double xr = va[4 * ks * (LDV - 1)];
-            fvr[ks] = ok ? xr : 0.0;
             fwr[ks] = wa[64 * ks];
-            if (CX) {
-              const double xi = va[vp + 4 * ks * (LDV - 1)];
-              fvi[ks] = ok ? xi : 0.0;
-              fwi[ks] = wa[wp + 64 * ks];
-            }
+            if (CX) fwi[ks] = wa[wp + 64 * ks];
           }
+          const int ilo = 0, ihi = 0;
           // k-steps outside [ilo / 4, ihi / 4] multiply structural zeros of V (the "ok" mask): all B / 4 are run, branch-free
           (void)ilo;
           (void)ihi;

@@ -90,3 +90,43 @@ def test_c4_dual_identities():
     lhs = r["gamma"] * r["alpha"] / sn**2 + yhat
     assert np.max(np.abs(lhs - y)) <= 1e-8 * np.max(np.abs(y))
     assert np.all(np.isfinite(sigma)) and np.all(sigma >= 0)
+
+
+def test_c5_sigma_grid_fullsize_three_sigmas():
+    """BASELINE config 5 at FULL size (n = 1e6, d = 128, D = 4096, 32 gammas) on three sigmas: the early-out driver
+    (``NLS_FIT_FINISH_IF_BELOW``: a sigma that cannot beat the incumbent stops after the selection) must pick the same (sigma, gamma)
+    and return the same winner as three unconditional fits, and every sigma's curve must satisfy the c3 identities that need no
+    oracle: argmin of its own error curve, trace(A) / c = sum(lam), LOO error = sum s |e_loo| at the selected gamma."""
+    import bench
+    import neo_ls_svm_amd as hp
+
+    cfg = bench.CONFIGS["c5"]
+    n, d, D = cfg["n"], cfg["d"], cfg["D"]
+    ctx = hp.default_context()
+    X, y = bench.synth(n, d, 0, n)
+    s = np.ones(n)
+    sn = s / s.sum()
+    shift, scale, B = bench.affine_params(n, d, D, ctx=ctx)
+    dX, dy, ds = ctx.to_device(X), ctx.to_device(y), ctx.to_device(s)
+    gammas = hp.gamma_grid(1024)[::33]
+    sigmas = np.array([0.5, 1.0, 2.0])
+    grid = hp.primal_fit_sigma_grid(dX, dy, ds, shift, scale, B, False, sigmas, gammas=gammas, ctx=ctx)
+    c = 1.0 / (n * (D + 1))
+    full = []
+    for k, sg in enumerate(sigmas):
+        r = hp.primal_fit(dX, y, s, shift, scale, B / sg, False, gammas=gammas, ctx=ctx)
+        full.append(r)
+        # the driver's table row is this fit's curve (bit for bit: same kernels, same inputs)
+        assert np.array_equal(grid["loo_errors"][k], r["loo_errors_gammas"]), k
+        assert r["opt"] == int(np.argmin(r["loo_errors_gammas"]))
+        assert abs(np.sum(sn * np.abs(r["loo_residuals"])) - r["loo_errors_gammas"][r["opt"]]) <= 1e-10 * r["loo_errors_gammas"][r["opt"]]
+        A, _ = hp.gram(dX, y, s, shift, scale, B / sg, ctx=ctx)
+        assert abs(np.trace(A).real / c - r["lam"].sum()) <= 1e-9 * r["lam"].sum()
+        lev = r["loo_leverage"]
+        assert np.max(np.abs(r["loo_residuals"] * (1.0 - lev) - r["residuals"])) <= 1e-8 * np.max(np.abs(r["residuals"]))
+    k_best = int(np.argmin([r["loo_errors_gammas"].min() for r in full]))
+    assert grid["sigma_index"] == k_best and grid["gamma_index"] == full[k_best]["opt"]
+    best = grid["best"]
+    assert best is not None
+    for key in ("beta", "loo_residuals", "loo_leverage", "loo_std", "residuals"):
+        assert np.array_equal(best[key], full[k_best][key]), key

@@ -19,11 +19,11 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _launch(mode, world=2, timeout=600):
+def _launch(mode, world=2, timeout=600, extra_env=None):
     port = _free_port()
     procs = []
     for rank in range(world):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+        env = dict(os.environ, **(extra_env or {}), RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    OMP_NUM_THREADS="2", OPENBLAS_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")  # fmt: skip
         procs.append(subprocess.Popen([sys.executable, str(HERE / "_sharded_worker.py"), mode], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))  # fmt: skip
@@ -63,3 +63,10 @@ def test_sharded_protocol_world2_gloo_cpu():
 def test_sharded_library_world2_one_gpu():
     """The library's real sharded path: two ranks share GPU 0, collectives staged over gloo."""
     _launch("gpu")
+
+
+@pytest.mark.gpu
+def test_sharded_library_world2_one_gpu_two_stage_evd():
+    """The same with the eigendecomposition forced through the two-stage reduction: the tridiagonal eigenvectors are computed on rank 0
+    and broadcast as REAL numbers, each rank back-transforms (both stages) its own column block, the blocks are all-gathered."""
+    _launch("gpu", extra_env={"NLS_EVD": "twostage"})

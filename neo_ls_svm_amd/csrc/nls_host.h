@@ -50,6 +50,7 @@ struct nls_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   rocblas_handle blas = nullptr;
+  double* sintab = nullptr;        // device copy of the feature map's (sin, cos) table (nls_sincos.h), built at context creation
   hipStream_t stream2 = nullptr;   // side stream (created on first use): the Cholesky factor L_ and its download run beside the residual pass
   rocblas_handle blas2 = nullptr;
   hipEvent_t side_ev[4] = {nullptr, nullptr, nullptr, nullptr};  // fork, potrf done, download done (timing of the side stream)

@@ -39,7 +39,29 @@ struct FeatureMapParams {
   double* phi;  // rows x (D+1) complex interleaved (complex variant only)
   int stagger_ticks;  // > 0: the workgroups of the first round start out of phase (see k1_stagger)
   SinCosCoef sc;      // constants of the short sincos (kernel arguments -> SGPR operands, nls_sincos.h)
+  SinCosTabCoef tc;   // constants of the table form (what the epilogues run)
+  const double* sintab;  // 256 x {S_hi, C_hi, S_lo, C_lo} in global memory; copied into the (then idle) tile LDS before the epilogue
 };
+
+// The epilogues' table of (sin, cos)(2 pi n / 256): every thread fetches its 4 entries' worth of doubles BEFORE the main loop (the
+// loads fly under it) and drops them over the tile engine's LDS image once the main loop is done with it.
+struct SinCosTabRegs {
+  double v[4 * SINCOS_TAB_N / Cfg4::NTHREADS];
+};
+static_assert(4 * SINCOS_TAB_N % Cfg4::NTHREADS == 0, "the table is dealt evenly to the threads");
+__device__ __forceinline__ SinCosTabRegs fetch_sincos_table(const FeatureMapParams& p) {
+  SinCosTabRegs r;
+#pragma unroll
+  for (int q = 0; q < 4 * SINCOS_TAB_N / Cfg4::NTHREADS; ++q) r.v[q] = p.sintab[threadIdx.x + Cfg4::NTHREADS * q];
+  return r;
+}
+__device__ __forceinline__ const double* stage_sincos_table(const SinCosTabRegs& r, double* smem) {
+  __syncthreads();  // every wave is out of the main loop: the LDS image is free
+#pragma unroll
+  for (int q = 0; q < 4 * SINCOS_TAB_N / Cfg4::NTHREADS; ++q) smem[threadIdx.x + Cfg4::NTHREADS * q] = r.v[q];
+  __syncthreads();
+  return smem;
+}
 
 // The tile kernels of K1 have two phases - matrix pipe (K = d is short), then sincos + 2 x 128 stores per lane - and all
 // workgroups take the same time, so the 512 workgroups that start together (2 per CU) stay in lock-step: the whole chip
@@ -80,6 +102,7 @@ __global__ void __launch_bounds__(Cfg4::NTHREADS, 1) k_featuremap(FeatureMapPara
   const long row0 = (long)blockIdx.y * BM;
   const long col0 = (long)blockIdx.x * BN;
   k1_stagger(p.stagger_ticks);
+  const SinCosTabRegs tabr = fetch_sincos_table(p);
   v4d acc[C::MT][C::NTL];
   zero_acc(acc);
   if (col0 < p.D) {
@@ -87,6 +110,7 @@ __global__ void __launch_bounds__(Cfg4::NTHREADS, 1) k_featuremap(FeatureMapPara
     KMajorLoader<C::NTHREADS, BN> lb{p.Bs, p.Kf, col0};
     mainloop_real<C, false>(acc, la, lb, 0, p.dk / BK, smem);
   }
+  const double* tab = stage_sincos_table(tabr, smem);
   // One range test per thread: |t| <= 2^30 everywhere (always, in practice) -> the short sincos, else the library's.
   const bool small = all_args_small(acc);
   if constexpr (!COMPLEX_OUT) {
@@ -105,7 +129,7 @@ __global__ void __launch_bounds__(Cfg4::NTHREADS, 1) k_featuremap(FeatureMapPara
 #pragma unroll
           for (int nt = 0; nt < C::NTL; ++nt) {
             double sv, cv;
-            sincos_reduced_full(acc[mt][nt][r], sv, cv, p.sc);
+            sincos_table(acc[mt][nt][r], sv, cv, p.tc, tab);
             pc[nt * 16] = cv * f;
             ps[nt * 16] = sv * f;
           }
@@ -129,7 +153,7 @@ __global__ void __launch_bounds__(Cfg4::NTHREADS, 1) k_featuremap(FeatureMapPara
           double c = 0.0, s = 0.0;
           if (col < p.D) {
             double sv, cv;
-            if constexpr (FAST) sincos_reduced_full(acc[mt][nt][r], sv, cv, p.sc);
+            if constexpr (FAST) sincos_table(acc[mt][nt][r], sv, cv, p.tc, tab);
             else sincos(acc[mt][nt][r], &sv, &cv);
             c = cv * f;
             s = sv * f;
@@ -164,11 +188,13 @@ __global__ void __launch_bounds__(Cfg4::NTHREADS, 1) k_featuremap_gemv(FeatureMa
   extern __shared__ double smem[];
   const long row0 = (long)blockIdx.y * BM;
   const long col0 = (long)blockIdx.x * BN;
+  const SinCosTabRegs tabr = fetch_sincos_table(p);
   v4d acc[C::MT][C::NTL];
   zero_acc(acc);
   MMajorLoader<C::NTHREADS, BM> la{p.Xs, p.dk, row0};
   KMajorLoader<C::NTHREADS, BN> lb{p.Bs, p.Kf, col0};
   mainloop_real<C, false>(acc, la, lb, 0, p.dk / BK, smem);
+  const double* tab = stage_sincos_table(tabr, smem);
   double br[C::NTL], bi[C::NTL];  // weights of this lane's columns (zero beyond D: padded columns drop out)
 #pragma unroll
   for (int nt = 0; nt < C::NTL; ++nt) {
@@ -191,7 +217,7 @@ __global__ void __launch_bounds__(Cfg4::NTHREADS, 1) k_featuremap_gemv(FeatureMa
 #pragma unroll
         for (int nt = 0; nt < C::NTL; ++nt) {
           double sv, cv;
-          if constexpr (FAST) sincos_reduced_full(acc[mt][nt][r], sv, cv, p.sc);
+          if constexpr (FAST) sincos_table(acc[mt][nt][r], sv, cv, p.tc, tab);
           else sincos(acc[mt][nt][r], &sv, &cv);
           sum += cv * br[nt] + sv * bi[nt];
         }

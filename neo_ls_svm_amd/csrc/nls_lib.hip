@@ -76,6 +76,8 @@ static int launch_featuremap_planes(nls_ctx* ctx, const MapParams& mp, const dou
   p.phi = nullptr;
   p.stagger_ticks = ctx->k1_stagger_ticks;
   p.sc = sincos_coef();
+  p.tc = sincos_tab_coef();
+  p.sintab = ctx->sintab;
   dim3 grid((unsigned)(mp.Kf / BN), (unsigned)(rows_pad / BM));
   hipLaunchKernelGGL(k_featuremap<false>, grid, dim3(Cfg4::NTHREADS), SMEM_REAL, ctx->stream, p);
   HIPCHK(ctx, hipGetLastError());
@@ -148,6 +150,16 @@ extern "C" int nls_ctx_create(int device, nls_ctx** out) {
     return bail("hipStreamCreate", hipGetErrorString(e));
   if (rocblas_create_handle(&ctx->blas) != rocblas_status_success) return bail("rocblas_create_handle", "status != success");
   rocblas_set_stream(ctx->blas, ctx->stream);
+  {  // the feature map's sincos table (8 KB), computed on the host in long double
+    std::vector<double> tab((size_t)4 * SINCOS_TAB_N);
+    sincos_tab_fill(tab.data());
+    if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->sintab), sizeof(double) * tab.size())) != hipSuccess ||
+        (e = hipMemcpy(ctx->sintab, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice)) != hipSuccess) {
+      rocblas_destroy_handle(ctx->blas);
+      (void)hipStreamDestroy(ctx->stream);
+      return bail("sincos table upload", hipGetErrorString(e));
+    }
+  }
   // Opt in to > 64 KiB of dynamic LDS for the tile kernels.
   const char* lds_fail = nullptr;
   hipError_t lds_err = hipSuccess;
@@ -191,6 +203,7 @@ extern "C" void nls_ctx_destroy(nls_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   (void)nls_comm_destroy(ctx);
   if (ctx->comm_scratch) (void)hipFree(ctx->comm_scratch);
+  if (ctx->sintab) (void)hipFree(ctx->sintab);
   for (nls_factor* f : ctx->factors) factor_free(f);
   for (auto& kv : ctx->ws)
     if (kv.second.p) (void)hipFree(kv.second.p);
@@ -316,6 +329,8 @@ extern "C" int nls_featuremap(nls_ctx* ctx, const double* X, int64_t n, int d, c
     p.Kf = mp.Kf;
     p.inv_sqrt_D = 1.0 / std::sqrt((double)D);
     p.sc = sincos_coef();
+    p.tc = sincos_tab_coef();
+    p.sintab = ctx->sintab;
     p.Fc = p.Fs = nullptr;
     p.phi = out_dev ? phi + 2 * r0 * mp.D1 : dphi;
     dim3 grid((unsigned)(round_up(mp.D1, BN) / BN), (unsigned)(round_up(rows, BM) / BM));  // covers the bias column D
@@ -1135,6 +1150,8 @@ extern "C" int nls_primal_predict(nls_ctx* ctx, const double* X, int64_t m, int 
       p.Kf = mp.Kf;
       p.inv_sqrt_D = 1.0 / std::sqrt((double)D);
       p.sc = sincos_coef();
+      p.tc = sincos_tab_coef();
+      p.sintab = ctx->sintab;
       hipLaunchKernelGGL(k_featuremap_gemv, dim3((unsigned)(Kf / BN), (unsigned)(rows_pad / BM)), dim3(Cfg4::NTHREADS), SMEM_REAL,
                          ctx->stream, p, wr, wi, rows_pad, part);
       hipLaunchKernelGGL(k_gemv_finish, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, ctx->stream, part, nparts, rows_pad, rows, bias,

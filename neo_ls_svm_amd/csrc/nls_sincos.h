@@ -70,6 +70,67 @@ NLS_HD void sincos_reduced_full(double t, double& s, double& c, const SinCosCoef
 #endif
 }
 
+// ---- table form (what the kernels run since round 3) ----------------------------------------------------------------------------
+// One reduction straight onto a 256-entry table of the full circle: n = rint(t 128/pi) (magic-number rounding: the low bits of the
+// biased sum ARE n mod 256), r0 = t - n pi/128 in two fused steps (pi/128 to 107 bits; |r0| <= pi/256), then
+//   sin t = S + (S_lo + S (cos r0 - 1) + C sin r0),   cos t = C + (C_lo + C (cos r0 - 1) - S sin r0)
+// with (S, C) = (sin, cos)(2 pi n / 256) held as hi + lo pairs and degree-5 / degree-6 Taylor polynomials in r0 (truncation < 1e-17):
+// the bracket is < 0.013, so the only rounding that matters is the final add - error <= 0.5 ulp + 2e-18, no quadrant logic, 19 vector
+// instructions + two 16-byte LDS reads instead of ~35.  Valid for |t| <= 2^30 like the form above.
+constexpr int SINCOS_TAB_N = 256;
+struct SinCosTabCoef {
+  double n_over_pi, h_hi, h_lo, magic;
+  double s3, s5, c2, c4, c6;
+};
+inline SinCosTabCoef sincos_tab_coef() {
+  SinCosTabCoef k;
+  k.n_over_pi = 40.74366543152520595687;    // 128 / pi
+  k.h_hi = 0.0245436926061702596754;        // pi / 128 rounded:         0x1.921fb54442d18p-6
+  k.h_lo = 9.56755311833869685e-19;         // pi / 128 - that, rounded: 0x1.1a62633145c07p-60
+  k.magic = 6755399441055744.0;             // 1.5 * 2^52
+  k.s3 = -1.0 / 6.0;
+  k.s5 = 1.0 / 120.0;
+  k.c2 = -0.5;
+  k.c4 = 1.0 / 24.0;
+  k.c6 = -1.0 / 720.0;
+  return k;
+}
+// tab[4 n + {0,1,2,3}] = {S_hi, C_hi, S_lo, C_lo} of the angle 2 pi n / 256 (host, long double)
+inline void sincos_tab_fill(double* tab) {
+  const long double two_pi = 6.283185307179586476925286766559005768L;
+  for (int n = 0; n < SINCOS_TAB_N; ++n) {
+    long double sv = sinl(two_pi * n / SINCOS_TAB_N), cv = cosl(two_pi * n / SINCOS_TAB_N);
+    if (n % 64 == 0) {  // exact values on the axes
+      sv = (n == 64) ? 1.0L : (n == 192 ? -1.0L : 0.0L);
+      cv = (n == 0) ? 1.0L : (n == 128 ? -1.0L : 0.0L);
+    }
+    const double sh = (double)sv, ch = (double)cv;
+    tab[4 * n + 0] = sh;
+    tab[4 * n + 1] = ch;
+    tab[4 * n + 2] = (double)(sv - (long double)sh);
+    tab[4 * n + 3] = (double)(cv - (long double)ch);
+  }
+}
+NLS_HD void sincos_table(double t, double& s, double& c, const SinCosTabCoef& k, const double* tab) {
+  const double fm = fma(t, k.n_over_pi, k.magic);
+  const double fn = fm - k.magic;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int idx = __double2loint(fm) & (SINCOS_TAB_N - 1);
+#else
+  long long bits;
+  __builtin_memcpy(&bits, &fm, 8);
+  const int idx = (int)(bits & (SINCOS_TAB_N - 1));
+#endif
+  double r0 = fma(-fn, k.h_hi, t);
+  r0 = fma(-fn, k.h_lo, r0);
+  const double z0 = r0 * r0;
+  const double sr0 = fma(r0, fma(z0, k.s5, k.s3) * z0, r0);              // sin r0
+  const double cm = fma(z0, fma(z0, k.c6, k.c4), k.c2) * z0;             // cos r0 - 1
+  const double S = tab[4 * idx], C = tab[4 * idx + 1], Sl = tab[4 * idx + 2], Cl = tab[4 * idx + 3];
+  s = S + fma(C, sr0, fma(S, cm, Sl));
+  c = C + fma(-S, sr0, fma(C, cm, Cl));
+}
+
 NLS_HD void sincos_fast(double t, double& s, double& c, const SinCosCoef& k) {
   if (fabs(t) <= 1073741824.0 || t != t) return sincos_reduced_full(t, s, c, k);
   // |t| > 2^30, Inf: rare, the library's full-range routine

@@ -50,6 +50,7 @@ struct nls_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   rocblas_handle blas = nullptr;
+  bool k1_table = false;           // NLS_K1_SINCOS=table: the feature map's epilogue takes the table form of sincos (measured slower: nls_kernels.h)
   double* sintab = nullptr;        // device copy of the feature map's (sin, cos) table (nls_sincos.h), built at context creation
   hipStream_t stream2 = nullptr;   // side stream (created on first use): the Cholesky factor L_ and its download run beside the residual pass
   rocblas_handle blas2 = nullptr;

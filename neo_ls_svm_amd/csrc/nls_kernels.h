@@ -52,15 +52,26 @@ static_assert(4 * SINCOS_TAB_N % Cfg4::NTHREADS == 0, "the table is dealt evenly
 __device__ __forceinline__ SinCosTabRegs fetch_sincos_table(const FeatureMapParams& p) {
   SinCosTabRegs r;
 #pragma unroll
-  for (int q = 0; q < 4 * SINCOS_TAB_N / Cfg4::NTHREADS; ++q) r.v[q] = p.sintab[threadIdx.x + Cfg4::NTHREADS * q];
+  for (int q = 0; q < 4 * SINCOS_TAB_N / Cfg4::NTHREADS; ++q) r.v[q] = p.sintab ? p.sintab[threadIdx.x + Cfg4::NTHREADS * q] : 0.0;
   return r;
 }
-__device__ __forceinline__ const double* stage_sincos_table(const SinCosTabRegs& r, double* smem) {
+__device__ __forceinline__ const double* stage_sincos_table(const FeatureMapParams& p, const SinCosTabRegs& r, double* smem) {
+  if (!p.sintab) return nullptr;  // uniform: the polynomial form needs no table
   __syncthreads();  // every wave is out of the main loop: the LDS image is free
 #pragma unroll
   for (int q = 0; q < 4 * SINCOS_TAB_N / Cfg4::NTHREADS; ++q) smem[threadIdx.x + Cfg4::NTHREADS * q] = r.v[q];
   __syncthreads();
   return smem;
+}
+
+// sin / cos of one accumulator: the polynomial form by default; the table form when the launch handed a table (NLS_K1_SINCOS=table).
+// Measured on MI355X (profiles/r03_k1_sincos_table.log): the table form has 19 instead of ~35 vector instructions and a third of the
+// error, but its two 16-byte LDS reads at per-lane random indices collide on the banks: K1 26.6 -> 29.1 ms per c3 fit, decision_function
+// 49 -> 39 M rows/s.  The polynomial form stays the default.
+template <bool TAB>
+__device__ __forceinline__ void k1_sincos(double t, double& s, double& c, const FeatureMapParams& p, const double* tab) {
+  if constexpr (TAB) sincos_table(t, s, c, p.tc, tab);
+  else sincos_reduced_full(t, s, c, p.sc);
 }
 
 // The tile kernels of K1 have two phases - matrix pipe (K = d is short), then sincos + 2 x 128 stores per lane - and all
@@ -95,14 +106,15 @@ __device__ __forceinline__ bool all_args_small(const v4d (&acc)[MT][NTL]) {
   return m < 0x41d00000u;  // high word of 2^30
 }
 
-template <bool COMPLEX_OUT>
+template <bool COMPLEX_OUT, bool TAB = false>
 __global__ void __launch_bounds__(Cfg4::NTHREADS, 1) k_featuremap(FeatureMapParams p) {
   using C = Cfg4;
   extern __shared__ double smem[];
   const long row0 = (long)blockIdx.y * BM;
   const long col0 = (long)blockIdx.x * BN;
   k1_stagger(p.stagger_ticks);
-  const SinCosTabRegs tabr = fetch_sincos_table(p);
+  SinCosTabRegs tabr;
+  if constexpr (TAB) tabr = fetch_sincos_table(p);
   v4d acc[C::MT][C::NTL];
   zero_acc(acc);
   if (col0 < p.D) {
@@ -110,7 +122,8 @@ __global__ void __launch_bounds__(Cfg4::NTHREADS, 1) k_featuremap(FeatureMapPara
     KMajorLoader<C::NTHREADS, BN> lb{p.Bs, p.Kf, col0};
     mainloop_real<C, false>(acc, la, lb, 0, p.dk / BK, smem);
   }
-  const double* tab = stage_sincos_table(tabr, smem);
+  const double* tab = nullptr;
+  if constexpr (TAB) tab = stage_sincos_table(p, tabr, smem);
   // One range test per thread: |t| <= 2^30 everywhere (always, in practice) -> the short sincos, else the library's.
   const bool small = all_args_small(acc);
   if constexpr (!COMPLEX_OUT) {
@@ -129,7 +142,7 @@ __global__ void __launch_bounds__(Cfg4::NTHREADS, 1) k_featuremap(FeatureMapPara
 #pragma unroll
           for (int nt = 0; nt < C::NTL; ++nt) {
             double sv, cv;
-            sincos_table(acc[mt][nt][r], sv, cv, p.tc, tab);
+            k1_sincos<TAB>(acc[mt][nt][r], sv, cv, p, tab);
             pc[nt * 16] = cv * f;
             ps[nt * 16] = sv * f;
           }
@@ -153,7 +166,7 @@ __global__ void __launch_bounds__(Cfg4::NTHREADS, 1) k_featuremap(FeatureMapPara
           double c = 0.0, s = 0.0;
           if (col < p.D) {
             double sv, cv;
-            if constexpr (FAST) sincos_table(acc[mt][nt][r], sv, cv, p.tc, tab);
+            if constexpr (FAST) k1_sincos<TAB>(acc[mt][nt][r], sv, cv, p, tab);
             else sincos(acc[mt][nt][r], &sv, &cv);
             c = cv * f;
             s = sv * f;
@@ -182,19 +195,22 @@ __global__ void __launch_bounds__(Cfg4::NTHREADS, 1) k_featuremap(FeatureMapPara
 // Kf / 64 partials in a fixed order (+ Re beta[D]): bit-reproducible, and 512 B per row of traffic instead of the
 // 2 x 16 D bytes of writing the planes and reading them back (decision_function: 24 -> ~50 M rows/s at D = 4096).
 // ------------------------------------------------------------------------------------------------
+template <bool TAB = false>
 __global__ void __launch_bounds__(Cfg4::NTHREADS, 1) k_featuremap_gemv(FeatureMapParams p, const double* wr, const double* wi, long rows_pad,
                                                                      double* part) {
   using C = Cfg4;
   extern __shared__ double smem[];
   const long row0 = (long)blockIdx.y * BM;
   const long col0 = (long)blockIdx.x * BN;
-  const SinCosTabRegs tabr = fetch_sincos_table(p);
+  SinCosTabRegs tabr;
+  if constexpr (TAB) tabr = fetch_sincos_table(p);
   v4d acc[C::MT][C::NTL];
   zero_acc(acc);
   MMajorLoader<C::NTHREADS, BM> la{p.Xs, p.dk, row0};
   KMajorLoader<C::NTHREADS, BN> lb{p.Bs, p.Kf, col0};
   mainloop_real<C, false>(acc, la, lb, 0, p.dk / BK, smem);
-  const double* tab = stage_sincos_table(tabr, smem);
+  const double* tab = nullptr;
+  if constexpr (TAB) tab = stage_sincos_table(p, tabr, smem);
   double br[C::NTL], bi[C::NTL];  // weights of this lane's columns (zero beyond D: padded columns drop out)
 #pragma unroll
   for (int nt = 0; nt < C::NTL; ++nt) {
@@ -217,7 +233,7 @@ __global__ void __launch_bounds__(Cfg4::NTHREADS, 1) k_featuremap_gemv(FeatureMa
 #pragma unroll
         for (int nt = 0; nt < C::NTL; ++nt) {
           double sv, cv;
-          if constexpr (FAST) sincos_table(acc[mt][nt][r], sv, cv, p.tc, tab);
+          if constexpr (FAST) k1_sincos<TAB>(acc[mt][nt][r], sv, cv, p, tab);
           else sincos(acc[mt][nt][r], &sv, &cv);
           sum += cv * br[nt] + sv * bi[nt];
         }

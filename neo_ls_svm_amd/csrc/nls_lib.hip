@@ -77,9 +77,12 @@ static int launch_featuremap_planes(nls_ctx* ctx, const MapParams& mp, const dou
   p.stagger_ticks = ctx->k1_stagger_ticks;
   p.sc = sincos_coef();
   p.tc = sincos_tab_coef();
-  p.sintab = ctx->sintab;
+  p.sintab = ctx->k1_table ? ctx->sintab : nullptr;
   dim3 grid((unsigned)(mp.Kf / BN), (unsigned)(rows_pad / BM));
-  hipLaunchKernelGGL(k_featuremap<false>, grid, dim3(Cfg4::NTHREADS), SMEM_REAL, ctx->stream, p);
+  if (p.sintab)
+    hipLaunchKernelGGL((k_featuremap<false, true>), grid, dim3(Cfg4::NTHREADS), SMEM_REAL, ctx->stream, p);
+  else
+    hipLaunchKernelGGL((k_featuremap<false, false>), grid, dim3(Cfg4::NTHREADS), SMEM_REAL, ctx->stream, p);
   HIPCHK(ctx, hipGetLastError());
   return NLS_OK;
 }
@@ -145,6 +148,7 @@ extern "C" int nls_ctx_create(int device, nls_ctx** out) {
   if (const char* ep = std::getenv("NLS_ROT_PATCH")) std::sscanf(ep, "%dx%d", &ctx->rot_pr, &ctx->rot_pc);
   if (const char* er = std::getenv("NLS_NO_RESIDENT_PLANES")) ctx->no_resident = er[0] == '1';
   if (const char* es = std::getenv("NLS_K1_STAGGER_US")) ctx->k1_stagger_ticks = std::max(0, std::min(100000, (int)(std::atof(es) * 100.0)));
+  if (const char* et = std::getenv("NLS_K1_SINCOS")) ctx->k1_table = std::string(et) == "table";
   if (const char* ek = std::getenv("NLS_ROT_KSTAGGER")) ctx->rot_kstagger = std::max(0, std::min(16, std::atoi(ek)));
   if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess)
     return bail("hipStreamCreate", hipGetErrorString(e));
@@ -174,9 +178,12 @@ extern "C" int nls_ctx_create(int device, nls_ctx** out) {
   lds(reinterpret_cast<const void*>(k_gram3), m3::SMEM3);
   lds(reinterpret_cast<const void*>(k_rotate3), m3::SMEM3);
   lds(reinterpret_cast<const void*>(k_sweep), SMEM_REAL);
-  lds(reinterpret_cast<const void*>(k_featuremap<false>), SMEM_REAL);
-  lds(reinterpret_cast<const void*>(k_featuremap<true>), SMEM_REAL);
-  lds(reinterpret_cast<const void*>(k_featuremap_gemv), SMEM_REAL);
+  lds(reinterpret_cast<const void*>(k_featuremap<false, false>), SMEM_REAL);
+  lds(reinterpret_cast<const void*>(k_featuremap<true, false>), SMEM_REAL);
+  lds(reinterpret_cast<const void*>(k_featuremap_gemv<false>), SMEM_REAL);
+  lds(reinterpret_cast<const void*>(k_featuremap<false, true>), SMEM_REAL);
+  lds(reinterpret_cast<const void*>(k_featuremap<true, true>), SMEM_REAL);
+  lds(reinterpret_cast<const void*>(k_featuremap_gemv<true>), SMEM_REAL);
   lds(reinterpret_cast<const void*>(k_gemm<EPI_STORE>), SMEM_REAL);
   lds(reinterpret_cast<const void*>(k_gemm<EPI_RBF>), SMEM_REAL);
 #undef lds
@@ -330,11 +337,14 @@ extern "C" int nls_featuremap(nls_ctx* ctx, const double* X, int64_t n, int d, c
     p.inv_sqrt_D = 1.0 / std::sqrt((double)D);
     p.sc = sincos_coef();
     p.tc = sincos_tab_coef();
-    p.sintab = ctx->sintab;
+    p.sintab = ctx->k1_table ? ctx->sintab : nullptr;
     p.Fc = p.Fs = nullptr;
     p.phi = out_dev ? phi + 2 * r0 * mp.D1 : dphi;
     dim3 grid((unsigned)(round_up(mp.D1, BN) / BN), (unsigned)(round_up(rows, BM) / BM));  // covers the bias column D
-    hipLaunchKernelGGL(k_featuremap<true>, grid, dim3(Cfg4::NTHREADS), SMEM_REAL, ctx->stream, p);
+    if (p.sintab)
+      hipLaunchKernelGGL((k_featuremap<true, true>), grid, dim3(Cfg4::NTHREADS), SMEM_REAL, ctx->stream, p);
+    else
+      hipLaunchKernelGGL((k_featuremap<true, false>), grid, dim3(Cfg4::NTHREADS), SMEM_REAL, ctx->stream, p);
     HIPCHK(ctx, hipGetLastError());
     if (!out_dev)
       HIPCHK(ctx, hipMemcpyAsync(phi + 2 * r0 * mp.D1, dphi, (size_t)rows * row_bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -1151,9 +1161,13 @@ extern "C" int nls_primal_predict(nls_ctx* ctx, const double* X, int64_t m, int 
       p.inv_sqrt_D = 1.0 / std::sqrt((double)D);
       p.sc = sincos_coef();
       p.tc = sincos_tab_coef();
-      p.sintab = ctx->sintab;
-      hipLaunchKernelGGL(k_featuremap_gemv, dim3((unsigned)(Kf / BN), (unsigned)(rows_pad / BM)), dim3(Cfg4::NTHREADS), SMEM_REAL,
-                         ctx->stream, p, wr, wi, rows_pad, part);
+      p.sintab = ctx->k1_table ? ctx->sintab : nullptr;
+      if (p.sintab)
+        hipLaunchKernelGGL(k_featuremap_gemv<true>, dim3((unsigned)(Kf / BN), (unsigned)(rows_pad / BM)), dim3(Cfg4::NTHREADS), SMEM_REAL,
+                           ctx->stream, p, wr, wi, rows_pad, part);
+      else
+        hipLaunchKernelGGL(k_featuremap_gemv<false>, dim3((unsigned)(Kf / BN), (unsigned)(rows_pad / BM)), dim3(Cfg4::NTHREADS), SMEM_REAL,
+                           ctx->stream, p, wr, wi, rows_pad, part);
       hipLaunchKernelGGL(k_gemv_finish, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, ctx->stream, part, nparts, rows_pad, rows, bias,
                          dy + r0);
       HIPCHK(ctx, hipGetLastError());

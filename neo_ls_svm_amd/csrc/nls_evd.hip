@@ -342,43 +342,48 @@ static int apply_q2(nls_ctx* ctx, const T* V2, int n, T* C, long ldc, int ncols)
   for (int S = 0; S < ngroups; ++S) off[S + 1] = off[S] + q2_nblocks(n, B, S);
   const int nblocks = off[ngroups];
   int* doff = nullptr;
-  T* Tb = nullptr;
+  T *Tb = nullptr, *Pk = nullptr;
+  using L = Q2P<T, B>;
+  static const bool valu_env = [] { const char* m = std::getenv("NLS_Q2_VALU"); return m && m[0] == '1'; }();  // the VALU form (reference; tests)
+  const bool valu = valu_env || !L::AVAILABLE;
   NLSCHK(ws_get_t(ctx, "q2.off", (size_t)ngroups + 1, &doff));
-  NLSCHK(ws_get_t(ctx, "q2.T", (size_t)nblocks * B * B, &Tb));
+  if (valu)
+    NLSCHK(ws_get_t(ctx, "q2.T", (size_t)nblocks * B * B, &Tb));
+  else
+    NLSCHK(ws_get_t(ctx, "q2.P", (size_t)nblocks * L::PER_BLOCK, &Pk));
   HIPCHK(ctx, hipMemcpyAsync(doff, off.data(), sizeof(int) * off.size(), hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // off is a local
   const size_t mat = (sizeof(T) * B * (B + 1) + 15) & ~(size_t)15, wmat = (sizeof(T) * B * (NC + 1) + 15) & ~(size_t)15;
-  const size_t lds_t = 2 * sizeof(T) * B * (B + 1);
+  const size_t lds_t = (L::AVAILABLE ? 3 : 2) * sizeof(T) * B * (B + 1);
   NLSCHK(sb_lds_optin(ctx, k_q2_tfactor<T, B>, lds_t, "k_q2_tfactor"));
-  hipLaunchKernelGGL((k_q2_tfactor<T, B>), dim3(nblocks), dim3(256), lds_t, ctx->stream, V2, ldv, n, doff, ngroups, Tb);
+  hipLaunchKernelGGL((k_q2_tfactor<T, B>), dim3(nblocks), dim3(256), lds_t, ctx->stream, V2, ldv, n, doff, ngroups, Tb, Pk);
   // groups per pass: as many as the LDS ring allows (2 G block rows of the slab), at most 8
   int G = 8;
   if (const char* eg = std::getenv("NLS_Q2_GROUPS")) G = std::max(1, std::atoi(eg));
-  static const bool valu = [] { const char* m = std::getenv("NLS_Q2_VALU"); return m && m[0] == '1'; }();  // the VALU form (reference; tests)
-  constexpr bool can_mfma = !(sizeof(T) == 16 && B == 64);
-  if (!valu && can_mfma) {
-    if constexpr (can_mfma) {
-      using M = Q2M<T, B>;
-      while (G > 1 && M::lds_bytes(G) > ((size_t)158 << 10)) --G;
+  if (!valu) {
+    if constexpr (L::AVAILABLE) {
+      // more slabs than CUs: two workgroups per CU (half the LDS each) cover each other's barriers and operand latencies
+      const unsigned nwg = (unsigned)((ncols + 15) / 16);
+      const size_t budget = nwg > (unsigned)ctx->cus ? ((size_t)80 << 10) : ((size_t)158 << 10);
+      while (G > 1 && L::lds_bytes(G) > budget) --G;
       G = std::min(G, ngroups);
-      NLSCHK(sb_lds_optin(ctx, k_q2_apply_mfma<T, B>, M::lds_bytes(G), "k_q2_apply_mfma"));
+      NLSCHK(sb_lds_optin(ctx, k_q2_apply_packed<T, B>, L::lds_bytes(G), "k_q2_apply_packed"));
       long long* stamps = nullptr;
       static const bool want_stamps = [] { const char* m = std::getenv("NLS_Q2_STAMP"); return m && m[0] == '1'; }();
       if (want_stamps) {
         NLSCHK(ws_get_t(ctx, "q2.stamps", (size_t)64, &stamps));
         HIPCHK(ctx, hipMemsetAsync(stamps, 0, 64 * sizeof(long long), ctx->stream));
       }
-      hipLaunchKernelGGL((k_q2_apply_mfma<T, B>), dim3((unsigned)((ncols + NC - 1) / NC)), dim3(256), M::lds_bytes(G), ctx->stream, V2, ldv, n, doff, ngroups, Tb,
-                         C, ldc, ncols, G, stamps);
+      hipLaunchKernelGGL((k_q2_apply_packed<T, B>), dim3(nwg), dim3(256), L::lds_bytes(G), ctx->stream, Pk, doff, ngroups, n, C, ldc, ncols, G, stamps);
       HIPCHK(ctx, hipGetLastError());
       if (want_stamps) {
         long long h[64];
         HIPCHK(ctx, hipMemcpyAsync(h, stamps, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         for (int q = 0; q < 8; ++q)
-          std::fprintf(stderr, "[q2 stamps G=%d] block %d: B0 wait %.2f us, ring+commit+fetch %.2f, B1 %.2f, W1 %.2f, B2+T %.2f, B3+update %.2f | next block %.2f us later\n", G,
-                       200 + q, 0.0, (h[q * 8 + 1] - h[q * 8]) * 0.01, (h[q * 8 + 2] - h[q * 8 + 1]) * 0.01, (h[q * 8 + 3] - h[q * 8 + 2]) * 0.01,
-                       (h[q * 8 + 4] - h[q * 8 + 3]) * 0.01, (h[q * 8 + 5] - h[q * 8 + 4]) * 0.01, q < 7 ? (h[(q + 1) * 8] - h[q * 8]) * 0.01 : 0.0);
+          std::fprintf(stderr, "[q2 stamps G=%d] block %d: barrier + ring %.2f us, W1 %.2f, barrier %.2f, update %.2f | next block %.2f us later\n", G, 200 + q,
+                       (h[q * 8 + 1] - h[q * 8]) * 0.01, (h[q * 8 + 2] - h[q * 8 + 1]) * 0.01, (h[q * 8 + 3] - h[q * 8 + 2]) * 0.01,
+                       (h[q * 8 + 4] - h[q * 8 + 3]) * 0.01, q < 7 ? (h[(q + 1) * 8] - h[q * 8]) * 0.01 : 0.0);
       }
     }
     return NLS_OK;

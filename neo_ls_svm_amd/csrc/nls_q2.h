@@ -47,13 +47,36 @@ __device__ __forceinline__ void q2_load_block(const T* V2, long ldv, int n, int 
   }
 }
 
-// T factor of every block: Tb[block][i + B j] (upper triangular, zeros below)
+// Operands of one block in the layout the MFMA kernel (k_q2_apply_packed) consumes, written once by k_q2_tfactor: every lane of a wave
+// then fetches its A-operand fragments with contiguous 16-byte loads straight into registers - no LDS staging of V, no T stage:
+//   F1[a][ks][lane]  = conj(V[rho][i]),  rho = 16 a + 4 ks + lane / 16, i = 16 a + lane % 16      (W1 = V^H Z; tile a = reflectors 16a ..)
+//   F2[b][ks][lane]  = (V T)[rho][j],    rho = 16 b + lane % 16,         j = 4 ks + lane / 16      (Z -= (V T) W1; tile b = window rows 16b ..)
+// with V[rho][i] = Vc[i][rho - i] (0 <= rho - i < B).  V T is zero for rho >= j + B: the k-steps ks < ks2_first(b) of tile b are structural zeros
+// (stored, never read).  Real operands are stored in pairs of k-steps so that one 16-byte load feeds two MFMAs.
 template <class T, int B>
-__global__ void __launch_bounds__(256) k_q2_tfactor(const T* V2, long ldv, int n, const int* blk_off, int ngroups, T* Tb) {
+struct Q2P {
+  static constexpr bool CX = sizeof(T) == 16;
+  static constexpr int NP = CX ? 2 : 1;
+  static constexpr int NT1 = B / 16, KS1 = B / 4 + 4, NT2 = 2 * B / 16, KS2 = B / 4;
+  static constexpr size_t F1 = (size_t)NT1 * KS1 * 64, F2 = (size_t)NT2 * KS2 * 64, PER_BLOCK = F1 + F2;  // elements of T per block
+  static constexpr bool AVAILABLE = !(CX && B == 64);  // complex blocks of 64: k_q2_tfactor's three B x B matrices do not fit the LDS
+  __host__ __device__ static constexpr int ks2_first(int b) { return 4 * b - B / 4 > 0 ? 4 * b - B / 4 : 0; }
+  __host__ __device__ static size_t pos(int tile, int KS, int ks, int lane) {
+    return CX ? ((size_t)tile * KS + ks) * 64 + lane : (((size_t)tile * (KS / 2) + ks / 2) * 64 + lane) * 2 + (ks & 1);
+  }
+  static size_t lds_bytes(int G) { return sizeof(double) * ((size_t)NP * 16 * ((size_t)2 * G * B + 4) + (size_t)NP * B * 16); }
+};
+
+// T factor of every block: Tb[block][i + B j] (upper triangular, zeros below; Tb == nullptr: not stored) and the packed operands P
+// (nullptr: not stored).
+template <class T, int B>
+__global__ void __launch_bounds__(256) k_q2_tfactor(const T* V2, long ldv, int n, const int* blk_off, int ngroups, T* Tb, T* P) {
+  using L = Q2P<T, B>;
   extern __shared__ __attribute__((aligned(16))) unsigned char q2_smem[];
   T(*Vc)[B + 1] = reinterpret_cast<T(*)[B + 1]>(q2_smem);
   T(*Ti)[B + 1] = reinterpret_cast<T(*)[B + 1]>(q2_smem + sizeof(T) * B * (B + 1));
-  T(*Tm)[B + 1] = Vc;  // the block itself is dead once Ti is formed
+  // with the packed operands the block is still needed after T is formed (V T); without them T overwrites it
+  T(*Tm)[B + 1] = L::AVAILABLE ? reinterpret_cast<T(*)[B + 1]>(q2_smem + 2 * sizeof(T) * B * (B + 1)) : Vc;
   __shared__ T tau[B];
   // block index -> (S, k)
   const int b = blockIdx.x;
@@ -88,8 +111,27 @@ __global__ void __launch_bounds__(256) k_q2_tfactor(const T* V2, long ldv, int n
     }
   }
   __syncthreads();
-  T* out = Tb + (long)b * B * B;
-  for (int e = threadIdx.x; e < B * B; e += 256) out[e] = Tm[e % B][e / B];
+  if (Tb != nullptr) {
+    T* out = Tb + (long)b * B * B;
+    for (int e = threadIdx.x; e < B * B; e += 256) out[e] = Tm[e % B][e / B];
+  }
+  if constexpr (L::AVAILABLE) {
+    if (P == nullptr) return;
+    T* out = P + (size_t)b * L::PER_BLOCK;
+    for (int e = threadIdx.x; e < (int)L::F1; e += 256) {
+      const int lane = e % 64, ks = (e / 64) % L::KS1, a = e / (64 * L::KS1);
+      const int i = 16 * a + (lane & 15), t = 4 * ks + (lane >> 4) - (lane & 15);
+      out[L::pos(a, L::KS1, ks, lane)] = (t >= 0 && t < B) ? conj_(Vc[i][t]) : zero_<T>();
+    }
+    out += L::F1;
+    for (int e = threadIdx.x; e < (int)L::F2; e += 256) {
+      const int lane = e % 64, ks = (e / 64) % L::KS2, bt = e / (64 * L::KS2);
+      const int rho = 16 * bt + (lane & 15), j = 4 * ks + (lane >> 4);
+      T s = zero_<T>();
+      for (int i = max(0, rho - B + 1); i <= min(j, rho); ++i) s = s + Vc[i][rho - i] * Tm[i][j];
+      out[L::pos(bt, L::KS2, ks, lane)] = s;
+    }
+  }
 }
 
 template <class T, int B, int NC>
@@ -238,27 +280,15 @@ __global__ void __launch_bounds__(256) k_q2_apply(const T* V2, long ldv, int n, 
 }
 
 // ================================================================================================================
-// MFMA form of k_q2_apply (the one the library runs).  Same passes / steps / ring as above; the three products of a block run on
-// v_mfma_f64_16x16x4_f64 (A[i][k]: lane = 16 k + i, B[k][j]: lane = 16 k + j, D[i][j]: lane = 16 (i % 4) + j, reg = i / 4), NC = 16 columns
-// of C per workgroup = one MFMA tile wide.  Everything in LDS is split into real planes.  Structural zeros of the parallelogram are
-// skipped in units of one k-step (4): W1 tile a (reflectors 16a .. 16a+15) sums window rows 16a .. 16a + B + 15; the update of window
-// rows 16b .. 16b+15 sums the reflectors that reach them; T is upper triangular.  Work per wave and block: real B = 64: 20 + 16 + 20
-// MFMAs; complex B = 32: 24 + 16 + 24 (wave = (tile set, real / imaginary part of the result)).
-// V and T of the NEXT block are fetched into registers while the current block computes.
+// MFMA form of k_q2_apply (the one the library runs).  Same passes / steps / ring as above, 16 columns of C per workgroup = one tile of
+// v_mfma_f64_16x16x4_f64 (A[i][k]: lane = 16 k + i, B[k][j]: lane = 16 k + j, D[i][j]: lane = 16 (i % 4) + j, reg = i / 4).  A block is two
+// products, W1 = V^H Z and Z -= (V T) W1, whose A operands come from the packed copy Q2P in registers: the fragments of the NEXT block are
+// requested as soon as the current ones have been consumed, so they travel while the other product runs.  LDS holds only the ring (real
+// planes, column-major with a leading dimension = 4 mod 32 doubles: operand reads, accumulator updates and the row transfers are all
+// conflict-free) and W1 - 48 to 80 KB, two workgroups per CU, which is what hides the barriers and the LDS latency of each other.
+// Waves: real: wave = tile set; complex: wave = (tile set, real / imaginary part of the result).  The roles rotate with the workgroup
+// index so that co-resident workgroups put their heavier waves on different SIMDs.
 // ================================================================================================================
-template <class T, int B>
-struct Q2M {
-  static constexpr bool CX = sizeof(T) == 16;
-  static constexpr int NP = CX ? 2 : 1;
-  static constexpr int NC = 16;
-  static constexpr int LDV = B + 3;  // (LDV - 1) = 2 (mod 32): the A-operand reads of V^H (lane stride LDV - 1) hit 32 distinct 8-byte banks
-  static constexpr int EPT = B * B / 256;  // elements of V (and of T) per thread
-  static_assert(!(CX && B == 64), "complex blocks of 64 do not fit the LDS budget");
-  static size_t lds_bytes(int G) {
-    return sizeof(double) * ((size_t)NP * (2 * G) * B * NC + (size_t)NP * B * LDV + 2 * (size_t)NP * B * NC);
-  }
-};
-
 __device__ __forceinline__ void q2_split(double x, double& re, double& im) {
   re = x;
   im = 0.0;
@@ -267,106 +297,115 @@ __device__ __forceinline__ void q2_split(Z x, double& re, double& im) {
   re = x.re;
   im = x.im;
 }
+// fragment registers of one tile: real: pairs of k-steps; complex: (re, im) of one k-step
+template <class T, int KS>
+struct Q2Frag;
+template <int KS>
+struct Q2Frag<double, KS> {
+  double2 v[KS / 2];
+  __device__ __forceinline__ void load(const double* base, int tile, int lane) {
+    const double2* p = reinterpret_cast<const double2*>(base) + (size_t)tile * (KS / 2) * 64 + lane;
+#pragma unroll
+    for (int q = 0; q < KS / 2; ++q) v[q] = p[64 * q];
+  }
+  __device__ __forceinline__ double re(int ks) const { return (ks & 1) ? v[ks / 2].y : v[ks / 2].x; }
+  __device__ __forceinline__ double im(int) const { return 0.0; }
+};
+template <int KS>
+struct Q2Frag<Z, KS> {
+  double2 v[KS];
+  __device__ __forceinline__ void load(const Z* base, int tile, int lane) {
+    const double2* p = reinterpret_cast<const double2*>(base) + (size_t)tile * KS * 64 + lane;
+#pragma unroll
+    for (int q = 0; q < KS; ++q) v[q] = p[64 * q];
+  }
+  __device__ __forceinline__ double re(int ks) const { return v[ks].x; }
+  __device__ __forceinline__ double im(int ks) const { return v[ks].y; }
+};
 
 template <class T, int B>
-__global__ void __launch_bounds__(256, 1) k_q2_apply_mfma(const T* V2, long ldv, int n, const int* blk_off, int ngroups, const T* Tb, T* C, long ldc, int ncols,
-                                                       int G, long long* stamps /* diagnostic (nullptr: none): workgroup 0, blocks 200 .. 207 */) {
-  using M = Q2M<T, B>;
-  constexpr bool CX = M::CX;
-  constexpr int NP = M::NP, NC = M::NC, LDV = M::LDV, EPT = M::EPT;
+__global__ void __launch_bounds__(256, 2) k_q2_apply_packed(const T* __restrict__ P, const int* __restrict__ blk_off, int ngroups, int n, T* C, long ldc,
+                                                             int ncols, int G, long long* stamps /* diagnostic (nullptr: none): workgroup 0, blocks 200 .. 207 */) {
+  using L = Q2P<T, B>;
+  constexpr bool CX = L::CX;
+  constexpr int NP = L::NP, KS1 = L::KS1, KS2 = L::KS2, NT1 = L::NT1, NT2 = L::NT2;
+  constexpr int NW = CX ? 2 : 4;  // waves per part of the result
+  constexpr int TPW = NT2 / NW;   // window tiles per wave
+  static_assert(NT1 <= NW && (TPW == 1 || TPW == 2), "tile distribution");
   extern __shared__ __attribute__((aligned(16))) unsigned char q2_smem[];
-  const int R = 2 * G;
-  double* ring = reinterpret_cast<double*>(q2_smem);          // [NP][R * B][NC]
-  double* Vc = ring + (size_t)NP * R * B * NC;                  // [NP][B][LDV]   Vc[i][t]: entry of reflector i at window row i + t
-  double* W1 = Vc + (size_t)NP * B * LDV;                       // [NP][B][NC]
-  double* W2 = W1 + (size_t)NP * B * NC;                        // [NP][B][NC]
-  const size_t ringp = (size_t)R * B * NC, vp = (size_t)B * LDV, wp = (size_t)B * NC;
-  const long c0 = (long)blockIdx.x * NC;
+  const int R = 2 * G, LDR = R * B + 4;
+  double* ring = reinterpret_cast<double*>(q2_smem);  // [NP][16][LDR]: ring[c LDR + slot B + r]
+  double* W1 = ring + (size_t)NP * 16 * LDR;          // [NP][B][16]
+  const int ringp = 16 * LDR, wp = B * 16;
+  const long c0 = (long)blockIdx.x * 16;
   const int lane = threadIdx.x & 63;
-  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave index in a scalar register: tile choices are uniform
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int l15 = lane & 15, l4 = lane >> 4;
+  const int role = (wv + (int)(blockIdx.x >> 8)) & 3;
+  const int wsel = CX ? role >> 1 : role, part = CX ? role & 1 : 0;
+  const int rl = l15 * LDR + l4;  // this lane's element of a 4-row x 16-column operand / accumulator slice: + first row
+  // complex products (ar + i ai)(br + i bi): part 0 sums ar br and ai bi (result: difference), part 1 sums ar bi and ai br (result: sum);
+  // which plane feeds which chain is a matter of addresses, decided once
+  const int pl1 = part ? 1 : 0, pl2 = part ? 0 : 1;
+  const double sgn = part ? 1.0 : -1.0;
 
-  auto load_blockrow = [&](int tb) {
-    const int slot = tb % R;
-    for (int idx = threadIdx.x; idx < B * NC; idx += 256) {
-      const int rr = idx % B, cc = idx / B;
+  // ---- block rows: C <-> ring, one row in flight in registers
+  constexpr int EPR = B * 16 / 256;
+  T pre[EPR];
+  auto fetch_row = [&](int tb) {
+#pragma unroll
+    for (int q = 0; q < EPR; ++q) {
+      const int idx = threadIdx.x + 256 * q, rr = idx % B, cc = idx / B;
       const long gr = (long)tb * B + 1 + rr;
-      double re = 0.0, im = 0.0;
-      if (gr < n && c0 + cc < ncols) q2_split(C[gr + (c0 + cc) * ldc], re, im);
-      ring[(size_t)(slot * B + rr) * NC + cc] = re;
-      if (CX) ring[ringp + (size_t)(slot * B + rr) * NC + cc] = im;
+      pre[q] = (gr < n && c0 + cc < ncols) ? C[gr + (c0 + cc) * ldc] : zero_<T>();
     }
   };
-  auto store_blockrow = [&](int tb) {
+  auto commit_row = [&](int tb) {
     const int slot = tb % R;
-    for (int idx = threadIdx.x; idx < B * NC; idx += 256) {
-      const int rr = idx % B, cc = idx / B;
+#pragma unroll
+    for (int q = 0; q < EPR; ++q) {
+      const int idx = threadIdx.x + 256 * q, rr = idx % B, cc = idx / B;
+      double re, im;
+      q2_split(pre[q], re, im);
+      ring[cc * LDR + slot * B + rr] = re;
+      if (CX) ring[ringp + cc * LDR + slot * B + rr] = im;
+    }
+  };
+  auto store_row = [&](int tb) {
+    const int slot = tb % R;
+#pragma unroll
+    for (int q = 0; q < EPR; ++q) {
+      const int idx = threadIdx.x + 256 * q, rr = idx % B, cc = idx / B;
       const long gr = (long)tb * B + 1 + rr;
       if (gr < n && c0 + cc < ncols) {
-        const double re = ring[(size_t)(slot * B + rr) * NC + cc];
-        const double im = CX ? ring[ringp + (size_t)(slot * B + rr) * NC + cc] : 0.0;
+        const double re = ring[cc * LDR + slot * B + rr];
+        const double im = CX ? ring[ringp + cc * LDR + slot * B + rr] : 0.0;
         C[gr + (c0 + cc) * ldc] = make_<T>(re, im);
       }
     }
   };
 
-  int nblk_done = 0;
-  // Prefetch registers.  V: this thread's EPT elements (idx = tid + 256 q: t = idx % B, i = idx / B), staged through LDS.  T: this lane's
-  // A-operand fragments of the W2 = T W1 product, straight from global memory (T[i][t] at Tb[i + B t]: the 16 lanes of a k-row read 16
-  // consecutive elements): tile a = a_w + ASTEP x, k-step ks, element (i = 16 a + l15, t = 4 ks + l4); only ks >= 4 a is non-zero.
-  constexpr int TT = CX ? 1 : (B / 16 + 3) / 4;  // T tiles per wave
-  constexpr int TKS = B / 4;
-  T pv[EPT], tfn[TT][TKS], tf[TT][TKS];
-  const int a_w = CX ? (wv >> 1) : wv;
-  constexpr int ASTEP_T = CX ? 2 : 4;
-  // V2 is zero-padded (ldv = n + B rows, whole groups of columns), so a block is loaded without bounds tests: element (i, t) of block
-  // (S, k) sits at V2[u + voff[q]] with the block-uniform u = S B (ldv + 1) + 1 + k B and the per-thread constant voff = i (ldv + 1) + t;
-  // only the leading entry (t = 0: it holds tau) is replaced by 1 where the reflector exists.
-  unsigned voff[EPT];
-#pragma unroll
-  for (int q = 0; q < EPT; ++q) {
-    const int idx = threadIdx.x + 256 * q;
-    voff[q] = (unsigned)((idx / B) * (ldv + 1) + idx % B);
-  }
-  auto fetch_block = [&](int S, int k) {
-    const T* tsrc = Tb + ((long)blk_off[S] + k) * B * B;
-    const T* vsrc = V2 + ((long)S * B * (ldv + 1) + 1 + (long)k * B);
-#pragma unroll
-    for (int q = 0; q < EPT; ++q) {
-      const int idx = threadIdx.x + 256 * q;
-      T v = vsrc[voff[q]];
-      if (idx % B == 0) v = ((long)S * B + idx / B + 1 + (long)k * B < n) ? one_<T>() : zero_<T>();
-      pv[q] = v;
-    }
-#pragma unroll
-    for (int x = 0; x < TT; ++x) {
-      const int a = a_w + ASTEP_T * x;
-#pragma unroll
-      for (int ks = 0; ks < TKS; ++ks)
-        tfn[x][ks] = (a < B / 16 && ks >= 4 * a) ? tsrc[(16 * a + l15) + (long)B * (4 * ks + l4)] : zero_<T>();
-    }
+  // window tiles of this wave
+  int btile[TPW];
+  btile[0] = wsel;
+  if (TPW == 2) btile[TPW - 1] = NT2 - 1 - wsel;
+  Q2Frag<T, KS1> f1;
+  Q2Frag<T, KS2> f2[TPW];
+  auto fetch1 = [&](int S, int k) {
+    if (wsel < NT1) f1.load(P + ((size_t)blk_off[S] + k) * L::PER_BLOCK, wsel, lane);
   };
-  auto commit_block = [&]() {
+  auto fetch2 = [&](int S, int k) {
 #pragma unroll
-    for (int q = 0; q < EPT; ++q) {
-      const int idx = threadIdx.x + 256 * q;
-      double re, im;
-      q2_split(pv[q], re, im);
-      Vc[(size_t)(idx / B) * LDV + idx % B] = re;
-      if (CX) Vc[vp + (size_t)(idx / B) * LDV + idx % B] = im;
-    }
-#pragma unroll
-    for (int x = 0; x < TT; ++x)
-#pragma unroll
-      for (int ks = 0; ks < TKS; ++ks) tf[x][ks] = tfn[x][ks];
+    for (int bi = 0; bi < TPW; ++bi) f2[bi].load(P + ((size_t)blk_off[S] + k) * L::PER_BLOCK + L::F1, btile[bi], lane);
   };
 
+  int nblk_done = 0;
   for (int S_hi = ngroups - 1; S_hi >= 0; S_hi -= G) {
     const int gcount = min(G, S_hi + 1);
     int u_last = 0;
     for (int i = 0; i < gcount; ++i) u_last = max(u_last, q2_nblocks(n, B, S_hi - i) - 1 + i);
     // cursor over the active blocks of the pass in execution order: (u, i) with k = u - i in [0, nblocks(S_hi - i))
-    auto next_active = [&](int& u, int& i) -> bool {  // advance to the next active block strictly after (u, i)
+    auto next_active = [&](int& u, int& i) -> bool {
       for (;;) {
         ++i;
         if (i >= gcount) {
@@ -380,237 +419,106 @@ __global__ void __launch_bounds__(256, 1) k_q2_apply_mfma(const T* V2, long ldv,
     };
     int cu = 0, ci = -1;
     bool have = next_active(cu, ci);
-    if (have) fetch_block(S_hi - ci, cu - ci);
-    int lo = S_hi - gcount + 1, hi = lo - 1;  // block rows in the ring
-    int ring_u = -1;                         // the step the ring has been prepared for
+    if (have) {
+      fetch1(S_hi - ci, cu - ci);
+      fetch2(S_hi - ci, cu - ci);
+    }
+    // the ring starts with the block rows S_hi - gcount + 1 .. S_hi + 1 (what step 0 and the joining groups need) and slides by one per step
+    int lo = S_hi - gcount + 1, hi = lo - 1;
+    __syncthreads();  // the previous pass has written its rows back
+    while (hi < S_hi + 1) {
+      ++hi;
+      fetch_row(hi);
+      commit_row(hi);
+    }
+    fetch_row(hi + 1);
+    int pre_tb = hi + 1;
     while (have) {
       const int u = cu, i = ci;
       const int S = S_hi - i, k = u - i, tb = S + k;
       const bool stamp = stamps != nullptr && blockIdx.x == 0 && threadIdx.x == 0 && nblk_done >= 200 && nblk_done < 208;
       long long* stp = stamps + (nblk_done - 200) * 8;
       if (stamp) stp[0] = wall_clock64();
-      chase::lds_barrier();  // B0: the previous block's update of the ring and its reads of Vc / Ts / W2 are complete
-      if (ring_u != u) {
-        const int want_hi = S_hi + u + 1;
-        while (hi < want_hi) {
+      chase::lds_barrier();  // B0: the previous block's update of the ring and its reads of W1 are complete
+      if (hi < S_hi + u + 1) {
+        while (hi < S_hi + u + 1) {
           if (hi + 1 - lo >= R) {
-            store_blockrow(lo);
+            store_row(lo);
             ++lo;
-            __syncthreads();
+            chase::lds_barrier();  // the slot has been read by everyone before it is overwritten
           }
           ++hi;
-          load_blockrow(hi);
+          if (pre_tb != hi) fetch_row(hi);
+          commit_row(hi);
         }
-        ring_u = u;
+        fetch_row(hi + 1);
+        pre_tb = hi + 1;
+        chase::lds_barrier();
       }
-      commit_block();
       int nu = cu, ni = ci;
       const bool more = next_active(nu, ni);
-      if (more) fetch_block(S_hi - ni, nu - ni);
       if (stamp) stp[1] = wall_clock64();
-      chase::lds_barrier();  // B1 (LDS only: the prefetch loads of the next block stay in flight)
-      if (stamp) stp[2] = wall_clock64();
       const int base0 = (tb % R) * B, base1 = ((tb + 1) % R) * B;
-      // window row rho0 + l4 (rho0 a multiple of 4, wave-uniform) of column l15 sits at ring[wbase(rho0) * NC + lane]
+      // first ring row of the 4-row slice that starts at window row rho0 (a multiple of 4, wave-uniform)
       auto wbase = [&](int rho0) -> int { return rho0 < B ? base0 + rho0 : base1 + rho0 - B; };
-      const int part = CX ? (wv & 1) : 0;
       // ---------------- W1 = V^H Z ----------------
-      {
-        constexpr int NTILE = B / 16;  // row tiles of W1
-        constexpr int KS = B / 4 + 4;  // k-steps per tile
-        constexpr int ASTEP = CX ? 2 : 4;
-        for (int a = CX ? (wv >> 1) : wv; a < NTILE; a += ASTEP) {
-          const int t0 = l4 - l15;                                    // t = 4 ks + t0
-          const double* va = Vc + (size_t)(16 * a + l15) * LDV + t0;  // + 4 ks
-          double fvr[KS], fvi[KS], fzr[KS], fzi[KS];
+      if (wsel < NT1) {
+        const int a = wsel;
+        double z1[KS1], z2[KS1];
 #pragma unroll
-          for (int ks = 0; ks < KS; ++ks) {
-            const int t = 4 * ks + t0;
-            const bool ok = (ks >= 4 || t >= 0) && (ks < B / 4 || t < B);
-            const int zo = wbase(16 * a + 4 * ks) * NC + lane;
-            const double xr = va[4 * ks];
-            fvr[ks] = ok ? xr : 0.0;
-            fzr[ks] = ring[zo];
-            if (CX) {
-              const double xi = va[vp + 4 * ks];
-              fvi[ks] = ok ? xi : 0.0;
-              fzi[ks] = ring[ringp + zo];
-            }
-          }
-          // Re(conj(v) z) = vr zr + vi zi (part 0);  Im = vr zi - vi zr (part 1): the part is chosen OUTSIDE the MFMA chains (a branch per
-          // k-step makes the compiler copy the accumulators around)
-          double* dst = W1 + (size_t)part * wp + 256 * a + lane;
-          if (!CX) {
-            v4d acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fvr[ks], fzr[ks], acc, 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) dst[64 * j] = acc[j];
-          } else if (part == 0) {
-            v4d acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fvr[ks], fzr[ks], acc, 0, 0, 0);
-              acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(fvi[ks], fzi[ks], acc2, 0, 0, 0);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) dst[64 * j] = acc[j] + acc2[j];
-          } else {
-            v4d acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fvr[ks], fzi[ks], acc, 0, 0, 0);
-              acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(fvi[ks], fzr[ks], acc2, 0, 0, 0);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) dst[64 * j] = acc[j] - acc2[j];
-          }
+        for (int ks = 0; ks < KS1; ++ks) {
+          const int o = rl + wbase(16 * a + 4 * ks);
+          z1[ks] = ring[pl1 * ringp + o];
+          if (CX) z2[ks] = ring[pl2 * ringp + o];
         }
+        v4d acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) {
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(f1.re(ks), z1[ks], acc, 0, 0, 0);
+          if (CX) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(f1.im(ks), z2[ks], acc2, 0, 0, 0);
+        }
+        double* dst = W1 + part * wp + 256 * a + lane;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dst[64 * j] = CX ? acc[j] + sgn * acc2[j] : acc[j];
       }
+      if (more) fetch1(S_hi - ni, nu - ni);
+      if (stamp) stp[2] = wall_clock64();
+      chase::lds_barrier();  // B1: W1 is complete
       if (stamp) stp[3] = wall_clock64();
-      chase::lds_barrier();  // B2
-      // ---------------- W2 = T W1 (T upper triangular; its fragments are in registers) ----------------
+      // ---------------- Z -= (V T) W1 ----------------
       {
+        double w1[KS2], w2[KS2];
 #pragma unroll
-        for (int x = 0; x < TT; ++x) {
-          const int a = a_w + ASTEP_T * x;
-          if (a < B / 16) {  // uniform
-            const double* wa = W1 + lane;  // + 64 ks
-            double fwr[TKS], fwi[TKS];
-#pragma unroll
-            for (int ks = 0; ks < TKS; ++ks) {
-              fwr[ks] = wa[64 * ks];
-              if (CX) fwi[ks] = wa[wp + 64 * ks];
-            }
-            // T is zero below the diagonal, so the k-steps before 4 a contribute exact zeros: running them all keeps the chains branch-free
-            double ftr[TKS], fti[TKS];
-#pragma unroll
-            for (int ks = 0; ks < TKS; ++ks) q2_split(tf[x][ks], ftr[ks], fti[ks]);
-            double* dst = W2 + (size_t)part * wp + 256 * a + lane;
-            if (!CX) {
-              v4d acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-              for (int ks = 0; ks < TKS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ftr[ks], fwr[ks], acc, 0, 0, 0);
-#pragma unroll
-              for (int j = 0; j < 4; ++j) dst[64 * j] = acc[j];
-            } else if (part == 0) {  // Re = tr wr - ti wi
-              v4d acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-              for (int ks = 0; ks < TKS; ++ks) {
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ftr[ks], fwr[ks], acc, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(fti[ks], fwi[ks], acc2, 0, 0, 0);
-              }
-#pragma unroll
-              for (int j = 0; j < 4; ++j) dst[64 * j] = acc[j] - acc2[j];
-            } else {  // Im = tr wi + ti wr
-              v4d acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-              for (int ks = 0; ks < TKS; ++ks) {
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ftr[ks], fwi[ks], acc, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(fti[ks], fwr[ks], acc2, 0, 0, 0);
-              }
-#pragma unroll
-              for (int j = 0; j < 4; ++j) dst[64 * j] = acc[j] + acc2[j];
-            }
-          }
+        for (int ks = 0; ks < KS2; ++ks) {
+          w1[ks] = W1[pl1 * wp + 64 * ks + lane];
+          if (CX) w2[ks] = W1[pl2 * wp + 64 * ks + lane];
         }
-      }
-      // ---------------- Z -= V W2 ----------------
-      // The V operands of this product only depend on Vc, so they are fetched BEFORE the barrier that publishes W2 (the reads overlap the
-      // wait); tile order balancing the k-steps: real B = 64: (0,3) (1,2) (4,7) (5,6); complex B = 32: (0,1) (2,3).
-      constexpr int NTILE2 = 2 * B / 16;  // row tiles of the window
-      constexpr int NW2 = CX ? 2 : 4;     // waves sharing the tiles (per part)
-      constexpr int TPW = NTILE2 / NW2;   // tiles per wave
-      const int wsel = CX ? (wv >> 1) : wv;
-      int btile[TPW];
-      double gvr[TPW][TKS], gvi[TPW][TKS];
-#pragma unroll
-      for (int bi = 0; bi < TPW; ++bi) {
-        int b;
-        if (TPW == 2) {
-          if (NTILE2 == 8) {
-            const int h = wsel >> 1, w2 = wsel & 1;
-            b = 4 * h + (bi == 0 ? w2 : 3 - w2);
-          } else {
-            b = 2 * wsel + bi;
-          }
-        } else {
-          b = wsel + NW2 * bi;
-        }
-        btile[bi] = b;
-        const int tl = 16 * b + l15 - l4;               // t = tl - 4 ks
-        const double* va = Vc + (size_t)l4 * LDV + tl;  // + 4 ks (LDV - 1)
-#pragma unroll
-        for (int ks = 0; ks < TKS; ++ks) {
-          const int t = tl - 4 * ks;
-          const bool ok = t >= 0 && t < B;
-          const double xr = va[4 * ks * (LDV - 1)];
-          gvr[bi][ks] = ok ? xr : 0.0;
-          if (CX) {
-            const double xi = va[vp + 4 * ks * (LDV - 1)];
-            gvi[bi][ks] = ok ? xi : 0.0;
-          }
-        }
-      }
-      if (stamp) stp[4] = wall_clock64();
-      chase::lds_barrier();  // B3
-      {
 #pragma unroll
         for (int bi = 0; bi < TPW; ++bi) {
           const int b = btile[bi];
-          const double* wa = W2 + lane;  // + 64 ks
-          double fwr[TKS], fwi[TKS];
-          double (&fvr)[TKS] = gvr[bi];
-          double (&fvi)[TKS] = gvi[bi];
+          v4d acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-          for (int ks = 0; ks < TKS; ++ks) {
-            fwr[ks] = wa[64 * ks];
-            if (CX) fwi[ks] = wa[wp + 64 * ks];
+          for (int ks = 0; ks < KS2; ++ks) {
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(f2[bi].re(ks), w1[ks], acc, 0, 0, 0);
+            if (CX) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(f2[bi].im(ks), w2[ks], acc2, 0, 0, 0);
           }
-          const int ilo = 0, ihi = 0;
-          // k-steps outside [ilo / 4, ihi / 4] multiply structural zeros of V (the "ok" mask): all B / 4 are run, branch-free
-          (void)ilo;
-          (void)ihi;
-          v4d res;
-          if (!CX) {
-            v4d acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int ks = 0; ks < TKS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fvr[ks], fwr[ks], acc, 0, 0, 0);
-            res = acc;
-          } else if (part == 0) {  // Re = vr wr - vi wi
-            v4d acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int ks = 0; ks < TKS; ++ks) {
-              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fvr[ks], fwr[ks], acc, 0, 0, 0);
-              acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(fvi[ks], fwi[ks], acc2, 0, 0, 0);
-            }
-            res = acc - acc2;
-          } else {  // Im = vr wi + vi wr
-            v4d acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int ks = 0; ks < TKS; ++ks) {
-              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fvr[ks], fwi[ks], acc, 0, 0, 0);
-              acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(fvi[ks], fwr[ks], acc2, 0, 0, 0);
-            }
-            res = acc + acc2;
-          }
-          double* dst = ring + (size_t)part * ringp + lane;
+          double* dst = ring + part * ringp + rl;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const size_t o = (size_t)wbase(16 * b + 4 * j) * NC;
-            dst[o] = dst[o] - res[j];
+            const int o = wbase(16 * b + 4 * j);
+            dst[o] = dst[o] - (CX ? acc[j] + sgn * acc2[j] : acc[j]);
           }
         }
       }
-      if (stamp) stp[5] = wall_clock64();
+      if (more) fetch2(S_hi - ni, nu - ni);
+      if (stamp) stp[4] = wall_clock64();
       ++nblk_done;
       cu = nu;
       ci = ni;
       have = more;
     }
     __syncthreads();
-    for (int tb = lo; tb <= hi; ++tb) store_blockrow(tb);
-    __syncthreads();
+    for (int tb = lo; tb <= hi; ++tb) store_row(tb);
   }
 }
 

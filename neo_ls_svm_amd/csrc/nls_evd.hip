@@ -277,7 +277,7 @@ static int sy2sb(nls_ctx* ctx, T* A, int n, long lda, T* tau1, int* dflag, int* 
     hipLaunchKernelGGL((k_sb_hemm_reduce<T, B>), dim3(nrb), dim3(256), lds_reduce, st, Wp, split, mh, kb, Zb, Wb, (long)n, Mp);
     hipLaunchKernelGGL((k_sb_reduce<T>), red_grid, dim3(256), 0, st, Mp, nrb, B * B, ps->G);
     hipLaunchKernelGGL((k_sb_x<T, B>), dim3(nrb), dim3(256), lds_x, st, Wb, Yb, (long)n, mh, kb, ps);
-    hipLaunchKernelGGL((k_sb_her2k<T>), dim3(NT * (NT + 1) / 2), dim3(256), 0, st, A22, lda, mh, Wb, Yb, (long)n, kb);
+    hipLaunchKernelGGL((k_sb_her2k<T, B>), dim3(NT * (NT + 1) / 2), dim3(256), 0, st, A22, lda, mh, Wb, Yb, (long)n, kb);
     HIPCHK(ctx, hipGetLastError());
     j += kb;
   }

@@ -538,81 +538,110 @@ __global__ void __launch_bounds__(256, 1) k_sb_finish(T* Yb, long ldy, int m, in
 // Row block I (64 rows) of the result needs the tiles A[I][J] (J < I), the Hermitian diagonal tile and A[K][I]^H (K > I): NT = mh / 64
 // tiles in all, every row block the same number - the lower triangle is read twice per product, all workgroups do equal work.  The
 // tiles of a row block are dealt round-robin to SPLIT workgroups (blockIdx.y) whose partial results k_sb_hemm_reduce adds in a fixed order.
-constexpr int HT = 64;   // tile edge
-constexpr int HK = 16;   // K slice held in LDS
+// On v_mfma_f64_16x16x4_f64 without LDS and without barriers: wave w of a workgroup owns rows 16 w .. 16 w + 15 of the row block and all B
+// columns; both operands go from global memory straight into the fragment registers.  The k index of an MFMA step is free as long as both
+// operands agree, so a lane takes FOUR consecutive k (k = 16 q + 4 (lane / 16) + e, e = 0 .. 3): the Z operand and the conjugate-transposed
+// tiles (k runs down a stored column) are then one 32-byte (complex: 64-byte) run per lane and whole 128-byte lines per 16 lanes; the tiles
+// left of the diagonal (k runs along a stored row) are four 8-byte loads, each contiguous over the 16 lanes.  One (tile, q) slice is in
+// flight while the previous one multiplies.
+constexpr int HT = 64;  // tile edge
+typedef double hv4d __attribute__((ext_vector_type(4)));
+
+// fragment of one (tile, q) slice: A operand a[e], Z operand z[jt][e]
 template <class T, int B>
-__global__ void __launch_bounds__(256) k_sb_hemm(const T* A, long lda, int mh, const T* Zb, long ldz, int kb, int split, T* Wp) {
-  constexpr int TC = B / 16;  // columns per thread (thread = 4 rows x TC columns)
-  __shared__ T As[HK][HT + 1], Zs[HK][B + 1];
-  const int I = blockIdx.x, part = blockIdx.y;
-  const int NT = (mh + HT - 1) / HT;
-  const int ty = threadIdx.x / 16, tx = threadIdx.x % 16;
-  T acc[4][TC];
+struct HemmSlice {
+  T a[4], z[B / 16][4];
+};
+// FULL: the tile and the row block lie inside the matrix (no bounds tests)
+template <class T, int B, bool FULL>
+__device__ __forceinline__ void hemm_load(HemmSlice<T, B>& f, const T* A, long lda, int mh, const T* Zb, long ldz, int I, int t, int q, int w, int lane) {
+  const int x = lane & 15, kk = lane >> 4;
+  const long r = (long)I * HT + 16 * w + x;     // row of the result this lane feeds (A operand: i = x)
+  const long k0 = (long)t * HT + 16 * q + 4 * kk;  // first of this lane's four k
 #pragma unroll
-  for (int x = 0; x < 4; ++x)
-#pragma unroll
-    for (int y = 0; y < TC; ++y) acc[x][y] = zero_<T>();
-  for (int t = part; t < NT; t += split) {
-    // tile t of the cross of row block I: t < I: A[I][t];  t == I: diagonal;  t > I: A[t][I]^H
-    const bool trans = t > I;
-    const long trow = (long)(trans ? t : I) * HT, tcol = (long)(trans ? I : t) * HT;  // stored tile: rows trow.., cols tcol..
-    for (int k0 = 0; k0 < HT; k0 += HK) {
-      __syncthreads();
-      // As[k][r] = Atile_effective[r][k0 + k]:  effective = stored tile (t < I), its conjugate transpose (t > I), Hermitian fill (t == I)
-      for (int idx = threadIdx.x; idx < HK * HT; idx += 256) {
-        int r, k;
-        T v;
-        if (!trans) {
-          r = idx % HT;
-          k = idx / HT;  // coalesced along the rows of a stored column
-          const long gr = trow + r, gc = tcol + k0 + k;
-          if (gr < mh && gc < mh) {
-            if (t == I && gc > gr)
-              v = conj_(A[gc + gr * lda]);  // upper part of the diagonal tile from its mirror
-            else
-              v = A[gr + gc * lda];
-            if (t == I && gc == gr) v = make_<T>(real_(v), 0.0);
-          } else {
-            v = zero_<T>();
-          }
-        } else {
-          k = idx % HK;
-          r = idx / HK;  // effective[r][k0 + k] = conj(stored[k0 + k][r]): coalesced along stored rows k0.. of column r
-          const long gr = trow + k0 + k, gc = tcol + r;
-          v = (gr < mh && gc < mh) ? conj_(A[gr + gc * lda]) : zero_<T>();
-        }
-        As[k][r] = v;
-      }
-      // Zs[k][c] = Z[(column block of the effective tile) * 64 + k0 + k][c]
-      {
-        const long zr0 = (long)t * HT + k0;
-        for (int idx = threadIdx.x; idx < HK * B; idx += 256) {
-          const int k = idx % HK, c = idx / HK;
-          Zs[k][c] = (zr0 + k < mh && c < kb) ? Zb[(zr0 + k) + (long)c * ldz] : zero_<T>();
-        }
-      }
-      __syncthreads();
-#pragma unroll 4
-      for (int k = 0; k < HK; ++k) {
-        T a[4], z[TC];
-#pragma unroll
-        for (int x = 0; x < 4; ++x) a[x] = As[k][4 * ty + x];
-#pragma unroll
-        for (int y = 0; y < TC; ++y) z[y] = Zs[k][tx + 16 * y];
-#pragma unroll
-        for (int x = 0; x < 4; ++x)
-#pragma unroll
-          for (int y = 0; y < TC; ++y) acc[x][y] = acc[x][y] + a[x] * z[y];
+  for (int e = 0; e < 4; ++e) {
+    const long k = k0 + e;
+    T v = zero_<T>();
+    if (FULL || (r < mh && k < mh)) {
+      if (t < I) {
+        v = A[r + k * lda];
+      } else if (t > I) {
+        v = conj_(A[k + r * lda]);
+      } else {  // diagonal tile: the stored half, mirrored
+        v = r >= k ? A[r + k * lda] : conj_(A[k + r * lda]);
+        if (r == k) v = make_<T>(real_(v), 0.0);
       }
     }
+    f.a[e] = v;
   }
+#pragma unroll
+  for (int jt = 0; jt < B / 16; ++jt) {
+    const T* zp = Zb + k0 + (long)(16 * jt + x) * ldz;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) f.z[jt][e] = (FULL || k0 + e < mh) ? zp[e] : zero_<T>();
+  }
+}
+template <int B>
+__device__ __forceinline__ void hemm_mac(hv4d (&acc)[2][B / 16], const HemmSlice<double, B>& f) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int jt = 0; jt < B / 16; ++jt) acc[0][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a[e], f.z[jt][e], acc[0][jt], 0, 0, 0);
+}
+template <int B>
+__device__ __forceinline__ void hemm_mac(hv4d (&acc)[2][B / 16], const HemmSlice<Z, B>& f) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const double ar = f.a[e].re, ai = f.a[e].im, nai = -ai;
+#pragma unroll
+    for (int jt = 0; jt < B / 16; ++jt) {
+      acc[0][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, f.z[jt][e].re, acc[0][jt], 0, 0, 0);
+      acc[0][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(nai, f.z[jt][e].im, acc[0][jt], 0, 0, 0);
+      acc[1][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, f.z[jt][e].im, acc[1][jt], 0, 0, 0);
+      acc[1][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, f.z[jt][e].re, acc[1][jt], 0, 0, 0);
+    }
+  }
+}
+// bounds tests only for the tiles that touch the end of the matrix (uniform choice)
+template <class T, int B>
+__device__ __forceinline__ void hemm_load_any(HemmSlice<T, B>& f, const T* A, long lda, int mh, const T* Zb, long ldz, int I, int t, int q, int w, int lane) {
+  if ((long)(max(I, t) + 1) * HT <= mh)
+    hemm_load<T, B, true>(f, A, lda, mh, Zb, ldz, I, t, q, w, lane);
+  else
+    hemm_load<T, B, false>(f, A, lda, mh, Zb, ldz, I, t, q, w, lane);
+}
+template <class T, int B>
+__global__ void __launch_bounds__(256) k_sb_hemm(const T* A, long lda, int mh, const T* Zb, long ldz, int kb, int split, T* Wp) {
+  constexpr bool CX = sizeof(T) == 16;
+  const int I = blockIdx.x, part = blockIdx.y;
+  const int NT = (mh + HT - 1) / HT;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  hv4d acc[2][B / 16];
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int jt = 0; jt < B / 16; ++jt) acc[p][jt] = hv4d{0.0, 0.0, 0.0, 0.0};
+  const int nmine = part < NT ? (NT - 1 - part) / split + 1 : 0;  // tiles part, part + split, ...
+  const int items = 4 * nmine;                                     // (tile, q) slices: an even number
+  if (items > 0) {
+    HemmSlice<T, B> f0, f1;
+    hemm_load_any<T, B>(f0, A, lda, mh, Zb, ldz, I, part, 0, w, lane);
+    for (int it = 0; it < items; it += 2) {
+      hemm_load_any<T, B>(f1, A, lda, mh, Zb, ldz, I, part + split * ((it + 1) >> 2), (it + 1) & 3, w, lane);
+      hemm_mac<B>(acc, f0);
+      if (it + 2 < items) hemm_load_any<T, B>(f0, A, lda, mh, Zb, ldz, I, part + split * ((it + 2) >> 2), (it + 2) & 3, w, lane);
+      hemm_mac<B>(acc, f1);
+    }
+  }
+  // D[i][j]: lane = 16 (i % 4) + j, reg = i / 4
   T* out = Wp + ((long)part * mh) * B;  // partial p: [mh][B] row-major
 #pragma unroll
-  for (int x = 0; x < 4; ++x) {
-    const long gr = (long)I * HT + 4 * ty + x;
+  for (int reg = 0; reg < 4; ++reg) {
+    const long gr = (long)I * HT + 16 * w + 4 * reg + (lane >> 4);
     if (gr < mh) {
 #pragma unroll
-      for (int y = 0; y < TC; ++y) out[gr * B + tx + 16 * y] = acc[x][y];
+      for (int jt = 0; jt < B / 16; ++jt) out[gr * B + 16 * jt + (lane & 15)] = make_<T>(acc[0][jt][reg], CX ? acc[1][jt][reg] : 0.0);
     }
   }
 }
@@ -709,63 +738,86 @@ __global__ void __launch_bounds__(256) k_sb_x(T* Wb, const T* Yb, long ld, int m
   }
 }
 
-// A22 -= X Y^H + Y X^H on the lower triangle (64 x 64 tiles R >= C; 4 x 4 register blocks; the structure of k_trd_rank2k with both
-// operand panels in buffers)
-template <class T>
+// A22 -= X Y^H + Y X^H on the lower triangle, 64 x 64 tiles R >= C, on v_mfma_f64_16x16x4_f64 without LDS.  The product is formed
+// TRANSPOSED, D[i][j] = update of A[r0 + 16 jt + j][c0 + 16 w + i] (wave w = 16 columns of the tile, jt = 0 .. 3), so that the 16 lanes of
+// an accumulator register are 16 consecutive rows of one stored column: the read-modify-write of A moves whole 128-byte lines.
+// A operand (i = column of the tile): conj(Y[c][k]), then conj(X[c][k]);  B operand (j = row): X[r][k], then Y[r][k];
+// the panel columns beyond kb (last, narrow panel) are masked.  Both panels are small (2 m B elements, cache resident) and are read by the
+// fragment layout directly: 16 lanes = 16 consecutive rows of one panel column.
+template <class T, int B, bool FULL>
+__device__ __forceinline__ void her2k_tile(T* A, long lda, int mh, const T* Xb, const T* Yb, long ld, int kb, long r0, long c0, bool diag, int w, int lane) {
+  constexpr bool CX = sizeof(T) == 16;
+  constexpr int KS = B / 4;
+  const int x = lane & 15, kk = lane >> 4;
+  const long c = c0 + 16 * w + x;  // A operand: column c of the tile
+  hv4d acc[2][4];
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) acc[p][jt] = hv4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const T* Pa = half == 0 ? Yb : Xb;  // column side
+    const T* Pb = half == 0 ? Xb : Yb;  // row side
+    T a[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int k = 4 * ks + kk;
+      a[ks] = (k < kb && (FULL || c < mh)) ? conj_(Pa[c + (long)k * ld]) : zero_<T>();
+    }
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+      const long r = r0 + 16 * jt + x;
+      T b[KS];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int k = 4 * ks + kk;
+        b[ks] = (k < kb && (FULL || r < mh)) ? Pb[r + (long)k * ld] : zero_<T>();
+      }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        if constexpr (!CX) {
+          acc[0][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks], acc[0][jt], 0, 0, 0);
+        } else {
+          const double ar = a[ks].re, ai = a[ks].im, nai = -ai;
+          acc[0][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, b[ks].re, acc[0][jt], 0, 0, 0);
+          acc[0][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(nai, b[ks].im, acc[0][jt], 0, 0, 0);
+          acc[1][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, b[ks].im, acc[1][jt], 0, 0, 0);
+          acc[1][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, b[ks].re, acc[1][jt], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // D[i][j]: lane = 16 (i % 4) + j, reg = i / 4:  column c0 + 16 w + 4 reg + lane / 16, row r0 + 16 jt + lane % 16
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    const long cc = c0 + 16 * w + 4 * reg + kk;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+      const long r = r0 + 16 * jt + x;
+      if ((FULL || (r < mh && cc < mh)) && (!diag || r >= cc)) {
+        // result element (r, cc) = conj-free: D holds sum_k conj(P[cc][k]) Q[r][k] = (X Y^H + Y X^H)[r][cc]
+        T v = A[r + cc * lda] - make_<T>(acc[0][jt][reg], CX ? acc[1][jt][reg] : 0.0);
+        if (r == cc) v = make_<T>(real_(v), 0.0);
+        A[r + cc * lda] = v;
+      }
+    }
+  }
+}
+template <class T, int B>
 __global__ void __launch_bounds__(256) k_sb_her2k(T* A, long lda, int mh, const T* Xb, const T* Yb, long ld, int kb) {
-  constexpr int UT = 64, UK = 16;
-  __shared__ T Xr[UK][UT], Yr[UK][UT], Xc[UK][UT], Yc[UK][UT];
+  constexpr int UT = 64;
   int t = blockIdx.x, R = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
   while ((R + 1) * (R + 2) / 2 <= t) ++R;
   while (R * (R + 1) / 2 > t) --R;
   const int C = t - R * (R + 1) / 2;
-  const int tx = threadIdx.x % 16, ty = threadIdx.x / 16;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const long r0 = (long)R * UT, c0 = (long)C * UT;
-  T acc[4][4];
-#pragma unroll
-  for (int x = 0; x < 4; ++x)
-#pragma unroll
-    for (int y = 0; y < 4; ++y) acc[x][y] = make_<T>(0.0, 0.0);
-  for (int k0 = 0; k0 < kb; k0 += UK) {
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < UK * UT / 256; ++it) {
-      const int row = threadIdx.x % UT, k = threadIdx.x / UT + (256 / UT) * it;
-      const bool kin = k0 + k < kb;
-      const long rr = r0 + row, cc = c0 + row;
-      Xr[k][row] = kin && rr < mh ? Xb[rr + (long)(k0 + k) * ld] : make_<T>(0.0, 0.0);
-      Yr[k][row] = kin && rr < mh ? Yb[rr + (long)(k0 + k) * ld] : make_<T>(0.0, 0.0);
-      Xc[k][row] = kin && cc < mh ? conj_(Xb[cc + (long)(k0 + k) * ld]) : make_<T>(0.0, 0.0);
-      Yc[k][row] = kin && cc < mh ? conj_(Yb[cc + (long)(k0 + k) * ld]) : make_<T>(0.0, 0.0);
-    }
-    __syncthreads();
-#pragma unroll 4
-    for (int k = 0; k < UK; ++k) {
-      T xr[4], yr[4], xc[4], yc[4];
-#pragma unroll
-      for (int x = 0; x < 4; ++x) {
-        xr[x] = Xr[k][tx + 16 * x];
-        yr[x] = Yr[k][tx + 16 * x];
-        xc[x] = Xc[k][ty + 16 * x];
-        yc[x] = Yc[k][ty + 16 * x];
-      }
-#pragma unroll
-      for (int x = 0; x < 4; ++x)
-#pragma unroll
-        for (int y = 0; y < 4; ++y) acc[x][y] = acc[x][y] + xr[x] * yc[y] + yr[x] * xc[y];
-    }
-  }
-#pragma unroll
-  for (int y = 0; y < 4; ++y)
-#pragma unroll
-    for (int x = 0; x < 4; ++x) {
-      const long r = r0 + tx + 16 * x, c = c0 + ty + 16 * y;
-      if (r < mh && c < mh && r >= c) {
-        T v = A[r + c * lda] - acc[x][y];
-        if (r == c) v = make_<T>(real_(v), 0.0);
-        A[r + c * lda] = v;
-      }
-    }
+  if (r0 + UT <= mh)  // c0 <= r0
+    her2k_tile<T, B, true>(A, lda, mh, Xb, Yb, ld, kb, r0, c0, R == C, w, lane);
+  else
+    her2k_tile<T, B, false>(A, lda, mh, Xb, Yb, ld, kb, r0, c0, R == C, w, lane);
 }
 
 // ---- dense (lower, bandwidth B) -> band storage AB[(i - j) + j * ldab], rows 0 .. 2B (the rows beyond B: room for the bulges, zero) ----

@@ -64,7 +64,10 @@ struct Q2P {
   __host__ __device__ static size_t pos(int tile, int KS, int ks, int lane) {
     return CX ? ((size_t)tile * KS + ks) * 64 + lane : (((size_t)tile * (KS / 2) + ks / 2) * 64 + lane) * 2 + (ks & 1);
   }
-  static size_t lds_bytes(int G) { return sizeof(double) * ((size_t)NP * 16 * ((size_t)2 * G * B + 4) + (size_t)NP * B * 16); }
+  // Real blocks of 32 hold too little work for four waves (2 + 4 tiles): the waves form two teams that take two blocks of the same step
+  // - they lie two block rows apart, hence independent - side by side, each with its own W1.
+  static constexpr int TEAMS = (!CX && B == 32) ? 2 : 1;
+  static size_t lds_bytes(int G) { return sizeof(double) * ((size_t)NP * 16 * ((size_t)2 * G * B + 4) + (size_t)TEAMS * NP * B * 16); }
 };
 
 // T factor of every block: Tb[block][i + B j] (upper triangular, zeros below; Tb == nullptr: not stored) and the packed operands P
@@ -286,8 +289,9 @@ __global__ void __launch_bounds__(256) k_q2_apply(const T* V2, long ldv, int n, 
 // requested as soon as the current ones have been consumed, so they travel while the other product runs.  LDS holds only the ring (real
 // planes, column-major with a leading dimension = 4 mod 32 doubles: operand reads, accumulator updates and the row transfers are all
 // conflict-free) and W1 - 48 to 80 KB, two workgroups per CU, which is what hides the barriers and the LDS latency of each other.
-// Waves: real: wave = tile set; complex: wave = (tile set, real / imaginary part of the result).  The roles rotate with the workgroup
-// index so that co-resident workgroups put their heavier waves on different SIMDs.
+// Waves: real: wave = tile set; complex: wave = (tile set, real / imaginary part of the result); real blocks of 32: two teams of two
+// waves, two independent blocks of a step at a time.  The roles rotate with the workgroup index so that co-resident workgroups put
+// their heavier waves on different SIMDs.
 // ================================================================================================================
 __device__ __forceinline__ void q2_split(double x, double& re, double& im) {
   re = x;
@@ -329,20 +333,22 @@ __global__ void __launch_bounds__(256, 2) k_q2_apply_packed(const T* __restrict_
   using L = Q2P<T, B>;
   constexpr bool CX = L::CX;
   constexpr int NP = L::NP, KS1 = L::KS1, KS2 = L::KS2, NT1 = L::NT1, NT2 = L::NT2;
-  constexpr int NW = CX ? 2 : 4;  // waves per part of the result
-  constexpr int TPW = NT2 / NW;   // window tiles per wave
+  constexpr int TEAMS = L::TEAMS, WT = 4 / TEAMS;  // teams of WT waves, one block per team at a time
+  constexpr int NW = CX ? WT / 2 : WT;             // waves per part of the result
+  constexpr int TPW = NT2 / NW;                    // window tiles per wave
   static_assert(NT1 <= NW && (TPW == 1 || TPW == 2), "tile distribution");
   extern __shared__ __attribute__((aligned(16))) unsigned char q2_smem[];
   const int R = 2 * G, LDR = R * B + 4;
   double* ring = reinterpret_cast<double*>(q2_smem);  // [NP][16][LDR]: ring[c LDR + slot B + r]
-  double* W1 = ring + (size_t)NP * 16 * LDR;          // [NP][B][16]
   const int ringp = 16 * LDR, wp = B * 16;
   const long c0 = (long)blockIdx.x * 16;
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int l15 = lane & 15, l4 = lane >> 4;
-  const int role = (wv + (int)(blockIdx.x >> 8)) & 3;
+  const int team = wv / WT;
+  const int role = (wv % WT + (int)(blockIdx.x >> 8)) % WT;
   const int wsel = CX ? role >> 1 : role, part = CX ? role & 1 : 0;
+  double* W1 = ring + (size_t)NP * 16 * LDR + (size_t)team * NP * wp;  // [NP][B][16], one per team
   const int rl = l15 * LDR + l4;  // this lane's element of a 4-row x 16-column operand / accumulator slice: + first row
   // complex products (ar + i ai)(br + i bi): part 0 sums ar br and ai bi (result: difference), part 1 sums ar bi and ai br (result: sum);
   // which plane feeds which chain is a matter of addresses, decided once
@@ -417,11 +423,29 @@ __global__ void __launch_bounds__(256, 2) k_q2_apply_packed(const T* __restrict_
         if (k >= 0 && k < q2_nblocks(n, B, S_hi - i)) return true;
       }
     };
-    int cu = 0, ci = -1;
-    bool have = next_active(cu, ci);
-    if (have) {
-      fetch1(S_hi - ci, cu - ci);
-      fetch2(S_hi - ci, cu - ci);
+    // one iteration = the next active block (team 0) and, with two teams, the following active block if it belongs to the SAME step (-1: none)
+    auto next_iter = [&](int& u, int& i, int& i0, int& i1) -> bool {
+      if (!next_active(u, i)) return false;
+      i0 = i;
+      i1 = -1;
+      if (TEAMS == 2) {
+        int u2 = u, i2 = i;
+        if (next_active(u2, i2) && u2 == u) {
+          i1 = i2;
+          i = i2;
+        }
+      }
+      return true;
+    };
+    static_assert(TEAMS <= 2, "next_iter hands out at most two blocks");
+    int cu = 0, ci = -1, ci0 = -1, ci1 = -1;
+    bool have = next_iter(cu, ci, ci0, ci1);
+    {
+      const int mine = team == 0 ? ci0 : ci1;
+      if (have && mine >= 0) {
+        fetch1(S_hi - mine, cu - mine);
+        fetch2(S_hi - mine, cu - mine);
+      }
     }
     // the ring starts with the block rows S_hi - gcount + 1 .. S_hi + 1 (what step 0 and the joining groups need) and slides by one per step
     int lo = S_hi - gcount + 1, hi = lo - 1;
@@ -434,12 +458,13 @@ __global__ void __launch_bounds__(256, 2) k_q2_apply_packed(const T* __restrict_
     fetch_row(hi + 1);
     int pre_tb = hi + 1;
     while (have) {
-      const int u = cu, i = ci;
+      const int u = cu, i = team == 0 ? ci0 : ci1;
+      const bool active = i >= 0;
       const int S = S_hi - i, k = u - i, tb = S + k;
       const bool stamp = stamps != nullptr && blockIdx.x == 0 && threadIdx.x == 0 && nblk_done >= 200 && nblk_done < 208;
       long long* stp = stamps + (nblk_done - 200) * 8;
       if (stamp) stp[0] = wall_clock64();
-      chase::lds_barrier();  // B0: the previous block's update of the ring and its reads of W1 are complete
+      chase::lds_barrier();  // B0: the previous blocks' updates of the ring and their reads of W1 are complete
       if (hi < S_hi + u + 1) {
         while (hi < S_hi + u + 1) {
           if (hi + 1 - lo >= R) {
@@ -455,14 +480,16 @@ __global__ void __launch_bounds__(256, 2) k_q2_apply_packed(const T* __restrict_
         pre_tb = hi + 1;
         chase::lds_barrier();
       }
-      int nu = cu, ni = ci;
-      const bool more = next_active(nu, ni);
+      int nu = cu, ni = ci, ni0 = -1, ni1 = -1;
+      const bool more = next_iter(nu, ni, ni0, ni1);
+      const int nmine = team == 0 ? ni0 : ni1;
+      const bool more_mine = more && nmine >= 0;
       if (stamp) stp[1] = wall_clock64();
       const int base0 = (tb % R) * B, base1 = ((tb + 1) % R) * B;
       // first ring row of the 4-row slice that starts at window row rho0 (a multiple of 4, wave-uniform)
       auto wbase = [&](int rho0) -> int { return rho0 < B ? base0 + rho0 : base1 + rho0 - B; };
       // ---------------- W1 = V^H Z ----------------
-      if (wsel < NT1) {
+      if (active && wsel < NT1) {
         const int a = wsel;
         double z1[KS1], z2[KS1];
 #pragma unroll
@@ -481,12 +508,12 @@ __global__ void __launch_bounds__(256, 2) k_q2_apply_packed(const T* __restrict_
 #pragma unroll
         for (int j = 0; j < 4; ++j) dst[64 * j] = CX ? acc[j] + sgn * acc2[j] : acc[j];
       }
-      if (more) fetch1(S_hi - ni, nu - ni);
+      if (more_mine) fetch1(S_hi - nmine, nu - nmine);
       if (stamp) stp[2] = wall_clock64();
       chase::lds_barrier();  // B1: W1 is complete
       if (stamp) stp[3] = wall_clock64();
       // ---------------- Z -= (V T) W1 ----------------
-      {
+      if (active) {
         double w1[KS2], w2[KS2];
 #pragma unroll
         for (int ks = 0; ks < KS2; ++ks) {
@@ -510,11 +537,13 @@ __global__ void __launch_bounds__(256, 2) k_q2_apply_packed(const T* __restrict_
           }
         }
       }
-      if (more) fetch2(S_hi - ni, nu - ni);
+      if (more_mine) fetch2(S_hi - nmine, nu - nmine);
       if (stamp) stp[4] = wall_clock64();
       ++nblk_done;
       cu = nu;
       ci = ni;
+      ci0 = ni0;
+      ci1 = ni1;
       have = more;
     }
     __syncthreads();

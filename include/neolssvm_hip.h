@@ -144,10 +144,13 @@ int nls_eigh_only(nls_ctx* ctx, void* A, int n, int is_complex, double* lam);
  *            (a panel that could not be orthogonalised: the library then falls back to the one-stage panel), columns reduced};
  *   stage 2: the band held in A's bw sub-diagonals -> d[n], e[n-1]; aux = the chase reflectors V2 (n x n); info[0] != 0: time-out;
  *   stage 3: aux (n x ncols, column-major) <- Q2 aux with the chase reflectors V2 handed in as A.
- * nls_twostage_fallbacks: eigendecompositions of this context that fell back from the two-stage to the one-stage reduction. */
+ * nls_twostage_rescues: eigendecompositions of this context whose band reduction met a panel it could not orthogonalise (columns dependent to
+ * working precision) and went through at the second attempt, every panel perturbed by 1e-13 of its norm (csrc/nls_sb.h, k_sb_perturb);
+ * nls_twostage_fallbacks: those that failed again (zero panels) and fell back from the two-stage to the one-stage reduction. */
 int nls_twostage_stage(nls_ctx* ctx, int stage, void* A, int n, int is_complex, int bw, void* aux, double* d, double* e, int ncols,
                        int* info);
 long nls_twostage_fallbacks(const nls_ctx* ctx);
+long nls_twostage_rescues(const nls_ctx* ctx);
 
 /* ---- primal fit ------------------------------------------------------------------------------- */
 typedef struct nls_primal_fit_args {

@@ -202,7 +202,7 @@ template <class T>
 struct TwoStageBw;  // default band width per arithmetic
 template <>
 struct TwoStageBw<double> {
-  static constexpr int B = 64;
+  static constexpr int B = 32;  // n = 10^4: 478 ms against 590 with 64 (the chase's critical path is 2 n stages whose time grows with the band width)
 };
 template <>
 struct TwoStageBw<trd::Z> {
@@ -221,7 +221,7 @@ static int sb_lds_optin(nls_ctx* ctx, F f, size_t bytes, const char* name) {
 // Stage 1.  A: n x n column-major (lda), lower triangle in; out: band in the B sub-diagonals, block reflectors below it, tau1[n].
 // flag (device int): raised when a panel could not be orthogonalised (see nls_sb.h); the caller falls back.
 template <class T, int B>
-static int sy2sb(nls_ctx* ctx, T* A, int n, long lda, T* tau1, int* dflag, int* ncols_reduced) {
+static int sy2sb(nls_ctx* ctx, T* A, int n, long lda, T* tau1, int* dflag, int* ncols_reduced, bool perturb = false) {
   using namespace sb;
   *ncols_reduced = 0;
   HIPCHK(ctx, hipMemsetAsync(tau1, 0, sizeof(T) * (size_t)n, ctx->stream));
@@ -261,6 +261,11 @@ static int sy2sb(nls_ctx* ctx, T* A, int n, long lda, T* tau1, int* dflag, int* 
     const int nch = (m + RW - 1) / RW;
     hipLaunchKernelGGL((k_sb_gram<T, B>), dim3(nch), dim3(256), 0, st, P, lda, m, kb, Gp);
     hipLaunchKernelGGL((k_sb_reduce<T>), red_grid, dim3(256), 0, st, Gp, nch, B * B, ps->G);
+    if (perturb) {  // second attempt after a degenerate panel (nls_sb.h, k_sb_perturb)
+      hipLaunchKernelGGL((k_sb_perturb<T>), dim3((unsigned)(((long)m * kb + 255) / 256)), dim3(256), 0, st, P, lda, m, kb, ps->G, B, (unsigned)j);
+      hipLaunchKernelGGL((k_sb_gram<T, B>), dim3(nch), dim3(256), 0, st, P, lda, m, kb, Gp);
+      hipLaunchKernelGGL((k_sb_reduce<T>), red_grid, dim3(256), 0, st, Gp, nch, B * B, ps->G);
+    }
     hipLaunchKernelGGL((k_sb_small_chol<T, B>), dim3(1), dim3(256), lds_chol, st, kb, m, 0, ps, dflag);
     hipLaunchKernelGGL((k_sb_apply<T, B>), dim3(nch), dim3(256), lds_apply, st, P, lda, m, kb, ps, Yb + zh, (long)n, Gp);
     hipLaunchKernelGGL((k_sb_reduce<T>), red_grid, dim3(256), 0, st, Gp, nch, B * B, ps->G);
@@ -363,8 +368,10 @@ static int apply_q2(nls_ctx* ctx, const T* V2, int n, T* C, long ldc, int ncols)
   if (!valu) {
     if constexpr (L::AVAILABLE) {
       // more slabs than CUs: two workgroups per CU (half the LDS each) cover each other's barriers and operand latencies
+      // (three for real blocks of 32, whose kernel is light enough in registers: 84 VGPRs)
       const unsigned nwg = (unsigned)((ncols + 15) / 16);
-      const size_t budget = nwg > (unsigned)ctx->cus ? ((size_t)80 << 10) : ((size_t)158 << 10);
+      const unsigned per_cu = std::min<unsigned>((nwg + ctx->cus - 1) / ctx->cus, (sizeof(T) == 8 && B == 32) ? 3u : 2u);
+      const size_t budget = per_cu >= 3 ? ((size_t)53 << 10) : per_cu == 2 ? ((size_t)80 << 10) : ((size_t)158 << 10);
       while (G > 1 && L::lds_bytes(G) > budget) --G;
       G = std::min(G, ngroups);
       NLSCHK(sb_lds_optin(ctx, k_q2_apply_packed<T, B>, L::lds_bytes(G), "k_q2_apply_packed"));
@@ -414,16 +421,18 @@ static int evd_bw(bool cplx) {
   return TwoStageBw<double>::B;
 }
 
-// When to take the two-stage reduction.  Measured on MI355X in round 3 (profiles/r03_evd_twostage.md) it is correct at every size but
-// not yet faster than the one-stage panel on ONE GPU (complex n = 4097: 224 vs 143 ms; real n = 1e4: 731 vs 587 ms; complex n = 1025: 29 vs
-// 18.5 ms), so the default stays one-stage; NLS_EVD=twostage forces it (n >= 4), NLS_TWOSTAGE_MIN = n gives a size rule.
+// When to take the two-stage reduction.  Measured on MI355X in round 3 (profiles/r03_evd_stages.log):
+//   real:    n = 4000: 139 against 128 ms one-stage, n = 5000: 135 against ~150, n = 6500: ~200 against ~250, n = 8000: 281 against 330, n = 10^4: 478 against 587
+//            -> two-stage from n = 6000 (the one-stage panel streams the trailing matrix from HBM once per column as soon as its lower
+//            triangle outgrows the 256 MB Infinity Cache);
+//   complex: n = 4097: 171 against 143, n = 1025: 27 against 18.5 -> one-stage.
+// NLS_EVD=twostage forces it (n >= 4), NLS_EVD=onestage forbids it, NLS_TWOSTAGE_MIN = n moves the size rule (both arithmetics).
 static bool evd_use_two_stage(int n, bool cplx) {
-  (void)cplx;
   const char* m = std::getenv("NLS_EVD");
   if (m && std::string(m) == "twostage") return n >= 4;
   if (m && std::string(m) == "onestage") return false;
   if (const char* e = std::getenv("NLS_TWOSTAGE_MIN")) return n >= std::max(4, std::atoi(e));
-  return false;
+  return !cplx && n >= 6000;
 }
 
 static bool evd_rocsolver_backtransform() {  // NLS_EVD_UNMTR=rocsolver: zunmtr / dormtr instead of apply_q_blocked (diagnostic)
@@ -549,19 +558,26 @@ static int evd_two_stage(nls_ctx* ctx, T* A, int n, double* lam, double* e_work,
     }
   };
   mark(0);
-  NLSCHK((sy2sb<T, B>(ctx, A, n, n, tau1, dflag, &nred)));
-  mark(1);
-  NLSCHK((sb2st<T, B>(ctx, A, n, n, lam, e_work, V2, &ctl)));
-  mark(2);
-  int hflag = 0;
+  // A panel whose columns are dependent to working precision raises the flag (nls_sb.h).  Second attempt: the saved copy again, every
+  // panel perturbed by 1e-13 of its norm (k_sb_perturb); if that fails too (zero panels: a diagonal matrix) the one-stage panel takes over.
   unsigned hctl[2] = {0, 0};
-  HIPCHK(ctx, hipMemcpyAsync(&hflag, dflag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipMemcpyAsync(hctl, ctl, sizeof(hctl), hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  if (hflag != 0) {
+  for (int attempt = 0;; ++attempt) {
+    NLSCHK((sy2sb<T, B>(ctx, A, n, n, tau1, dflag, &nred, attempt == 1)));
+    if (attempt == 0) mark(1);
+    NLSCHK((sb2st<T, B>(ctx, A, n, n, lam, e_work, V2, &ctl)));
+    if (attempt == 0) mark(2);
+    int hflag = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&hflag, dflag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(hctl, ctl, sizeof(hctl), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (hflag == 0) break;
     HIPCHK(ctx, hipMemcpyAsync(A, Acopy, sizeof(T) * (size_t)n * n, hipMemcpyDeviceToDevice, ctx->stream));
-    ctx->twostage_fallbacks++;
-    return NLS_OK;
+    if (attempt == 1) {
+      ctx->twostage_fallbacks++;
+      return NLS_OK;
+    }
+    ctx->twostage_rescues++;
+    HIPCHK(ctx, hipMemsetAsync(dflag, 0, 4 * sizeof(int), ctx->stream));
   }
   if (hctl[1] != 0) return fail(ctx, NLS_ERR_HIP, "band -> tridiagonal chase: a workgroup timed out waiting for its predecessor (n = %d)", n);
   double* Cr = nullptr;
@@ -863,3 +879,4 @@ extern "C" int nls_twostage_stage(nls_ctx* ctx, int stage, void* A, int n, int i
 }
 
 extern "C" long nls_twostage_fallbacks(const nls_ctx* ctx) { return ctx ? ctx->twostage_fallbacks : -1; }
+extern "C" long nls_twostage_rescues(const nls_ctx* ctx) { return ctx ? ctx->twostage_rescues : -1; }

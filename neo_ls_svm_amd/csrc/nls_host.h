@@ -66,6 +66,7 @@ struct nls_ctx {
   ncclComm_t comm = nullptr;  // native RCCL communicator (nls_comm_init_rank); takes precedence over the hook
   double* comm_scratch = nullptr;  // a few doubles on the device for nls_comm_allreduce
   size_t ws_bytes = 0;        // bytes currently held by the workspace arena
+  long twostage_rescues = 0;    // eigendecompositions whose band reduction met a degenerate panel and succeeded at the second, perturbed attempt
   long twostage_fallbacks = 0;  // eigendecompositions whose band reduction met a degenerate panel and fell back to the one-stage panel
   std::vector<nls_factor*> factors;
   // XCD patch shape of k_rotate3 (NLS_ROT_PATCH=RxC; 0x0 = plain order, the default: patches raise the L2 hit rate

@@ -534,6 +534,32 @@ __global__ void __launch_bounds__(256, 1) k_sb_finish(T* Yb, long ldy, int m, in
   }
 }
 
+// ---- rescue of a degenerate panel: P += E, |E|_F = 1e-13 |P|_F ----------------------------------------------------------------
+// CholeskyQR cannot orthogonalise a panel whose columns are dependent to working precision (a matrix "identity + low rank" runs out of
+// rank in the middle of a panel).  The second attempt of the band reduction (driver: evd_two_stage) adds a fixed pseudo-random
+// perturbation of relative size 1e-13 to every panel before it is factored: its condition number is then <= ~1e13, which the shifted
+// CholeskyQR3 handles, and what is not annihilated below the band - and dropped - is of the size of the perturbation, a backward error
+// of 1e-13 |A| per panel.  G = the panel's Gram matrix (its trace gives |P|_F); the hash depends on (row, column, j) only: reproducible.
+__device__ __forceinline__ double sb_hash_unit(unsigned a, unsigned b, unsigned c) {  // in [-1, 1)
+  unsigned h = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u) * 0x85EBCA77u ^ (c + 0x165667B1u) * 0xC2B2AE3Du;
+  h ^= h >> 15;
+  h *= 0x2C1B3C6Du;
+  h ^= h >> 12;
+  h *= 0x297A2D39u;
+  h ^= h >> 15;
+  return (double)(int)h * (1.0 / 2147483648.0);
+}
+template <class T>
+__global__ void __launch_bounds__(256) k_sb_perturb(T* P, long lda, int m, int kb, const T* G, int ldg, unsigned j) {
+  const long idx = blockIdx.x * 256L + threadIdx.x;
+  if (idx >= (long)m * kb) return;
+  double tr = 0.0;
+  for (int c = 0; c < kb; ++c) tr += real_(G[c + (long)ldg * c]);
+  const double delta = 1e-13 * sqrt(tr / ((double)m * kb));
+  const int r = (int)(idx % m), c = (int)(idx / m);
+  P[r + (long)c * lda] = P[r + (long)c * lda] + make_<T>(delta * sb_hash_unit((unsigned)r, (unsigned)c, j), sizeof(T) == 16 ? delta * sb_hash_unit((unsigned)r, (unsigned)c, ~j) : 0.0);
+}
+
 // ---- W = A22 Z for the Hermitian A22 stored in the lower triangle ----------------------------------------------------------
 // Row block I (64 rows) of the result needs the tiles A[I][J] (J < I), the Hermitian diagonal tile and A[K][I]^H (K > I): NT = mh / 64
 // tiles in all, every row block the same number - the lower triangle is read twice per product, all workgroups do equal work.  The

@@ -107,20 +107,32 @@ def test_eigh_two_stage_at_path_sizes(hp, monkeypatch):
         assert abs(lam[0] - 1e-3) < 1e-8 * nrm
 
 
-def test_degenerate_panels_fall_back_to_the_one_stage_reduction(hp, monkeypatch):
-    """A diagonal matrix (zero panels) and one with exactly repeated columns cannot be orthogonalised by CholeskyQR: the band reduction
-    flags it, the saved copy is reduced by the one-stage panel, the counter moves, the result is right."""
+def test_degenerate_panels_are_rescued_or_fall_back_to_the_one_stage_reduction(hp, monkeypatch):
+    """Panels that CholeskyQR cannot orthogonalise raise a flag.  A diagonal matrix (zero panels) ends in the one-stage panel; a matrix
+    with exactly dependent columns goes through at the second attempt (panels perturbed by 1e-13 of their norm); both counters move,
+    the results are right."""
     monkeypatch.setenv("NLS_EVD", "twostage")
     ctx = hp.default_context()
-    before = ctx.lib.nls_twostage_fallbacks(ctx.handle)
+    fb, rs = ctx.lib.nls_twostage_fallbacks(ctx.handle), ctx.lib.nls_twostage_rescues(ctx.handle)
     lam, Q = hp.eigh(np.diag(np.arange(1.0, 301.0)))
     assert np.array_equal(lam, np.arange(1.0, 301.0)) and np.allclose(np.abs(Q), np.eye(300), atol=1e-14)
+    assert ctx.lib.nls_twostage_fallbacks(ctx.handle) == fb + 1
     rng = np.random.default_rng(1)
     M = rng.standard_normal((260, 3))
     A = M @ M.T  # rank 3: the first panel's 32 columns are exactly dependent
     lam, Q = hp.eigh(A)
     assert np.max(np.abs(lam - np.linalg.eigvalsh(A))) <= 1e-11 * lam[-1] and np.max(np.abs(A @ Q - Q * lam)) <= 1e-11 * lam[-1]
-    assert ctx.lib.nls_twostage_fallbacks(ctx.handle) >= before + 1
+    assert np.max(np.abs(Q.T @ Q - np.eye(260))) <= 1e-12
+    assert ctx.lib.nls_twostage_rescues(ctx.handle) + ctx.lib.nls_twostage_fallbacks(ctx.handle) >= rs + fb + 2
+    # identity + low rank: the reduction runs out of rank in the middle of a panel (condition number 1e16)
+    n = 1400
+    M = rng.standard_normal((n, n // 2 + 8))
+    A = M @ M.T / n + np.eye(n)
+    for bw in ("32", "64"):
+        monkeypatch.setenv("NLS_SB_BW", bw)
+        lam, Q = hp.eigh(A)
+        assert np.max(np.abs(lam - np.linalg.eigvalsh(A))) <= 1e-11 * lam[-1] and np.max(np.abs(A @ Q - Q * lam)) <= 1e-10 * lam[-1]
+        assert np.max(np.abs(Q.T @ Q - np.eye(n))) <= 1e-11
 
 
 def test_fits_through_the_two_stage_reduction_match_the_reference(hp, monkeypatch):

@@ -227,15 +227,16 @@ static int sy2sb(nls_ctx* ctx, T* A, int n, long lda, T* tau1, int* dflag, int* 
   HIPCHK(ctx, hipMemsetAsync(tau1, 0, sizeof(T) * (size_t)n, ctx->stream));
   if (n - B < 2) return NLS_OK;
   const int nch_max = (n + RW - 1) / RW, nrb_max = (n + RC - 1) / RC;
-  const int split_max = 16;
-  T *Yb = nullptr, *Zb = nullptr, *Wb = nullptr, *Gp = nullptr, *Wp = nullptr, *Mp = nullptr;
+  const int parts_max = 32;  // partial results of W = A22 Z per row block (one per wave)
+  T *Yb = nullptr, *Zb = nullptr, *Zr = nullptr, *Wb = nullptr, *Gp = nullptr, *Wp = nullptr, *Mp = nullptr;
   PanelSmall<T, B>* ps = nullptr;
   NLSCHK(ws_get_t(ctx, "sb.Y", (size_t)n * B, &Yb));
   NLSCHK(ws_get_t(ctx, "sb.Z", (size_t)n * B, &Zb));
+  NLSCHK(ws_get_t(ctx, "sb.Zr", (size_t)n * B, &Zr));
   NLSCHK(ws_get_t(ctx, "sb.W", (size_t)n * B, &Wb));
   NLSCHK(ws_get_t(ctx, "sb.Gp", (size_t)nch_max * B * B, &Gp));
   NLSCHK(ws_get_t(ctx, "sb.Mp", (size_t)nrb_max * B * B, &Mp));
-  NLSCHK(ws_get_t(ctx, "sb.Wp", (size_t)split_max * n * B, &Wp));
+  NLSCHK(ws_get_t(ctx, "sb.Wp", (size_t)parts_max * n * B, &Wp));
   NLSCHK(ws_get_t(ctx, "sb.ps", (size_t)1, &ps));
   const size_t mat = sb_mat_bytes<T, B>(B), tile = sb_mat_bytes<T, B>(64);
   const size_t lds_chol = 2 * mat, lds_recon = 3 * mat, lds_apply = mat + tile, lds_finish = mat + tile, lds_reduce = 2 * tile, lds_x = tile + mat;
@@ -245,6 +246,8 @@ static int sy2sb(nls_ctx* ctx, T* A, int n, long lda, T* tau1, int* dflag, int* 
   NLSCHK(sb_lds_optin(ctx, k_sb_finish<T, B>, lds_finish, "k_sb_finish"));
   NLSCHK(sb_lds_optin(ctx, k_sb_hemm_reduce<T, B>, lds_reduce, "k_sb_hemm_reduce"));
   NLSCHK(sb_lds_optin(ctx, k_sb_x<T, B>, lds_x, "k_sb_x"));
+  const size_t lds_her2k = her2k_lds_bytes<T, B>();
+  NLSCHK(sb_lds_optin(ctx, k_sb_her2k<T, B>, lds_her2k, "k_sb_her2k"));
   hipStream_t st = ctx->stream;
   const dim3 red_grid((B * B + 255) / 256);
   int j = 0;
@@ -256,6 +259,7 @@ static int sy2sb(nls_ctx* ctx, T* A, int n, long lda, T* tau1, int* dflag, int* 
     if (zh > 0) {
       HIPCHK(ctx, hipMemsetAsync(Yb, 0, sizeof(T) * (size_t)n * B, st));
       HIPCHK(ctx, hipMemsetAsync(Zb, 0, sizeof(T) * (size_t)n * B, st));
+      HIPCHK(ctx, hipMemsetAsync(Zr, 0, sizeof(T) * (size_t)n * B, st));
     }
     T* P = A + (long)(j + B) + (long)j * lda;
     const int nch = (m + RW - 1) / RW;
@@ -273,16 +277,17 @@ static int sy2sb(nls_ctx* ctx, T* A, int n, long lda, T* tau1, int* dflag, int* 
     hipLaunchKernelGGL((k_sb_apply<T, B>), dim3(nch), dim3(256), lds_apply, st, Yb + zh, (long)n, m, kb, ps, Yb + zh, (long)n, Gp);
     hipLaunchKernelGGL((k_sb_reduce<T>), red_grid, dim3(256), 0, st, Gp, nch, B * B, ps->G);
     hipLaunchKernelGGL((k_sb_small_recon<T, B>), dim3(1), dim3(256), lds_recon, st, kb, Yb + zh, (long)n, ps, P, lda, tau1 + j, dflag);
-    hipLaunchKernelGGL((k_sb_finish<T, B>), dim3(nch), dim3(256), lds_finish, st, Yb, (long)n, m, kb, ps, Zb, P, lda);
+    hipLaunchKernelGGL((k_sb_finish<T, B>), dim3(nch), dim3(256), lds_finish, st, Yb, (long)n, m, kb, ps, Zb, Zr, P, lda);
     HIPCHK(ctx, hipGetLastError());
     T* A22 = A + (long)(j + kb) + (long)(j + kb) * lda;
     const int NT = (mh + HT - 1) / HT, nrb = (mh + RC - 1) / RC;
-    const int split = std::max(1, std::min({split_max, NT, (2 * ctx->cus + NT - 1) / NT}));
-    hipLaunchKernelGGL((k_sb_hemm<T, B>), dim3(NT, split), dim3(256), 0, st, A22, lda, mh, Zb, (long)n, kb, split, Wp);
-    hipLaunchKernelGGL((k_sb_hemm_reduce<T, B>), dim3(nrb), dim3(256), lds_reduce, st, Wp, split, mh, kb, Zb, Wb, (long)n, Mp);
+    // one wave per (row block, part): ~8 waves per CU, at least two tiles per wave
+    const int parts = std::max(1, std::min({parts_max, (NT + 1) / 2, (8 * ctx->cus + NT - 1) / NT}));
+    hipLaunchKernelGGL((k_sb_hemm<T, B>), dim3(NT, (parts + HemmCfg<T, B>::PPW - 1) / HemmCfg<T, B>::PPW), dim3(256), 0, st, A22, lda, mh, Zr, kb, parts, Wp);
+    hipLaunchKernelGGL((k_sb_hemm_reduce<T, B>), dim3(nrb), dim3(256), lds_reduce, st, Wp, parts, mh, kb, Zb, Wb, (long)n, Mp);
     hipLaunchKernelGGL((k_sb_reduce<T>), red_grid, dim3(256), 0, st, Mp, nrb, B * B, ps->G);
     hipLaunchKernelGGL((k_sb_x<T, B>), dim3(nrb), dim3(256), lds_x, st, Wb, Yb, (long)n, mh, kb, ps);
-    hipLaunchKernelGGL((k_sb_her2k<T, B>), dim3(NT * (NT + 1) / 2), dim3(256), 0, st, A22, lda, mh, Wb, Yb, (long)n, kb);
+    hipLaunchKernelGGL((k_sb_her2k<T, B>), dim3(NT * (NT + 1) / 2), dim3(256), lds_her2k, st, A22, lda, mh, Wb, Yb, (long)n, kb);
     HIPCHK(ctx, hipGetLastError());
     j += kb;
   }

@@ -473,9 +473,10 @@ __global__ void __launch_bounds__(256, 1) k_sb_small_recon(int kb, const T* Ytop
 }
 
 // ---- finish: Y (explicit, m x kb) and Z = Y T into the panel buffers, Y's strictly-lower part into A below the band -----------------
-// Row r < kb of Y comes from Y1, rows >= kb are the rows of Q2 solved against M = U R3 (ps->Rs).  Yb / Zb have zh = B - kb zero rows on top.
+// Row r < kb of Y comes from Y1, rows >= kb are the rows of Q2 solved against M = U R3 (ps->Rs).  Yb / Zb have zh = B - kb zero rows on top;
+// Zr is Z once more, row-major with B columns.
 template <class T, int B>
-__global__ void __launch_bounds__(256, 1) k_sb_finish(T* Yb, long ldy, int m, int kb, const PanelSmall<T, B>* ps, T* Zb, T* Apanel, long lda) {
+__global__ void __launch_bounds__(256, 1) k_sb_finish(T* Yb, long ldy, int m, int kb, const PanelSmall<T, B>* ps, T* Zb, T* Zr, T* Apanel, long lda) {
   size_t off = 0;
   T(*Ms)[B + 1] = sb_carve<T, B + 1>(B, off);  // M, later T
   T(*Ps)[B + 1] = sb_carve<T, B + 1>(64, off);
@@ -529,7 +530,10 @@ __global__ void __launch_bounds__(256, 1) k_sb_finish(T* Yb, long ldy, int m, in
     if (r0 + rr < m) {
 #pragma unroll
       for (int c = 0; c < CQ; ++c)
-        if (q4 + 4 * c < kb) Zb[(r0 + rr + zh) + (long)(q4 + 4 * c) * ldy] = z[c];
+        if (q4 + 4 * c < kb) {
+          Zb[(r0 + rr + zh) + (long)(q4 + 4 * c) * ldy] = z[c];
+          Zr[(long)(r0 + rr + zh) * B + q4 + 4 * c] = z[c];  // row-major copy: the operand layout of k_sb_hemm
+        }
     }
   }
 }
@@ -562,114 +566,139 @@ __global__ void __launch_bounds__(256) k_sb_perturb(T* P, long lda, int m, int k
 
 // ---- W = A22 Z for the Hermitian A22 stored in the lower triangle ----------------------------------------------------------
 // Row block I (64 rows) of the result needs the tiles A[I][J] (J < I), the Hermitian diagonal tile and A[K][I]^H (K > I): NT = mh / 64
-// tiles in all, every row block the same number - the lower triangle is read twice per product, all workgroups do equal work.  The
-// tiles of a row block are dealt round-robin to SPLIT workgroups (blockIdx.y) whose partial results k_sb_hemm_reduce adds in a fixed order.
-// On v_mfma_f64_16x16x4_f64 without LDS and without barriers: wave w of a workgroup owns rows 16 w .. 16 w + 15 of the row block and all B
-// columns; both operands go from global memory straight into the fragment registers.  The k index of an MFMA step is free as long as both
-// operands agree, so a lane takes FOUR consecutive k (k = 16 q + 4 (lane / 16) + e, e = 0 .. 3): the Z operand and the conjugate-transposed
-// tiles (k runs down a stored column) are then one 32-byte (complex: 64-byte) run per lane and whole 128-byte lines per 16 lanes; the tiles
-// left of the diagonal (k runs along a stored row) are four 8-byte loads, each contiguous over the 16 lanes.  One (tile, q) slice is in
-// flight while the previous one multiplies.
+// tiles in all, every row block the same number - the lower triangle is read twice per product, all row blocks do equal work.  The
+// tiles of a row block are dealt round-robin to PARTS waves whose partial results k_sb_hemm_reduce adds in a fixed order.
+// On v_mfma_f64_16x16x4_f64 without LDS and without barriers: a WAVE owns (row block, part): all 64 rows x B columns of its partial
+// result (4 x B/16 accumulator tiles) and whole 64 x 64 tiles of A - no operand is fetched by two waves.  Both operands go from global
+// memory straight into the fragment registers.  The k index of an MFMA step is free as long as both operands agree, so a lane takes FOUR
+// consecutive k (k = 16 q + 4 (lane / 16) + e, e = 0 .. 3): the conjugate-transposed tiles (k runs down a stored column) are then one
+// 32-byte (complex: 64-byte) run per lane, whole 128-byte lines per 16 lanes; the tiles left of the diagonal (k runs along a stored row)
+// and Z - read from its ROW-major copy Zr[k][c] - are 8-byte loads contiguous over the 16 lanes.  One (tile, q) slice is in flight
+// while the previous one multiplies.
 constexpr int HT = 64;  // tile edge
 typedef double hv4d __attribute__((ext_vector_type(4)));
 
-// fragment of one (tile, q) slice: A operand a[e], Z operand z[jt][e]
+// Row tiles per wave: 4 (the whole row block) where the accumulators and two slices fit 256 registers (real, B = 32), else 2 - the two
+// halves of a row block then go to two waves, which both fetch the slice of Z.
+template <class T, int B>
+struct HemmCfg {
+  static constexpr int RT = (sizeof(T) == 8 && B == 32) ? 4 : 2;
+  static constexpr int SLABS = 4 / RT;      // waves that share a row block
+  static constexpr int PPW = 4 / SLABS;     // parts per workgroup (blockIdx.y)
+};
+// fragments of one (tile, q) slice: A operand a[rt][e] (row tile rt), Z operand z[jt][e] (column tile jt)
 template <class T, int B>
 struct HemmSlice {
-  T a[4], z[B / 16][4];
+  T a[HemmCfg<T, B>::RT][4], z[B / 16][4];
 };
-// FULL: the tile and the row block lie inside the matrix (no bounds tests)
+// FULL: the tile and the row block lie inside the matrix (no bounds tests).  r0: first row of this wave's slab.
 template <class T, int B, bool FULL>
-__device__ __forceinline__ void hemm_load(HemmSlice<T, B>& f, const T* A, long lda, int mh, const T* Zb, long ldz, int I, int t, int q, int w, int lane) {
+__device__ __forceinline__ void hemm_load(HemmSlice<T, B>& f, const T* A, long lda, int mh, const T* Zr, int I, long r0, int t, int q, int lane) {
+  constexpr int RT = HemmCfg<T, B>::RT;
   const int x = lane & 15, kk = lane >> 4;
-  const long r = (long)I * HT + 16 * w + x;     // row of the result this lane feeds (A operand: i = x)
   const long k0 = (long)t * HT + 16 * q + 4 * kk;  // first of this lane's four k
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const long k = k0 + e;
-    T v = zero_<T>();
-    if (FULL || (r < mh && k < mh)) {
-      if (t < I) {
-        v = A[r + k * lda];
-      } else if (t > I) {
-        v = conj_(A[k + r * lda]);
-      } else {  // diagonal tile: the stored half, mirrored
-        v = r >= k ? A[r + k * lda] : conj_(A[k + r * lda]);
-        if (r == k) v = make_<T>(real_(v), 0.0);
+  for (int rt = 0; rt < RT; ++rt) {
+    const long r = r0 + 16 * rt + x;  // row of the result this lane feeds (A operand: i = x)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const long k = k0 + e;
+      T v = zero_<T>();
+      if (FULL || (r < mh && k < mh)) {
+        if (t < I) {
+          v = A[r + k * lda];
+        } else if (t > I) {
+          v = conj_(A[k + r * lda]);
+        } else {  // diagonal tile: the stored half, mirrored
+          v = r >= k ? A[r + k * lda] : conj_(A[k + r * lda]);
+          if (r == k) v = make_<T>(real_(v), 0.0);
+        }
       }
-    }
-    f.a[e] = v;
-  }
-#pragma unroll
-  for (int jt = 0; jt < B / 16; ++jt) {
-    const T* zp = Zb + k0 + (long)(16 * jt + x) * ldz;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) f.z[jt][e] = (FULL || k0 + e < mh) ? zp[e] : zero_<T>();
-  }
-}
-template <int B>
-__device__ __forceinline__ void hemm_mac(hv4d (&acc)[2][B / 16], const HemmSlice<double, B>& f) {
-#pragma unroll
-  for (int e = 0; e < 4; ++e)
-#pragma unroll
-    for (int jt = 0; jt < B / 16; ++jt) acc[0][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a[e], f.z[jt][e], acc[0][jt], 0, 0, 0);
-}
-template <int B>
-__device__ __forceinline__ void hemm_mac(hv4d (&acc)[2][B / 16], const HemmSlice<Z, B>& f) {
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const double ar = f.a[e].re, ai = f.a[e].im, nai = -ai;
-#pragma unroll
-    for (int jt = 0; jt < B / 16; ++jt) {
-      acc[0][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, f.z[jt][e].re, acc[0][jt], 0, 0, 0);
-      acc[0][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(nai, f.z[jt][e].im, acc[0][jt], 0, 0, 0);
-      acc[1][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, f.z[jt][e].im, acc[1][jt], 0, 0, 0);
-      acc[1][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, f.z[jt][e].re, acc[1][jt], 0, 0, 0);
+      f.a[rt][e] = v;
     }
   }
+#pragma unroll
+  for (int jt = 0; jt < B / 16; ++jt)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) f.z[jt][e] = (FULL || k0 + e < mh) ? Zr[(k0 + e) * B + 16 * jt + x] : zero_<T>();
 }
 // bounds tests only for the tiles that touch the end of the matrix (uniform choice)
 template <class T, int B>
-__device__ __forceinline__ void hemm_load_any(HemmSlice<T, B>& f, const T* A, long lda, int mh, const T* Zb, long ldz, int I, int t, int q, int w, int lane) {
+__device__ __forceinline__ void hemm_load_any(HemmSlice<T, B>& f, const T* A, long lda, int mh, const T* Zr, int I, long r0, int t, int q, int lane) {
   if ((long)(max(I, t) + 1) * HT <= mh)
-    hemm_load<T, B, true>(f, A, lda, mh, Zb, ldz, I, t, q, w, lane);
+    hemm_load<T, B, true>(f, A, lda, mh, Zr, I, r0, t, q, lane);
   else
-    hemm_load<T, B, false>(f, A, lda, mh, Zb, ldz, I, t, q, w, lane);
+    hemm_load<T, B, false>(f, A, lda, mh, Zr, I, r0, t, q, lane);
 }
+template <int B, int RT, int JT>
+__device__ __forceinline__ void hemm_mac(hv4d (&acc)[2][RT][JT], const HemmSlice<double, B>& f) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int jt = 0; jt < JT; ++jt) acc[0][rt][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a[rt][e], f.z[jt][e], acc[0][rt][jt], 0, 0, 0);
+}
+template <int B, int RT, int JT>
+__device__ __forceinline__ void hemm_mac(hv4d (&acc)[2][RT][JT], const HemmSlice<Z, B>& f) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const double ar = f.a[rt][e].re, ai = f.a[rt][e].im, nai = -ai;
+#pragma unroll
+      for (int jt = 0; jt < JT; ++jt) {
+        acc[0][rt][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, f.z[jt][e].re, acc[0][rt][jt], 0, 0, 0);
+        acc[0][rt][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(nai, f.z[jt][e].im, acc[0][rt][jt], 0, 0, 0);
+        acc[1][rt][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, f.z[jt][e].im, acc[1][rt][jt], 0, 0, 0);
+        acc[1][rt][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, f.z[jt][e].re, acc[1][rt][jt], 0, 0, 0);
+      }
+    }
+}
+// grid (NT, ceil(parts / PPW)), 256 threads: wave w of workgroup (I, y) is slab w % SLABS of row block I, part PPW y + w / SLABS
 template <class T, int B>
-__global__ void __launch_bounds__(256) k_sb_hemm(const T* A, long lda, int mh, const T* Zb, long ldz, int kb, int split, T* Wp) {
+__global__ void __launch_bounds__(256) k_sb_hemm(const T* A, long lda, int mh, const T* Zr, int kb, int parts, T* Wp) {
+  using Cf = HemmCfg<T, B>;
   constexpr bool CX = sizeof(T) == 16;
-  const int I = blockIdx.x, part = blockIdx.y;
-  const int NT = (mh + HT - 1) / HT;
+  constexpr int RT = Cf::RT;
+  const int I = blockIdx.x;
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  hv4d acc[2][B / 16];
+  const int part = Cf::PPW * blockIdx.y + w / Cf::SLABS;
+  const long r0 = (long)I * HT + 16 * RT * (w % Cf::SLABS);
+  if (part >= parts) return;
+  const int NT = (mh + HT - 1) / HT;
+  hv4d acc[2][RT][B / 16];
 #pragma unroll
   for (int p = 0; p < 2; ++p)
 #pragma unroll
-    for (int jt = 0; jt < B / 16; ++jt) acc[p][jt] = hv4d{0.0, 0.0, 0.0, 0.0};
-  const int nmine = part < NT ? (NT - 1 - part) / split + 1 : 0;  // tiles part, part + split, ...
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int jt = 0; jt < B / 16; ++jt) acc[p][rt][jt] = hv4d{0.0, 0.0, 0.0, 0.0};
+  const int nmine = part < NT ? (NT - 1 - part) / parts + 1 : 0;  // tiles part, part + parts, ...
   const int items = 4 * nmine;                                     // (tile, q) slices: an even number
   if (items > 0) {
     HemmSlice<T, B> f0, f1;
-    hemm_load_any<T, B>(f0, A, lda, mh, Zb, ldz, I, part, 0, w, lane);
+    hemm_load_any<T, B>(f0, A, lda, mh, Zr, I, r0, part, 0, lane);
     for (int it = 0; it < items; it += 2) {
-      hemm_load_any<T, B>(f1, A, lda, mh, Zb, ldz, I, part + split * ((it + 1) >> 2), (it + 1) & 3, w, lane);
-      hemm_mac<B>(acc, f0);
-      if (it + 2 < items) hemm_load_any<T, B>(f0, A, lda, mh, Zb, ldz, I, part + split * ((it + 2) >> 2), (it + 2) & 3, w, lane);
-      hemm_mac<B>(acc, f1);
+      hemm_load_any<T, B>(f1, A, lda, mh, Zr, I, r0, part + parts * ((it + 1) >> 2), (it + 1) & 3, lane);
+      hemm_mac(acc, f0);
+      if (it + 2 < items) hemm_load_any<T, B>(f0, A, lda, mh, Zr, I, r0, part + parts * ((it + 2) >> 2), (it + 2) & 3, lane);
+      hemm_mac(acc, f1);
     }
   }
   // D[i][j]: lane = 16 (i % 4) + j, reg = i / 4
   T* out = Wp + ((long)part * mh) * B;  // partial p: [mh][B] row-major
 #pragma unroll
-  for (int reg = 0; reg < 4; ++reg) {
-    const long gr = (long)I * HT + 16 * w + 4 * reg + (lane >> 4);
-    if (gr < mh) {
+  for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-      for (int jt = 0; jt < B / 16; ++jt) out[gr * B + 16 * jt + (lane & 15)] = make_<T>(acc[0][jt][reg], CX ? acc[1][jt][reg] : 0.0);
+    for (int reg = 0; reg < 4; ++reg) {
+      const long gr = r0 + 16 * rt + 4 * reg + (lane >> 4);
+      if (gr < mh) {
+#pragma unroll
+        for (int jt = 0; jt < B / 16; ++jt) out[gr * B + 16 * jt + (lane & 15)] = make_<T>(acc[0][rt][jt][reg], CX ? acc[1][rt][jt][reg] : 0.0);
+      }
     }
-  }
 }
 
 // W = sum of the partials (fixed order) -> Wb (column-major, ld);  per row block the partial of M = Z^H W
@@ -683,8 +712,19 @@ __global__ void __launch_bounds__(256) k_sb_hemm_reduce(const T* Wp, int split, 
   for (int idx = threadIdx.x; idx < RC * B; idx += 256) {
     const int c = idx % B, r = idx / B;  // partials are row-major
     T s = zero_<T>();
-    if (r0 + r < mh && c < kb)
-      for (int p = 0; p < split; ++p) s = s + Wp[((long)p * mh + r0 + r) * B + c];
+    if (r0 + r < mh && c < kb) {
+      const T* wp = Wp + ((long)r0 + r) * B + c;
+      const long pstride = (long)mh * B;
+      int p = 0;
+      for (; p + 8 <= split; p += 8) {  // eight loads in flight, added in the fixed order
+        T v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = wp[(p + u) * pstride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s = s + v[u];
+      }
+      for (; p < split; ++p) s = s + wp[p * pstride];
+    }
     Ws[r][c] = s;
   }
   for (int idx = threadIdx.x; idx < RC * B; idx += 256) {
@@ -764,18 +804,43 @@ __global__ void __launch_bounds__(256) k_sb_x(T* Wb, const T* Yb, long ld, int m
   }
 }
 
-// A22 -= X Y^H + Y X^H on the lower triangle, 64 x 64 tiles R >= C, on v_mfma_f64_16x16x4_f64 without LDS.  The product is formed
-// TRANSPOSED, D[i][j] = update of A[r0 + 16 jt + j][c0 + 16 w + i] (wave w = 16 columns of the tile, jt = 0 .. 3), so that the 16 lanes of
-// an accumulator register are 16 consecutive rows of one stored column: the read-modify-write of A moves whole 128-byte lines.
-// A operand (i = column of the tile): conj(Y[c][k]), then conj(X[c][k]);  B operand (j = row): X[r][k], then Y[r][k];
-// the panel columns beyond kb (last, narrow panel) are masked.  Both panels are small (2 m B elements, cache resident) and are read by the
-// fragment layout directly: 16 lanes = 16 consecutive rows of one panel column.
+// A22 -= X Y^H + Y X^H on the lower triangle, 64 x 64 tiles R >= C, on v_mfma_f64_16x16x4_f64.  The product is formed TRANSPOSED,
+// D[i][j] = update of A[r0 + 16 jt + j][c0 + 16 w + i] (wave w = 16 columns of the tile, jt = 0 .. 3), so that the 16 lanes of an accumulator
+// register are 16 consecutive rows of one stored column: the read-modify-write of A moves whole 128-byte lines.
+// A operand (i = column of the tile): conj(Y[c][k]), then conj(X[c][k]), from global memory in the fragment layout (16 lanes = 16
+// consecutive rows of one panel column; every wave has its own 16 columns).  B operand (j = row): X[r][k], then Y[r][k] - the same 64
+// rows for all four waves, staged once in LDS as [k][row] (leading dimension 72 = 8 mod 32 doubles: conflict-free fragment reads).
+// The panel columns beyond kb (last, narrow panel) are masked.
+constexpr int H2LD = 72;
+template <class T, int B>
+constexpr size_t her2k_lds_bytes() {
+  return 2 * (size_t)B * H2LD * sizeof(T);
+}
 template <class T, int B, bool FULL>
 __device__ __forceinline__ void her2k_tile(T* A, long lda, int mh, const T* Xb, const T* Yb, long ld, int kb, long r0, long c0, bool diag, int w, int lane) {
   constexpr bool CX = sizeof(T) == 16;
   constexpr int KS = B / 4;
+  T(*Xs)[H2LD] = reinterpret_cast<T(*)[H2LD]>(sb_smem);
+  T(*Ys)[H2LD] = Xs + B;
+  for (int idx = threadIdx.x; idx < B * 64; idx += 256) {
+    const int row = idx % 64, k = idx / 64;
+    const bool in = k < kb && (FULL || r0 + row < mh);
+    Xs[k][row] = in ? Xb[r0 + row + (long)k * ld] : zero_<T>();
+    Ys[k][row] = in ? Yb[r0 + row + (long)k * ld] : zero_<T>();
+  }
   const int x = lane & 15, kk = lane >> 4;
   const long c = c0 + 16 * w + x;  // A operand: column c of the tile
+  T a[2][KS];
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const T* Pa = half == 0 ? Yb : Xb;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int k = 4 * ks + kk;
+      a[half][ks] = (k < kb && (FULL || c < mh)) ? conj_(Pa[c + (long)k * ld]) : zero_<T>();
+    }
+  }
+  __syncthreads();
   hv4d acc[2][4];
 #pragma unroll
   for (int p = 0; p < 2; ++p)
@@ -783,29 +848,18 @@ __device__ __forceinline__ void her2k_tile(T* A, long lda, int mh, const T* Xb, 
     for (int jt = 0; jt < 4; ++jt) acc[p][jt] = hv4d{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
-    const T* Pa = half == 0 ? Yb : Xb;  // column side
-    const T* Pb = half == 0 ? Xb : Yb;  // row side
-    T a[KS];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const int k = 4 * ks + kk;
-      a[ks] = (k < kb && (FULL || c < mh)) ? conj_(Pa[c + (long)k * ld]) : zero_<T>();
-    }
+    T(*Pb)[H2LD] = half == 0 ? Xs : Ys;  // row side
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) {
-      const long r = r0 + 16 * jt + x;
       T b[KS];
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const int k = 4 * ks + kk;
-        b[ks] = (k < kb && (FULL || r < mh)) ? Pb[r + (long)k * ld] : zero_<T>();
-      }
+      for (int ks = 0; ks < KS; ++ks) b[ks] = Pb[4 * ks + kk][16 * jt + x];
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         if constexpr (!CX) {
-          acc[0][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks], acc[0][jt], 0, 0, 0);
+          acc[0][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[half][ks], b[ks], acc[0][jt], 0, 0, 0);
         } else {
-          const double ar = a[ks].re, ai = a[ks].im, nai = -ai;
+          const double ar = a[half][ks].re, ai = a[half][ks].im, nai = -ai;
           acc[0][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, b[ks].re, acc[0][jt], 0, 0, 0);
           acc[0][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(nai, b[ks].im, acc[0][jt], 0, 0, 0);
           acc[1][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, b[ks].im, acc[1][jt], 0, 0, 0);
@@ -822,7 +876,7 @@ __device__ __forceinline__ void her2k_tile(T* A, long lda, int mh, const T* Xb, 
     for (int jt = 0; jt < 4; ++jt) {
       const long r = r0 + 16 * jt + x;
       if ((FULL || (r < mh && cc < mh)) && (!diag || r >= cc)) {
-        // result element (r, cc) = conj-free: D holds sum_k conj(P[cc][k]) Q[r][k] = (X Y^H + Y X^H)[r][cc]
+        // D holds sum_k conj(P[cc][k]) Q[r][k] = (X Y^H + Y X^H)[r][cc]
         T v = A[r + cc * lda] - make_<T>(acc[0][jt][reg], CX ? acc[1][jt][reg] : 0.0);
         if (r == cc) v = make_<T>(real_(v), 0.0);
         A[r + cc * lda] = v;

@@ -69,9 +69,10 @@ struct nls_ctx {
   long twostage_rescues = 0;    // eigendecompositions whose band reduction met a degenerate panel and succeeded at the second, perturbed attempt
   long twostage_fallbacks = 0;  // eigendecompositions whose band reduction met a degenerate panel and fell back to the one-stage panel
   std::vector<nls_factor*> factors;
-  // XCD patch shape of k_rotate3 (NLS_ROT_PATCH=RxC; 0x0 = plain order, the default: patches raise the L2 hit rate
-  // from 0.57 to 0.78 and halve the fabric traffic but run 1-4 % slower, profiles/r01_pmc_summary.md)
+  // XCD patch shape of k_rotate3 (NLS_ROT_PATCH=RxC; 0x0 = plain order).  Unset: plain on one GPU, a padding-free patch with a communicator
+  // (launch_rotate in nls_lib.hip has the counters)
   int rot_pr = 0, rot_pc = 0;
+  bool rot_patch_set = false;
   int k1_stagger_ticks = 0;  // NLS_K1_STAGGER_US: period over which the first-round workgroups of K1 are spread (k1_stagger)
   int rot_kstagger = 0;  // NLS_ROT_KSTAGGER=S: K-walk phase (tr + tc) % S slices per workgroup (see mainloop_3m)
   bool no_resident = false;  // NLS_NO_RESIDENT_PLANES=1: recompute the feature planes per phase even when they would fit

@@ -92,9 +92,24 @@ static int launch_rotate(nls_ctx* ctx, const MapParams& mp, const double* Fc, co
                          const double* mbr, const double* mbi, const double* vr, const double* vi, double* U, double* Gm,
                          const double* inv_rs, long rows_pad) {
   const long tiles_r = rows_pad / BM, tiles_c = mp.Np / m3::BN3;
-  const long grid = ctx->rot_pr > 0 ? xcd_patch_grid(tiles_r, tiles_c, ctx->rot_pr, ctx->rot_pc) : tiles_r * tiles_c;
+  // XCD patch order (NLS_ROT_PATCH=RxC; 0x0: plain).  Round-3 counters (profiles/r03_pmc_summary.md, 333 440 rows, 65 column tiles): a patch whose
+  // column count DIVIDES the number of column tiles has no padding blocks and costs nothing - 8 x 5: 500 GB past L2 against 932 GB plain
+  // (11.9 x the algorithmic bytes against 21.7 x, L2 hit 0.76 against 0.56) at 465.6 against 463.8 ms; the 4 x 8 patch of round 2 (every ninth
+  // patch 7/8 empty) took 485.8 ms.  The fabric is shared by the ranks of a node, so with a communicator the order is patched when such a
+  // divisor exists; one GPU keeps the plain order.
+  int pr = ctx->rot_pr, pc = ctx->rot_pc;
+  if (!ctx->rot_patch_set && multi_rank(ctx)) {
+    pr = pc = 0;
+    for (int c : {5, 6, 7, 8, 4, 9, 10, 11, 12, 13})
+      if (tiles_c % c == 0) {
+        pr = 8;
+        pc = c;
+        break;
+      }
+  }
+  const long grid = pr > 0 ? xcd_patch_grid(tiles_r, tiles_c, pr, pc) : tiles_r * tiles_c;
   hipLaunchKernelGGL(k_rotate3, dim3((unsigned)grid), dim3(m3::NT3), m3::SMEM3, ctx->stream, Fc, Fs, mp.Kf, Mr, Mi, mbr, mbi, mp.Np,
-                     vr, vi, U, Gm, inv_rs, tiles_r, ctx->rot_pr, ctx->rot_pc, ctx->rot_kstagger);
+                     vr, vi, U, Gm, inv_rs, tiles_r, pr, pc, ctx->rot_kstagger);
   HIPCHK(ctx, hipGetLastError());
   return NLS_OK;
 }
@@ -145,7 +160,7 @@ extern "C" int nls_ctx_create(int device, nls_ctx** out) {
   }
   ctx->hbm_bytes = prop.totalGlobalMem;
   ctx->cus = prop.multiProcessorCount;
-  if (const char* ep = std::getenv("NLS_ROT_PATCH")) std::sscanf(ep, "%dx%d", &ctx->rot_pr, &ctx->rot_pc);
+  if (const char* ep = std::getenv("NLS_ROT_PATCH")) ctx->rot_patch_set = std::sscanf(ep, "%dx%d", &ctx->rot_pr, &ctx->rot_pc) == 2;
   if (const char* er = std::getenv("NLS_NO_RESIDENT_PLANES")) ctx->no_resident = er[0] == '1';
   if (const char* es = std::getenv("NLS_K1_STAGGER_US")) ctx->k1_stagger_ticks = std::max(0, std::min(100000, (int)(std::atof(es) * 100.0)));
   if (const char* et = std::getenv("NLS_K1_SINCOS")) ctx->k1_table = std::string(et) == "table";

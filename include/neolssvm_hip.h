@@ -32,7 +32,8 @@
  *     which (hipPointerGetAttributes).  Device-resident inputs are used in place, host inputs are
  *     staged with one H2D copy.  Small parameter arrays (shift, scale, B, gammas, beta, L, alpha) and
  *     all outputs are host pointers.  Nothing is retained after a call returns.
- *   - Calls are blocking; one host thread per context.  The library never uses a CPU fallback.
+ *   - Calls are blocking; one host thread per context, and ONE fitting context per process and GPU at a time: two contexts of one process
+ *     running fits concurrently is not a supported mode (profiles/r03_sigma_overlap.log).  The library never uses a CPU fallback.
  *   - Multi-GPU: one process and one context per GPU, rows sharded by the caller.  The path exchanges data at
  *     four points: {sum s, sum s*y, n}, the Hermitian block A||b (sum all-reduce), the eigenvectors (rank 0 runs the
  *     tridiagonal eigensolver and broadcasts; every rank back-transforms one column block; all-gather) and the

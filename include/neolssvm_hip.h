@@ -175,7 +175,7 @@ typedef struct nls_primal_fit_args {
   double finish_below;    /* NLS_FIT_FINISH_IF_BELOW: threshold on the selected objective         */
   /* outputs (host; any may be NULL) */
   double* beta;          /* 2 (D+1)   fitted weights, complex128                              */
-  double* L;             /* 2 (D+1)^2 cho_factor(gamma* C + A) as scipy returns it: upper     */
+  double* L;             /* 2 (D+1)^2 cho_factor(gamma* C + A) as scipy returns it: upper; only that triangle is defined */
                          /*           triangular factor U (A = U^H U), row-major, lower=False */
   double* lam;           /* D+1       eigenvalues of A / c (ascending)                        */
   double* loo_errors;    /* G         s @ |e_loo(gamma)|                  (loo_errors_gammas_) */
@@ -264,7 +264,7 @@ typedef struct nls_dual_fit_args {
   int32_t is_classifier;
   int32_t gamma_index_in;
   double* alpha;         /* n */
-  double* L;             /* n x n  cho_factor(gamma* diag(sn^-2) + K), upper, row-major */
+  double* L;             /* n x n  cho_factor(gamma* diag(sn^-2) + K), upper, row-major; only that triangle is defined */
   double* lam;           /* n */
   double* loo_errors;    /* G */
   double* objective;     /* G */

@@ -277,7 +277,7 @@ extern "C" int nls_dual_fit(nls_ctx* ctx, const nls_dual_fit_args* a) {
     NLSCHK(d2h(a->loo_std, sig, sizeof(double) * n));
     NLSCHK(d2h(a->residuals, res, sizeof(double) * n));
     // Column-major lower Cholesky factor == row-major upper factor U (M2 = U^T U): scipy's lower=False layout.
-    NLSCHK(d2h(a->L, M2, sizeof(double) * n * n));
+    if (a->L) NLSCHK(download_factor(ctx, a->L, M2, (int)n, sizeof(double), ctx->stream, pinL.p != nullptr));
   }
   NLSCHK(spans_collect(ctx, tm));
   if (a->loo_errors) std::memcpy(a->loo_errors, herrs.data(), sizeof(double) * G);

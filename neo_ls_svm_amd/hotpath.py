@@ -289,7 +289,7 @@ def primal_fit(
         "objective": np.empty(G),
     }
     if want_L:
-        out["L"] = np.empty((D1, D1), dtype=np.complex128)
+        out["L"] = np.zeros((D1, D1), dtype=np.complex128)  # only the upper triangle is defined (cho_factor layout; large factors arrive as the triangle alone)
     if want_rows:
         for k in ("loo_residuals", "loo_leverage", "loo_std", "residuals"):
             out[k] = np.empty(n)
@@ -477,7 +477,7 @@ def dual_fit(
         "residuals": np.empty(n),
     }
     if want_L:
-        out["L"] = np.empty((n, n))
+        out["L"] = np.zeros((n, n))  # only the upper triangle is defined (cho_factor layout; large factors arrive as the triangle alone)
     score, opt = C.c_double(), C.c_int32()
     tm = np.zeros(_lib.NUM_TIMINGS)
     a = DualFitArgs()

@@ -250,6 +250,9 @@ static int sy2sb(nls_ctx* ctx, T* A, int n, long lda, T* tau1, int* dflag, int* 
   NLSCHK(sb_lds_optin(ctx, k_sb_her2k<T, B>, lds_her2k, "k_sb_her2k"));
   hipStream_t st = ctx->stream;
   const dim3 red_grid((B * B + 255) / 256);
+  // well-conditioned panels take two passes instead of three (k_sb_small_chol); not in the rescue attempt; NLS_SB_ADAPTIVE=0: never
+  static const bool adaptive_env = [] { const char* m = std::getenv("NLS_SB_ADAPTIVE"); return !(m && m[0] == '0'); }();
+  const int adaptive = adaptive_env && !perturb ? 1 : 0;
   int j = 0;
   for (;;) {
     const int m = n - j - B;            // rows below the band in column j
@@ -270,11 +273,12 @@ static int sy2sb(nls_ctx* ctx, T* A, int n, long lda, T* tau1, int* dflag, int* 
       hipLaunchKernelGGL((k_sb_gram<T, B>), dim3(nch), dim3(256), 0, st, P, lda, m, kb, Gp);
       hipLaunchKernelGGL((k_sb_reduce<T>), red_grid, dim3(256), 0, st, Gp, nch, B * B, ps->G);
     }
-    hipLaunchKernelGGL((k_sb_small_chol<T, B>), dim3(1), dim3(256), lds_chol, st, kb, m, 0, ps, dflag);
-    hipLaunchKernelGGL((k_sb_apply<T, B>), dim3(nch), dim3(256), lds_apply, st, P, lda, m, kb, ps, Yb + zh, (long)n, Gp);
+    hipLaunchKernelGGL((k_sb_small_chol<T, B>), dim3(1), dim3(256), lds_chol, st, kb, m, 0, ps, dflag, adaptive);
+    hipLaunchKernelGGL((k_sb_apply<T, B>), dim3(nch), dim3(256), lds_apply, st, P, lda, m, kb, ps, Yb + zh, (long)n, Gp, 0);
     hipLaunchKernelGGL((k_sb_reduce<T>), red_grid, dim3(256), 0, st, Gp, nch, B * B, ps->G);
-    hipLaunchKernelGGL((k_sb_small_chol<T, B>), dim3(1), dim3(256), lds_chol, st, kb, m, 1, ps, dflag);
-    hipLaunchKernelGGL((k_sb_apply<T, B>), dim3(nch), dim3(256), lds_apply, st, Yb + zh, (long)n, m, kb, ps, Yb + zh, (long)n, Gp);
+    // (second pass: returns at once for a well-conditioned panel - the reduction then re-adds the first pass's partials, unchanged)
+    hipLaunchKernelGGL((k_sb_small_chol<T, B>), dim3(1), dim3(256), lds_chol, st, kb, m, 1, ps, dflag, adaptive);
+    hipLaunchKernelGGL((k_sb_apply<T, B>), dim3(nch), dim3(256), lds_apply, st, Yb + zh, (long)n, m, kb, ps, Yb + zh, (long)n, Gp, 1);
     hipLaunchKernelGGL((k_sb_reduce<T>), red_grid, dim3(256), 0, st, Gp, nch, B * B, ps->G);
     hipLaunchKernelGGL((k_sb_small_recon<T, B>), dim3(1), dim3(256), lds_recon, st, kb, Yb + zh, (long)n, ps, P, lda, tau1 + j, dflag);
     hipLaunchKernelGGL((k_sb_finish<T, B>), dim3(nch), dim3(256), lds_finish, st, Yb, (long)n, m, kb, ps, Zb, Zr, P, lda);

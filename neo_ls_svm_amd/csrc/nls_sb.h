@@ -82,6 +82,7 @@ struct PanelSmall {
   T Racc[B * B];   // R3 R2 R1 so far (upper triangular)
   T Tm[B * B];     // T of the block reflector (upper triangular)
   T Y1[B * B];     // top block of Y (unit lower triangular), explicit
+  int skip2;       // the panel is well conditioned: its first pass ran unshifted and the second pass is skipped (CholeskyQR2)
 };
 
 // out[e] = sum_p part[p * count + e] in index order (bit-reproducible), 8 loads in flight per thread
@@ -227,38 +228,76 @@ __device__ __attribute__((noinline)) void lds_row_solve_upper(T (*X)[B + 1], int
 }
 
 // ---- small kernel of passes 1 and 2:  G (+ shift) = R^H R;  ps->Rs = R;  Racc = R Racc -----------------------------------------
+// adaptive: pass 0 first factors the UNSHIFTED Gram matrix; if that succeeds with pivots within a factor 100 of each other (kappa(P) of the
+// order of 10^2 .. 10^3: one unshifted pass leaves an orthogonality error kappa^2 u <= 1e-10, which the last pass - k_sb_small_recon - removes:
+// CholeskyQR2) the second pass is skipped (ps->skip2; its kernels return at once).  Otherwise the shifted three-pass scheme runs as before.
 template <class T, int B>
-__global__ void __launch_bounds__(256) k_sb_small_chol(int kb, int m, int pass, PanelSmall<T, B>* ps, int* flag) {
+__global__ void __launch_bounds__(256) k_sb_small_chol(int kb, int m, int pass, PanelSmall<T, B>* ps, int* flag, int adaptive) {
   using S = Small<B>;
+  if (pass == 1 && ps->skip2) return;  // uniform
   size_t off = 0;
   T(*R)[B + 1] = sb_carve<T, B + 1>(B, off);
   T(*Ra)[B + 1] = sb_carve<T, B + 1>(B, off);
   __shared__ T col[2][B];
   __shared__ double sc[1];
+  __shared__ int skip_s;
   const int r = threadIdx.x / S::TPR, cg = threadIdx.x % S::TPR;
   T a[S::CPT];
 #pragma unroll
   for (int q = 0; q < S::CPT; ++q) a[q] = ps->G[r + B * (cg + S::TPR * q)];
-  if (pass == 0) {
-    // trace through LDS: the diagonal entry of row r is held by the thread with cg == r % TPR (static register index: compare per q)
+  bool done = false;
+  if (pass == 0 && adaptive) {
+    const bool ok0 = reg_cholesky<T, B>(a, kb, col);
+    __syncthreads();
 #pragma unroll
     for (int q = 0; q < S::CPT; ++q)
-      if (cg + S::TPR * q == r) col[0][r] = r < kb ? a[q] : zero_<T>();
+      if (cg + S::TPR * q == r) col[0][r] = a[q];
     __syncthreads();
     if (threadIdx.x < 64) {
-      double tr = 0.0;
-      for (int i = threadIdx.x; i < B; i += 64) tr += real_(col[0][i]);
-      tr = wave_sum(tr);
-      if (threadIdx.x == 0) sc[0] = 11.0 * ((double)m * kb + (double)kb * (kb + 1)) * 1.1102230246251565e-16 * tr + 1e-300;
+      double mn = 1e300, mx = 0.0;
+      for (int i = threadIdx.x; i < kb; i += 64) {
+        const double v = real_(col[0][i]);
+        mn = fmin(mn, v);
+        mx = fmax(mx, v);
+      }
+#pragma unroll
+      for (int msk = 32; msk > 0; msk >>= 1) {
+        mn = fmin(mn, __shfl_xor(mn, msk, 64));
+        mx = fmax(mx, __shfl_xor(mx, msk, 64));
+      }
+      if (threadIdx.x == 0) skip_s = (ok0 && mn > 1e-2 * mx) ? 1 : 0;
     }
     __syncthreads();
+    done = skip_s != 0;
+    if (!done) {
 #pragma unroll
-    for (int q = 0; q < S::CPT; ++q)
-      if (cg + S::TPR * q == r && r < kb) a[q] = a[q] + make_<T>(sc[0], 0.0);
-    __syncthreads();
+      for (int q = 0; q < S::CPT; ++q) a[q] = ps->G[r + B * (cg + S::TPR * q)];
+    }
   }
-  const bool ok = reg_cholesky<T, B>(a, kb, col);
-  if (!ok && threadIdx.x == 0) flag[0] = 1;
+  if (pass == 0 && threadIdx.x == 0) ps->skip2 = done ? 1 : 0;
+  if (!done) {
+    if (pass == 0) {
+      // trace through LDS: the diagonal entry of row r is held by the thread with cg == r % TPR (static register index: compare per q)
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < S::CPT; ++q)
+        if (cg + S::TPR * q == r) col[0][r] = r < kb ? a[q] : zero_<T>();
+      __syncthreads();
+      if (threadIdx.x < 64) {
+        double tr = 0.0;
+        for (int i = threadIdx.x; i < B; i += 64) tr += real_(col[0][i]);
+        tr = wave_sum(tr);
+        if (threadIdx.x == 0) sc[0] = 11.0 * ((double)m * kb + (double)kb * (kb + 1)) * 1.1102230246251565e-16 * tr + 1e-300;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < S::CPT; ++q)
+        if (cg + S::TPR * q == r && r < kb) a[q] = a[q] + make_<T>(sc[0], 0.0);
+      __syncthreads();
+    }
+    const bool ok = reg_cholesky<T, B>(a, kb, col);
+    if (!ok && threadIdx.x == 0) flag[0] = 1;
+  }
   // R = L^H (upper; identity outside the leading block)
 #pragma unroll
   for (int q = 0; q < S::CPT; ++q) {
@@ -289,8 +328,9 @@ __global__ void __launch_bounds__(256) k_sb_small_chol(int kb, int m, int pass, 
 
 // ---- apply pass: rows of Q = rows of P solved against R (ps->Rs), written to dst; Gram partials of the result -----------------------
 template <class T, int B>
-__global__ void __launch_bounds__(256, 1) k_sb_apply(const T* src, long lds_, int m, int kb, const PanelSmall<T, B>* ps, T* dst, long ldd, T* Gp) {
+__global__ void __launch_bounds__(256, 1) k_sb_apply(const T* src, long lds_, int m, int kb, const PanelSmall<T, B>* ps, T* dst, long ldd, T* Gp, int second) {
   constexpr int TI = B / 16;
+  if (second && ps->skip2) return;  // the second pass of a well-conditioned panel (k_sb_small_chol)
   size_t off = 0;
   T(*Rs)[B + 1] = sb_carve<T, B + 1>(B, off);
   T(*Ps)[B + 1] = sb_carve<T, B + 1>(64, off);

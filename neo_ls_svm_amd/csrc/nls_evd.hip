@@ -251,8 +251,8 @@ static int sy2sb(nls_ctx* ctx, T* A, int n, long lda, T* tau1, int* dflag, int* 
   hipStream_t st = ctx->stream;
   const dim3 red_grid((B * B + 255) / 256);
   // well-conditioned panels take two passes instead of three (k_sb_small_chol); not in the rescue attempt; NLS_SB_ADAPTIVE=0: never
-  static const bool adaptive_env = [] { const char* m = std::getenv("NLS_SB_ADAPTIVE"); return !(m && m[0] == '0'); }();
-  const int adaptive = adaptive_env && !perturb ? 1 : 0;
+  const char* adaptive_env = std::getenv("NLS_SB_ADAPTIVE");
+  const int adaptive = !(adaptive_env && adaptive_env[0] == '0') && !perturb ? 1 : 0;
   int j = 0;
   for (;;) {
     const int m = n - j - B;            // rows below the band in column j

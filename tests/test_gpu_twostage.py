@@ -135,6 +135,22 @@ def test_degenerate_panels_are_rescued_or_fall_back_to_the_one_stage_reduction(h
         assert np.max(np.abs(Q.T @ Q - np.eye(n))) <= 1e-11
 
 
+@pytest.mark.parametrize("cplx", [False, True])
+def test_three_pass_panels_equal_the_adaptive_two_pass_ones(cplx, hp, monkeypatch):
+    """Well-conditioned panels skip the second CholeskyQR pass by default; NLS_SB_ADAPTIVE=0 keeps all three: same decomposition to rounding."""
+    monkeypatch.setenv("NLS_EVD", "twostage")
+    n = 700
+    A = _herm(n, cplx, 3)
+    lam0 = np.linalg.eigvalsh(A)
+    scale = np.max(np.abs(lam0))
+    for mode in ("1", "0"):
+        monkeypatch.setenv("NLS_SB_ADAPTIVE", mode)
+        lam, Q = hp.eigh(A)
+        assert np.max(np.abs(lam - lam0)) <= 1e-13 * n * scale
+        assert np.max(np.abs(A @ Q - Q * lam[None, :])) <= 1e-13 * n * scale
+        assert np.max(np.abs(Q.conj().T @ Q - np.eye(n))) <= 1e-13 * n
+
+
 def test_fits_through_the_two_stage_reduction_match_the_reference(hp, monkeypatch):
     """The primal and the dual fit with every eigendecomposition forced through the two-stage path: same parity bar as the default."""
     monkeypatch.setenv("NLS_EVD", "twostage")

@@ -579,13 +579,15 @@ static int evd_two_stage(nls_ctx* ctx, T* A, int n, double* lam, double* e_work,
     HIPCHK(ctx, hipMemcpyAsync(&hflag, dflag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(hctl, ctl, sizeof(hctl), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    if (hflag == 0) break;
+    if (hflag == 0) {
+      if (attempt == 1) ctx->twostage_rescues++;
+      break;
+    }
     HIPCHK(ctx, hipMemcpyAsync(A, Acopy, sizeof(T) * (size_t)n * n, hipMemcpyDeviceToDevice, ctx->stream));
     if (attempt == 1) {
       ctx->twostage_fallbacks++;
       return NLS_OK;
     }
-    ctx->twostage_rescues++;
     HIPCHK(ctx, hipMemsetAsync(dflag, 0, 4 * sizeof(int), ctx->stream));
   }
   if (hctl[1] != 0) return fail(ctx, NLS_ERR_HIP, "band -> tridiagonal chase: a workgroup timed out waiting for its predecessor (n = %d)", n);

@@ -659,53 +659,38 @@ static int evd_hermitian_core(nls_ctx* ctx, double2* A, int n, double* lam, doub
     }
   }
   NLSCHK(trd_fused<trd::Z>(ctx, reinterpret_cast<trd::Z*>(A), n, n, lam, e_work, tau));
-  if (collective && multi_rank(ctx) && n >= 64) {
-    // Every rank holds the same all-reduced matrix and the tridiagonalisation is bit-reproducible, so the reflectors are
-    // replicated.  The tridiagonal eigensolver runs on rank 0 ONLY and (lam, C) are broadcast: all ranks then pair the
-    // same eigenvalues with the same basis whatever rocSOLVER's stedc does on clustered spectra.  The back-transformation
-    // is split by columns over the ranks and the blocks are all-gathered.
-    // A failure on rank 0 (API error or info != 0) travels to all ranks through the broadcast flag instead of leaving them blocked in
-    // the collective.
-    double* flag = nullptr;
-    NLSCHK(ws_get_t(ctx, "evd.flag", 2, &flag));
-    double hflag = 0.0;
-    if (ctx->rank == 0) {
-      const rocblas_status st = rocsolver_zstedc(ctx->blas, rocblas_evect_tridiagonal, n, lam, e_work, reinterpret_cast<rocblas_double_complex*>(C), n, dinfo);
-      rocblas_int info = 0;
-      const hipError_t h1 = hipMemcpyAsync(&info, dinfo, sizeof(info), hipMemcpyDeviceToHost, ctx->stream);
-      const hipError_t h2 = hipStreamSynchronize(ctx->stream);
-      hflag = st != rocblas_status_success ? -1.0 : ((h1 != hipSuccess || h2 != hipSuccess) ? -2.0 : (double)info);
-    }
-    HIPCHK(ctx, hipMemcpyAsync(flag, &hflag, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    NLSCHK(do_broadcast(ctx, flag, 1, 0));
-    HIPCHK(ctx, hipMemcpyAsync(&hflag, flag, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    if (hflag != 0.0)
-      return fail(ctx, NLS_ERR_LINALG, "rocsolver_zstedc on rank 0: %s (code %d)", hflag > 0 ? "no convergence" : "API failure", (int)hflag);
-    NLSCHK(do_broadcast(ctx, lam, (size_t)n, 0));
-    NLSCHK(do_broadcast(ctx, reinterpret_cast<double*>(C), (size_t)2 * n * n, 0));
+  // The tridiagonal matrix of a Hermitian matrix is REAL (LAPACK convention: the phases live in the reflectors), so its eigenvectors
+  // come from dstedc (15 instead of zstedc's 22 ms at n = 4097) and are widened to complex only for the back-transformation.
+  // collective: every rank holds the same all-reduced matrix and the tridiagonalisation is bit-reproducible, so the reflectors are
+  // replicated.  The tridiagonal eigensolver runs on rank 0 ONLY and (lam, the real eigenvectors: 134 instead of 268 MB) are broadcast:
+  // all ranks then pair the same eigenvalues with the same basis whatever rocSOLVER's stedc does on clustered spectra (a failure on
+  // rank 0 travels through the broadcast flag: stedc_real).  The back-transformation is split by columns over the ranks and the blocks
+  // are all-gathered.
+  const bool split = collective && multi_rank(ctx) && n >= 64;
+  double* Cr = nullptr;
+  NLSCHK(ws_get_t(ctx, "evd2.Cr", (size_t)n * n, &Cr));
+  NLSCHK(stedc_real(ctx, n, lam, e_work, Cr, dinfo, split));
+  long c0 = 0, c1 = n;
+  if (split) {
+    c0 = (long)n * ctx->rank / ctx->world;
+    c1 = (long)n * (ctx->rank + 1) / ctx->world;
+  }
+  if (c1 > c0) {
+    const long cnt = (c1 - c0) * n;
+    hipLaunchKernelGGL(k_real_to_complex, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream, Cr + c0 * n, cnt, C + c0 * n);
+    HIPCHK(ctx, hipGetLastError());
+  }
+  if (evd_rocsolver_backtransform()) {
+    BLASCHK(ctx, rocsolver_zunmtr(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, n, (rocblas_int)(c1 - c0),
+                                  reinterpret_cast<rocblas_double_complex*>(A), n, reinterpret_cast<rocblas_double_complex*>(tau),
+                                  reinterpret_cast<rocblas_double_complex*>(C + c0 * n), n));
+  } else {
+    NLSCHK(apply_q_blocked<trd::Z>(ctx, reinterpret_cast<trd::Z*>(A), n, n, tau, reinterpret_cast<trd::Z*>(C + c0 * n), n, (int)(c1 - c0)));
+  }
+  if (split) {
     std::vector<size_t> offs((size_t)ctx->world + 1);
     for (int r = 0; r <= ctx->world; ++r) offs[r] = (size_t)2 * n * (size_t)((long)n * r / ctx->world);
-    const long c0 = (long)n * ctx->rank / ctx->world, c1 = (long)n * (ctx->rank + 1) / ctx->world;
-    if (evd_rocsolver_backtransform()) {
-      BLASCHK(ctx, rocsolver_zunmtr(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, n, (rocblas_int)(c1 - c0),
-                                    reinterpret_cast<rocblas_double_complex*>(A), n, reinterpret_cast<rocblas_double_complex*>(tau),
-                                    reinterpret_cast<rocblas_double_complex*>(C + c0 * n), n));
-    } else {
-      NLSCHK(apply_q_blocked<trd::Z>(ctx, reinterpret_cast<trd::Z*>(A), n, n, tau, reinterpret_cast<trd::Z*>(C + c0 * n), n, (int)(c1 - c0)));
-    }
     NLSCHK(do_allgather_blocks(ctx, reinterpret_cast<double*>(C), offs));
-    *Q = C;
-    return NLS_OK;
-  }
-  BLASCHK(ctx, rocsolver_zstedc(ctx->blas, rocblas_evect_tridiagonal, n, lam, e_work, reinterpret_cast<rocblas_double_complex*>(C), n, dinfo));
-  NLSCHK(check_info(ctx, dinfo, "rocsolver_zstedc"));
-  if (evd_rocsolver_backtransform()) {
-    BLASCHK(ctx, rocsolver_zunmtr(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, n, n,
-                                  reinterpret_cast<rocblas_double_complex*>(A), n, reinterpret_cast<rocblas_double_complex*>(tau),
-                                  reinterpret_cast<rocblas_double_complex*>(C), n));
-  } else {
-    NLSCHK(apply_q_blocked<trd::Z>(ctx, reinterpret_cast<trd::Z*>(A), n, n, tau, reinterpret_cast<trd::Z*>(C), n, n));
   }
   *Q = C;
   return NLS_OK;

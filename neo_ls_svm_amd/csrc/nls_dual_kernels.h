@@ -243,6 +243,12 @@ __global__ void k_dual_chol_inputs(const double* F, long ldf, const double* sn, 
   if (Kp) Kp[i * n + j] = f - 1.0;
 }
 
+// out[i] = T[i][g] (T row-major with leading dimension ld): the selected column of a grid table
+__global__ void k_dual_take_column(const double* T, long ld, int g, long n, double* out) {
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i < n) out[i] = T[i * ld + g];
+}
+
 // out[i] = f(sum_j A[i][j] x[j]) ; one wave per row.  mode 0: dot + bias ; mode 1: dot - y[i] with clipping.
 __global__ void k_dual_gemv(const double* A, long ld, long rows, long cols, const double* x, double bias, const double* y,
                             int is_clf, double* out) {

@@ -4,12 +4,43 @@
 #include "nls_dual_kernels.h"
 #include "nls_host.h"
 #include "nls_kernels.h"
+#include "nls_potrf.h"
 
 using namespace nls;
 
 namespace {
 
 constexpr size_t SMEM_REAL_D = 2 * 2 * TILE_DOUBLES * sizeof(double);
+
+// A = L L^T in place (lower, column-major): nls_potrf.h; NLS_POTRF=rocsolver takes rocsolver_dpotrf instead (diagnostic).  info: device word,
+// 0 or the 1-based index of the first non-positive pivot.
+static int potrf_lower_real(nls_ctx* ctx, double* A, int n, long lda, rocblas_int* dinfo) {
+  using namespace potrf;
+  const char* m = std::getenv("NLS_POTRF");
+  if (m && std::string(m) == "rocsolver") {
+    BLASCHK(ctx, rocsolver_dpotrf(ctx->blas, rocblas_fill_lower, (rocblas_int)n, A, (rocblas_int)lda, dinfo));
+    return NLS_OK;
+  }
+  double* Sinv = nullptr;
+  NLSCHK(ws_get_t(ctx, "potrf.Sinv", (size_t)NB * SBK, &Sinv));
+  HIPCHK(ctx, hipMemsetAsync(dinfo, 0, sizeof(rocblas_int), ctx->stream));
+  static_assert(sizeof(rocblas_int) == sizeof(int), "info word");
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_leaf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEAF_LDS) != hipSuccess)
+    return fail(ctx, NLS_ERR_HIP, "k_potrf_leaf: %zu bytes of LDS refused", LEAF_LDS);
+  for (int k0 = 0; k0 < n; k0 += NB) {
+    const int w = std::min(NB, n - k0), mrows = n - k0 - w;
+    double* D = A + (long)k0 + (long)k0 * lda;
+    hipLaunchKernelGGL(k_potrf_leaf, dim3(1), dim3(256), LEAF_LDS, ctx->stream, D, lda, w, k0, Sinv, reinterpret_cast<int*>(dinfo));
+    if (mrows > 0) {
+      double* P = D + w;  // A21: rows below the diagonal block
+      hipLaunchKernelGGL(k_potrf_panel, dim3((unsigned)((mrows + 63) / 64)), dim3(256), 0, ctx->stream, P, lda, mrows, w, D, Sinv);
+      const int nt = (mrows + 63) / 64;
+      hipLaunchKernelGGL(k_potrf_syrk, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(256), 0, ctx->stream, D + w + (long)w * lda, lda, mrows, P, lda, w);
+    }
+    HIPCHK(ctx, hipGetLastError());
+  }
+  return NLS_OK;
+}
 
 template <int EPI>
 int launch_gemm(nls_ctx* ctx, const GemmParams& p, long M, long N) {
@@ -256,8 +287,8 @@ extern "C" int nls_dual_fit(nls_ctx* ctx, const nls_dual_fit_args* a) {
     HIPCHK(ctx, hipGetLastError());
     // (a blocked variant on rocBLAS trsm / syrk with 1024-wide panels was measured in round 3: 49.7 against 52.7 ms here and 17.6 against
     // 16.5 ms for the primal path's complex 4097 - not worth the code)
-    BLASCHK(ctx, rocsolver_dpotrf(ctx->blas, rocblas_fill_lower, (rocblas_int)n, M2, (rocblas_int)n, dinfo));
-    NLSCHK(check_info(ctx, dinfo, "rocsolver_dpotrf"));
+    NLSCHK(potrf_lower_real(ctx, M2, (int)n, (long)n, dinfo));
+    NLSCHK(check_info(ctx, dinfo, "Cholesky factorisation (potrf)"));
   }
   {
     SpanGuard g(ctx, NLS_T_RESIDUALS);

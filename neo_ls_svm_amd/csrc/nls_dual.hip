@@ -25,8 +25,11 @@ static int potrf_lower_real(nls_ctx* ctx, double* A, int n, long lda, rocblas_in
   NLSCHK(ws_get_t(ctx, "potrf.Sinv", (size_t)NB * SBK, &Sinv));
   HIPCHK(ctx, hipMemsetAsync(dinfo, 0, sizeof(rocblas_int), ctx->stream));
   static_assert(sizeof(rocblas_int) == sizeof(int), "info word");
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_leaf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEAF_LDS) != hipSuccess)
-    return fail(ctx, NLS_ERR_HIP, "k_potrf_leaf: %zu bytes of LDS refused", LEAF_LDS);
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_leaf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEAF_LDS) != hipSuccess ||
+      hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_syrk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_REAL_D) != hipSuccess)
+    return fail(ctx, NLS_ERR_HIP, "Cholesky kernels: %zu / %zu bytes of LDS refused", LEAF_LDS, SMEM_REAL_D);
+  if (lda % 2 != 0 || lda < (long)((n + BM - 1) / BM) * BM)
+    return fail(ctx, NLS_ERR_ARG, "potrf_lower_real: the leading dimension (%ld) must be n rounded up to %d", lda, BM);
   for (int k0 = 0; k0 < n; k0 += NB) {
     const int w = std::min(NB, n - k0), mrows = n - k0 - w;
     double* D = A + (long)k0 + (long)k0 * lda;
@@ -34,8 +37,9 @@ static int potrf_lower_real(nls_ctx* ctx, double* A, int n, long lda, rocblas_in
     if (mrows > 0) {
       double* P = D + w;  // A21: rows below the diagonal block
       hipLaunchKernelGGL(k_potrf_panel, dim3((unsigned)((mrows + 63) / 64)), dim3(256), 0, ctx->stream, P, lda, mrows, w, D, Sinv);
-      const int nt = (mrows + 63) / 64;
-      hipLaunchKernelGGL(k_potrf_syrk, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(256), 0, ctx->stream, D + w + (long)w * lda, lda, mrows, P, lda, w);
+      const int nt = (mrows + BM - 1) / BM;
+      hipLaunchKernelGGL(k_potrf_syrk, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(Cfg4::NTHREADS), SMEM_REAL_D, ctx->stream, D + w + (long)w * lda, lda, mrows, P,
+                         lda);
     }
     HIPCHK(ctx, hipGetLastError());
   }
@@ -275,7 +279,7 @@ extern "C" int nls_dual_fit(nls_ctx* ctx, const nls_dual_fit_args* a) {
   HIPCHK(ctx, hipMemcpyAsync(hsum, csum, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
 
   // ---- D5: Cholesky re-solve, residuals, sigma -----------------------------------------------------
-  double* M2 = Q;  // n x n, Q is dead
+  double* M2 = Q;  // n x n with leading dimension n_pad; Q (n_pad x n_pad) is dead
   // alpha(gamma*) = M^-1 y = sn W (gamma* + Lam)^-1 W^T sn y is the selected column of AG, which the sweep has already formed for the whole
   // grid (_neo_ls_svm.py:313-316 solve it with the Cholesky factor: two n x n triangular solves, 10.6 ms at n = 10^4).  The factorisation
   // itself only produces the L_ output and is skipped when the caller does not ask for it.
@@ -283,11 +287,11 @@ extern "C" int nls_dual_fit(nls_ctx* ctx, const nls_dual_fit_args* a) {
   HIPCHK(ctx, hipGetLastError());
   if (a->L) {
     SpanGuard g(ctx, NLS_T_CHOLESKY);
-    hipLaunchKernelGGL(k_dual_chol_inputs, grid2(n, n), dim3(256), 0, ctx->stream, F, n_pad, d_sn, n, gamma_opt, M2, (double*)nullptr);
+    hipLaunchKernelGGL(k_dual_chol_inputs, grid2(n, n), dim3(256), 0, ctx->stream, F, n_pad, d_sn, n, gamma_opt, M2, n_pad, (double*)nullptr);
     HIPCHK(ctx, hipGetLastError());
     // (a blocked variant on rocBLAS trsm / syrk with 1024-wide panels was measured in round 3: 49.7 against 52.7 ms here and 17.6 against
     // 16.5 ms for the primal path's complex 4097 - not worth the code)
-    NLSCHK(potrf_lower_real(ctx, M2, (int)n, (long)n, dinfo));
+    NLSCHK(potrf_lower_real(ctx, M2, (int)n, n_pad, dinfo));  // leading dimension n_pad: the rank-128 update reads whole 128-row blocks
     NLSCHK(check_info(ctx, dinfo, "Cholesky factorisation (potrf)"));
   }
   {
@@ -311,7 +315,7 @@ extern "C" int nls_dual_fit(nls_ctx* ctx, const nls_dual_fit_args* a) {
     NLSCHK(d2h(a->loo_std, sig, sizeof(double) * n));
     NLSCHK(d2h(a->residuals, res, sizeof(double) * n));
     // Column-major lower Cholesky factor == row-major upper factor U (M2 = U^T U): scipy's lower=False layout.
-    if (a->L) NLSCHK(download_factor(ctx, a->L, M2, (int)n, sizeof(double), ctx->stream, pinL.p != nullptr));
+    if (a->L) NLSCHK(download_factor(ctx, a->L, M2, (int)n, n_pad, sizeof(double), ctx->stream, pinL.p != nullptr));
   }
   NLSCHK(spans_collect(ctx, tm));
   if (a->loo_errors) std::memcpy(a->loo_errors, herrs.data(), sizeof(double) * G);

@@ -234,12 +234,12 @@ __global__ void k_dual_column(const double* yloo, const double* y, const double*
 }
 
 // M2[i][j] = F[i][j] + (i == j) gamma / sn_i^2 (n x n, ld = n, for dpotrf); Kp = F - 1 alongside.
-__global__ void k_dual_chol_inputs(const double* F, long ldf, const double* sn, long n, double gamma, double* M2, double* Kp) {
+__global__ void k_dual_chol_inputs(const double* F, long ldf, const double* sn, long n, double gamma, double* M2, long ldm, double* Kp) {
   const long j = blockIdx.x * (long)blockDim.x + threadIdx.x;
   const long i = blockIdx.y;
   if (j >= n) return;
   const double f = F[i * ldf + j];
-  M2[i * n + j] = f + ((i == j) ? gamma / (sn[i] * sn[i]) : 0.0);
+  M2[i * ldm + j] = f + ((i == j) ? gamma / (sn[i] * sn[i]) : 0.0);
   if (Kp) Kp[i * n + j] = f - 1.0;
 }
 

@@ -311,16 +311,20 @@ static double wall() {
 // memory (HostPin: the 800 MB of the dual fit) only the triangle travels: block columns of 256, rows from the block's first row down - half
 // the bytes of the square, 22.7 -> 7.7 ms at n = 10^4.  Pageable memory takes the square in one copy (strided copies through the staging
 // buffers are no faster: 13.6 against 11.9 ms for the 268 MB of the primal fit); the caller may rely on the upper triangle only.
-static int download_factor(nls_ctx* ctx, void* host, const void* dev, int n, size_t elem_bytes, hipStream_t stream, bool pinned) {
+static int download_factor(nls_ctx* ctx, void* host, const void* dev, int n, long ld_dev, size_t elem_bytes, hipStream_t stream, bool pinned) {
+  const size_t spitch = (size_t)ld_dev * elem_bytes, dpitch = (size_t)n * elem_bytes;  // (device: leading dimension ld_dev >= n; host: dense)
   if (!pinned) {
-    HIPCHK(ctx, hipMemcpyAsync(host, dev, (size_t)n * n * elem_bytes, hipMemcpyDeviceToHost, stream));
+    if (ld_dev == n)
+      HIPCHK(ctx, hipMemcpyAsync(host, dev, (size_t)n * n * elem_bytes, hipMemcpyDeviceToHost, stream));
+    else
+      HIPCHK(ctx, hipMemcpy2DAsync(host, dpitch, dev, spitch, dpitch, (size_t)n, hipMemcpyDeviceToHost, stream));
     return NLS_OK;
   }
   constexpr int NBD = 256;
   for (int j0 = 0; j0 < n; j0 += NBD) {
     const int w = std::min(NBD, n - j0);
-    const size_t off = ((size_t)j0 + (size_t)j0 * n) * elem_bytes, pitch = (size_t)n * elem_bytes;
-    HIPCHK(ctx, hipMemcpy2DAsync(static_cast<char*>(host) + off, pitch, static_cast<const char*>(dev) + off, pitch, (size_t)(n - j0) * elem_bytes, (size_t)w,
+    HIPCHK(ctx, hipMemcpy2DAsync(static_cast<char*>(host) + ((size_t)j0 + (size_t)j0 * n) * elem_bytes, dpitch,
+                                 static_cast<const char*>(dev) + ((size_t)j0 + (size_t)j0 * ld_dev) * elem_bytes, spitch, (size_t)(n - j0) * elem_bytes, (size_t)w,
                                  hipMemcpyDeviceToHost, stream));
   }
   return NLS_OK;

@@ -976,7 +976,7 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
     const long tot = (long)D1 * D1;
     hipLaunchKernelGGL(k_conj_inplace, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s2, Acm, tot);
     HIPCHK(ctx, hipGetLastError());
-    NLSCHK(download_factor(ctx, a->L, Acm, D1, sizeof(double2), s2, pinL.p != nullptr));
+    NLSCHK(download_factor(ctx, a->L, Acm, D1, (long)D1, sizeof(double2), s2, pinL.p != nullptr));
     HIPCHK(ctx, hipEventRecord(ctx->side_ev[2], s2));
   }
   {

@@ -2,7 +2,7 @@
 // the dual fit (cho_factor(gamma* diag(sn^-2) + K), _neo_ls_svm.py:313-314).
 //
 // Why not rocsolver_dpotrf: at n = 10^4 it takes 42 ms = 8 TFLOP/s - 79 diagonal blocks through a chain of small kernels (potf2_kernel_small,
-// 165 us each) with trsm / syrk calls of 128 columns in between.  Here (27 ms: k_potrf_syrk 15, k_potrf_leaf 9, k_potrf_panel 3), right-looking
+// 165 us each) with trsm / syrk calls of 128 columns in between.  Here (24.7 ms: k_potrf_syrk 12.7, k_potrf_leaf 8.7, k_potrf_panel 3.0), right-looking
 // in panels of NB = 128 columns, three launches per panel:
 //   k_potrf_leaf : ONE workgroup factors the 128 x 128 diagonal block in LDS (four 32 x 32 sub-blocks: a wave holds a sub-block in registers, one
 //                  row per lane, pivot and column entries travel by v_readlane - no barrier inside a sub-block; the rows below it are solved one
@@ -12,9 +12,10 @@
 //                  D'[c][r]: its accumulator layout (c = 4 reg + lane / 16) IS the B-operand layout (k = 4 ks + lane / 16), so a finished block
 //                  feeds the next products straight from its registers, and the store runs down stored columns (16 lanes = 16 consecutive
 //                  rows); every wave reads and writes its own 16 rows only: in place;
-//   k_potrf_syrk : A22 -= L21 L21^T on the lower 64 x 64 tiles, the read-modify-write of nls_sb.h's rank-2b update with one panel.
+//   k_potrf_syrk : A22 -= L21 L21^T on the lower 128 x 128 tiles through the real tile engine (nls_gemm.h).
 // A pivot <= 0 (or NaN) raises info = its 1-based index, as LAPACK does; the factorisation carries on with garbage (finite control flow).
 #pragma once
+#include "nls_gemm.h"
 #include "nls_sb.h"
 
 namespace nls {
@@ -192,56 +193,34 @@ __global__ void __launch_bounds__(256) k_potrf_panel(double* A21, long lda, int 
   }
 }
 
-// A22 -= L21 L21^T on the lower triangle: 64 x 64 tiles R >= C of the m x m matrix A22; L21: m x w (leading dimension ldl).  The product of
-// a tile is formed transposed (wave = 16 columns, 16 lanes = 16 consecutive rows of a stored column), as in sb::k_sb_her2k.
-template <bool FULL>
-__device__ __forceinline__ void syrk_tile(double* A, long lda, int m, const double* Lp, long ldl, int w, long r0, long c0, bool diag, int wv, int lane) {
-  constexpr int KS = NB / 4;
-  const int x = lane & 15, kk = lane >> 4;
-  const long c = c0 + 16 * wv + x;
-  double a[KS];
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    const int k = 4 * ks + kk;
-    a[ks] = (k < w && (FULL || c < m)) ? Lp[c + (long)k * ldl] : 0.0;
-  }
-  hv4d acc[4];
-#pragma unroll
-  for (int jt = 0; jt < 4; ++jt) acc[jt] = hv4d{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-  for (int jt = 0; jt < 4; ++jt) {
-    const long r = r0 + 16 * jt + x;
-    double b[KS];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const int k = 4 * ks + kk;
-      b[ks] = (k < w && (FULL || r < m)) ? Lp[r + (long)k * ldl] : 0.0;
-    }
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks], acc[jt], 0, 0, 0);
-  }
-#pragma unroll
-  for (int reg = 0; reg < 4; ++reg) {
-    const long cc = c0 + 16 * wv + 4 * reg + kk;
-#pragma unroll
-    for (int jt = 0; jt < 4; ++jt) {
-      const long r = r0 + 16 * jt + x;
-      if ((FULL || (r < m && cc < m)) && (!diag || r >= cc)) A[r + cc * lda] -= acc[jt][reg];
-    }
-  }
-}
-__global__ void __launch_bounds__(256) k_potrf_syrk(double* A, long lda, int m, const double* Lp, long ldl, int w) {
+// A22 -= L21 L21^T on the lower triangle: 128 x 128 tiles R >= C of the m x m matrix A22 on the real tile engine of nls_gemm.h (double-buffered
+// LDS slices of 16 k, one barrier per slice, 64 x 64 per wave).  L21: m x NB, leading dimension ldl - as a [k][row] plane it is the engine's
+// k-major operand for BOTH sides.  The tile is formed transposed (A operand: the tile's columns, B operand: its rows), so the 16 lanes of an
+// accumulator register are 16 consecutive rows of one stored column.  The loaders have no bounds tests: the panel must be readable up to a
+// multiple of 128 rows (the caller's leading dimension is padded; rows beyond m only feed results that are not stored).
+__global__ void __launch_bounds__(Cfg4::NTHREADS, 2) k_potrf_syrk(double* A, long lda, int m, const double* Lp, long ldl) {
+  using C4 = Cfg4;
+  extern __shared__ double smem[];
   int t = blockIdx.x, R = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
   while ((R + 1) * (R + 2) / 2 <= t) ++R;
   while (R * (R + 1) / 2 > t) --R;
   const int C = t - R * (R + 1) / 2;
-  const int lane = threadIdx.x & 63;
-  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const long r0 = (long)R * 64, c0 = (long)C * 64;
-  if (r0 + 64 <= m)
-    syrk_tile<true>(A, lda, m, Lp, ldl, w, r0, c0, R == C, wv, lane);
-  else
-    syrk_tile<false>(A, lda, m, Lp, ldl, w, r0, c0, R == C, wv, lane);
+  v4d acc[C4::MT][C4::NTL];
+  zero_acc(acc);
+  KMajorLoader<C4::NTHREADS, BM> la{Lp, ldl, (long)C * BM};
+  KMajorLoader<C4::NTHREADS, BN> lb{Lp, ldl, (long)R * BN};
+  mainloop_real<C4, true>(acc, la, lb, 0, NB / BK, smem);
+#pragma unroll
+  for (int mt = 0; mt < C4::MT; ++mt)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const long cc = (long)C * BM + C4::acc_row(mt, reg);
+#pragma unroll
+      for (int nt = 0; nt < C4::NTL; ++nt) {
+        const long r = (long)R * BN + C4::acc_col(nt);
+        if (r < m && cc < m && r >= cc) A[r + cc * lda] -= acc[mt][nt][reg];
+      }
+    }
 }
 
 }  // namespace potrf

@@ -289,8 +289,8 @@ extern "C" int nls_dual_fit(nls_ctx* ctx, const nls_dual_fit_args* a) {
     SpanGuard g(ctx, NLS_T_CHOLESKY);
     hipLaunchKernelGGL(k_dual_chol_inputs, grid2(n, n), dim3(256), 0, ctx->stream, F, n_pad, d_sn, n, gamma_opt, M2, n_pad, (double*)nullptr);
     HIPCHK(ctx, hipGetLastError());
-    // (a blocked variant on rocBLAS trsm / syrk with 1024-wide panels was measured in round 3: 49.7 against 52.7 ms here and 17.6 against
-    // 16.5 ms for the primal path's complex 4097 - not worth the code)
+    // own factorisation (nls_potrf.h): 24.7 ms at n = 10^4 against rocsolver_dpotrf's 42.5 (a blocked variant on rocBLAS trsm / syrk with
+    // rocSOLVER leaves had given 49.7 against 52.7 with the triangular solves still inside)
     NLSCHK(potrf_lower_real(ctx, M2, (int)n, n_pad, dinfo));  // leading dimension n_pad: the rank-128 update reads whole 128-row blocks
     NLSCHK(check_info(ctx, dinfo, "Cholesky factorisation (potrf)"));
   }

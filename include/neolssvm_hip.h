@@ -138,11 +138,13 @@ int nls_rotate_only(nls_ctx* ctx, const double* X, int64_t n, int d, const doubl
  *   environment selects rocSOLVER's zheevd / dsyevd for every eigendecomposition of the library. */
 int nls_tridiag_only(nls_ctx* ctx, void* A, int n, int is_complex, double* d, double* e, void* tau);
 int nls_eigh_only(nls_ctx* ctx, void* A, int n, int is_complex, double* lam);
-/* The eigendecompositions above take a TWO-STAGE reduction for larger matrices (dense -> band of width bw -> tridiagonal, two
- * back-transformations; csrc/nls_sb.h, nls_chase.h, nls_q2.h): NLS_EVD=twostage / onestage forces / forbids it, NLS_TWOSTAGE_MIN
- * moves the size rule, NLS_SB_BW = 32 / 64 the band width.  nls_twostage_stage runs ONE stage of it on host data (tests, profiling):
+/* The eigendecompositions above take a TWO-STAGE reduction for large real matrices (n >= 6000; dense -> band of width bw -> tridiagonal, two
+ * back-transformations; csrc/nls_sb.h, nls_chase.h, nls_q2.h) and the one-stage panel otherwise (complex matrices always): NLS_EVD=twostage /
+ * onestage forces / forbids it, NLS_TWOSTAGE_MIN moves the size rule (both arithmetics), NLS_SB_BW = 32 / 64 the band width of real matrices
+ * (default 32; complex: 32).  nls_twostage_stage runs ONE stage of it on host data (tests, profiling):
  *   stage 1: A (n x n column-major, lower) -> band in its bw sub-diagonals + block reflectors below; aux = tau1[n]; info = {failure flag
- *            (a panel that could not be orthogonalised: the library then falls back to the one-stage panel), columns reduced};
+ *            (a panel that could not be orthogonalised: the library then repeats the reduction with perturbed panels, then falls back to the
+ *            one-stage panel), columns reduced};
  *   stage 2: the band held in A's bw sub-diagonals -> d[n], e[n-1]; aux = the chase reflectors V2 (n x n); info[0] != 0: time-out;
  *   stage 3: aux (n x ncols, column-major) <- Q2 aux with the chase reflectors V2 handed in as A.
  * nls_twostage_rescues: eigendecompositions of this context whose band reduction met a panel it could not orthogonalise (columns dependent to

@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(256) k_potrf_leaf(double* A, long lda, int w, 
         for (int c = 0; c < SBK; ++c)
           if (c <= r) Ls[kb + r][kb + c] = a[c];
       }
-      if (bad != 0 && lane == 0 && kb + 0 < w && bad <= w) atomicCAS(info, 0, k0 + bad);
+      if (bad != 0 && bad <= w && lane == 0) atomicCAS(info, 0, k0 + bad);  // (pivots of the identity padding beyond w cannot fail)
     }
     __syncthreads();
     const int below = NB - kb - SBK;  // rows under the sub-block

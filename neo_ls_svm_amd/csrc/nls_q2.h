@@ -7,7 +7,8 @@
 // workgroup per block).  Order (see tools/twostage_proto.py for the derivation and the check against the reflector-by-reflector
 // product): groups descending, steps ascending inside a group; block (S - 1, k) needs the blocks (S, k' <= k).
 //
-// k_q2_apply: one workgroup per slab of NC columns of C, no communication between workgroups.  G groups are taken together ("pass"):
+// k_q2_apply (VALU reference form; the library runs k_q2_apply_packed below, same passes / steps / ring on fp64 MFMA): one workgroup per slab
+// of NC columns of C, no communication between workgroups.  G groups are taken together ("pass"):
 // at step u of a pass group S_hi - i applies its block k = u - i; those G blocks are two block rows apart, hence independent, and all lie in
 // a window of 2G block rows of the slab that is kept in LDS and slides down by ONE block row (B rows) per step - the slab streams through
 // LDS once per pass instead of once per group.  The products skip the structural zeros of V (exactly B terms per output).

@@ -9,21 +9,24 @@
 //
 // One panel (columns j .. j+kb-1, P = A[j+B:, j:j+kb], m x kb, m = n - j - B, kb = min(B, m - 1)):
 //   1. orthogonal factor of P by shifted CholeskyQR3 (three Gram / Cholesky / triangular-multiply passes; the shift of the
-//      first pass, 11 (m kb + kb (kb+1)) u trace(G), keeps its Cholesky alive up to kappa(P) ~ 1/u): k_sb_gram,
+//      first pass, 11 (m kb + kb (kb+1)) u trace(G), keeps its Cholesky alive up to kappa(P) ~ 1/u; a well-conditioned panel -
+//      unshifted first factorisation with pivots within a factor 100 - takes two passes: CholeskyQR2): k_sb_gram, k_sb_reduce,
 //      k_sb_small_chol, k_sb_apply;
 //   2. Householder reconstruction (Ballard et al., "Reconstructing Householder vectors from TSQR", 2014): a modified LU
 //      of the orthonormal factor gives Y (unit lower trapezoidal) and T (upper triangular) with Q = I - Y T Y^H and
 //      P = Q[:, :kb] R: k_sb_small_recon, k_sb_finish;
 //   3. two-sided update of A22 = A[j+kb:, j+kb:] (the block of Y zero-padded by B - kb rows on top, so that the narrower LAST
-//      panel also transforms the panel columns it does not factor): Z = Y T, W = A22 Z (k_sb_hemm + k_sb_hemm_reduce),
-//      M = Z^H W (k_sb_small_m), X = W - Y M / 2 (k_sb_x), A22 -= X Y^H + Y X^H (k_sb_her2k).
+//      panel also transforms the panel columns it does not factor): Z = Y T, W = A22 Z (k_sb_hemm + k_sb_hemm_reduce,
+//      both on fp64 MFMA with operands straight from global memory), M = Z^H W (partials from k_sb_hemm_reduce, k_sb_reduce),
+//      X = W - Y M / 2 (k_sb_x), A22 -= X Y^H + Y X^H (k_sb_her2k, fp64 MFMA).
 // Y stays below the band in A (LAPACK layout: unit diagonal implied at row j + B + c of column j + c), tau1[j + c] = T[c][c]
 // (the block is a product of kb elementary reflectors, so the blocked back-transformation of nls_evd.hip rebuilds its
 // T^-1 = striu(Y^H Y) + diag(1 / tau) from Y and tau1 alone).
 //
 // Failure: a Cholesky pivot <= 0 / NaN or a second-pass Gram matrix further than 1e-6 from I (kappa(P) beyond ~1e15:
-// exactly dependent or zero panel columns, e.g. a diagonal matrix) raises flag[0]; the driver then reduces the saved copy of
-// the matrix with the one-stage panel instead.  All reductions run over per-block partials in a fixed order: bit-reproducible.
+// exactly dependent or zero panel columns, e.g. a diagonal matrix) raises flag[0]; the driver then repeats the reduction on the saved
+// copy with every panel perturbed by 1e-13 of its norm (k_sb_perturb) and, if that fails too, hands the copy to the one-stage panel.
+// All reductions run over per-block partials in a fixed order: bit-reproducible.
 #pragma once
 #include "nls_trd.h"
 

@@ -640,9 +640,11 @@ __global__ void __launch_bounds__(256) k_sum_partials(const double* part, long n
 // Column of the selected gamma: P7 / P9 outputs and the score sums.
 //   part[blk][0] = clf: sum s [sign(yloo) == y]   reg: sum s (y - yloo)^2
 //   part[blk][1] = reg: sum s (y - ybar)^2
+// res: residuals_ = Re(phi beta(gamma*)) - y (clipped for classifiers; _neo_ls_svm.py:184-187): num IS Re(phi beta) on the grid, so the selected
+// column gives them without another pass over the feature planes.
 __global__ void k_loo_column(const double* num, const double* hs, const double* y, const double* s, long n, int Gp,
                              int g, int is_clf, double ybar, double* loo_res, double* loo_lev, double* loo_std,
-                             double* part) {
+                             double* res, double* part) {
   __shared__ double s0[256], s1[256];
   const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
   double a0 = 0.0, a1 = 0.0;
@@ -654,6 +656,11 @@ __global__ void k_loo_column(const double* num, const double* hs, const double* 
     if (is_clf && ((yi > 0 && e > 0) || (yi < 0 && e < 0))) e = 0.0;
     loo_res[i] = e;
     loo_lev[i] = lev;
+    {
+      double r = num[i * Gp + g] - yi;
+      if (is_clf && ((yi > 0 && r > 0) || (yi < 0 && r < 0))) r = 0.0;
+      res[i] = r;
+    }
     const double sh = si * h;
     loo_std[i] = sqrt(h + sh * sh / (1.0 - lev));
     const double yl = yi + e_raw;

@@ -714,7 +714,7 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
   const int G = a->G, is_clf = a->is_classifier ? 1 : 0;
   NLSCHK(upload_map(ctx, a->shift, a->scale, a->B, a->d, a->D, &st.mp));
   const MapParams& mp = st.mp;
-  const int D = mp.D, D1 = mp.D1, Kf = mp.Kf, Np = mp.Np;
+  const int D1 = mp.D1, Kf = mp.Kf, Np = mp.Np;
   const int Gp = (int)round_up(G, BN);
   NLSCHK(primal_prepare(ctx, st, a->X, a->y, a->s, n, a->d));
   const size_t fixed = 2ull * st.n_pad * Gp * 8 + 6ull * D1 * D1 * 16 + 2ull * Kf * Np * 8 + (size_t)Np * Gp * 8;
@@ -921,7 +921,7 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
   {
     SpanGuard g(ctx, NLS_T_LOO);
     hipLaunchKernelGGL(k_loo_column, dim3((unsigned)cblk), dim3(256), 0, ctx->stream, num, hs, st.dy, st.s_norm, n, Gp, opt, is_clf,
-                       ybar, loo_res, loo_lev, loo_std, cpart);
+                       ybar, loo_res, loo_lev, loo_std, res, cpart);
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, ctx->stream, cpart, cblk, 2L, csum, 0);
     HIPCHK(ctx, hipGetLastError());
   }
@@ -935,12 +935,9 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
   // ---- P8: re-solve at gamma* -------------------------------------------------------------------
   // beta = Q (v / (gamma* + lam)) from the eigendecomposition (exactly (gamma* C + A)^-1 b: A + gamma c I = c Q (Lam + gamma) Q^H): no
   // factorisation on the critical path.  The Cholesky factor (_neo_ls_svm.py:176-178) is only an OUTPUT (L_): when the caller asks for it,
-  // zpotrf and the 16 (D+1)^2-byte download run on a side stream beside the residual pass; a->L == NULL skips both.
+  // zpotrf and the 16 (D+1)^2-byte download run on a side stream beside beta and the outputs of the main stream; a->L == NULL skips both.
   double2* dbeta = nullptr;
-  double *br = nullptr, *bi = nullptr;
   NLSCHK(ws_get_t(ctx, "chol.beta", (size_t)D1, &dbeta));
-  NLSCHK(ws_get_t(ctx, "chol.br", (size_t)Kf, &br));
-  NLSCHK(ws_get_t(ctx, "chol.bi", (size_t)Kf, &bi));
   rocblas_int* dinfo2 = nullptr;
   bool side = false;
   struct SideJoin {  // an early (error) return must not leave the side stream writing into the caller's L
@@ -987,27 +984,11 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
     hipLaunchKernelGGL(k_beta_evd_partial, dim3((unsigned)((D1 + 63) / 64), (unsigned)nchunks), dim3(256), 0, ctx->stream, Qev_keep, (long)D1, D1, rb.vr, rb.vi,
                        lam, gamma_opt, bpart);
     hipLaunchKernelGGL(k_beta_evd_finish, dim3((unsigned)((D1 + 255) / 256)), dim3(256), 0, ctx->stream, bpart, nchunks, D1, dbeta);
-    hipLaunchKernelGGL(k_split_vec, dim3((unsigned)((Kf + 255) / 256)), dim3(256), 0, ctx->stream, dbeta, D, Kf, br, bi);
     HIPCHK(ctx, hipGetLastError());
   }
 
-  // ---- residuals_ = Re(phi beta) - y (P8) -------------------------------------------------------
-  for (long r0 = 0; r0 < n; r0 += st.rc) {
-    const long rows = std::min<long>(st.rc, n - r0);
-    const long rows_pad = round_up(rows, BM);
-    if (!st.resident) {
-      SpanGuard g(ctx, NLS_T_FEATUREMAP);
-      NLSCHK(launch_featuremap_planes(ctx, mp, st.dX + r0 * mp.d, rows, rows_pad, st.rs + r0, st.Fc, st.Fs));
-      tm[NLS_T_FEATUREMAP_LAUNCHES] += 1;
-      tm[NLS_T_FEATUREMAP_FLOPS] += 2.0 * rows * mp.d * mp.D;
-    }
-    {
-      SpanGuard g(ctx, NLS_T_RESIDUALS);
-      hipLaunchKernelGGL(k_plane_gemv, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, planes_c(st, r0), planes_s(st, r0), Kf,
-                         br, bi, dbeta, D, rows, st.dy + r0, is_clf, res + r0, st.inv_rs + r0);
-      HIPCHK(ctx, hipGetLastError());
-    }
-  }
+  // residuals_ = Re(phi beta) - y (P8) came out of k_loo_column: the sweep's table holds Re(phi beta(gamma)) on the whole grid (round 2 made another
+  // pass over the feature planes for it - 11 ms at c3, and a second feature map when the planes are not resident).
 
   // ---- outputs ---------------------------------------------------------------------------------
   {

@@ -54,6 +54,8 @@ struct nls_ctx {
   double* sintab = nullptr;        // device copy of the feature map's (sin, cos) table (nls_sincos.h), built at context creation
   hipStream_t stream2 = nullptr;   // side stream (created on first use): the Cholesky factor L_ and its download run beside the residual pass
   rocblas_handle blas2 = nullptr;
+  hipStream_t copy_stream = nullptr;  // block columns of a Cholesky factor travel to the host on it while the rest is still being factored
+  std::vector<hipEvent_t> blk_ev;     // one event per finished block column
   hipEvent_t side_ev[4] = {nullptr, nullptr, nullptr, nullptr};  // fork, potrf done, download done (timing of the side stream)
   std::string err;
   std::map<std::string, DevBuf> ws;  // grow-only named workspace
@@ -328,6 +330,50 @@ static int download_factor(nls_ctx* ctx, void* host, const void* dev, int n, lon
                                  hipMemcpyDeviceToHost, stream));
   }
   return NLS_OK;
+}
+
+// Pipelined download of a Cholesky factor: the factorisation records blk_ev[b] on its own stream when block column b (columns b nbk ...) is final
+// and no longer read; the copy stream then (optionally conjugates and) sends rows b nbk .. n of those columns - the defined triangle only - while the
+// following block columns are still being factored.  Into pageable memory each copy blocks the calling thread until it is done: issue these
+// AFTER everything else has been enqueued (the thread would wait for the result anyway).
+static int ensure_copy_stream(nls_ctx* ctx, int nblk) {
+  if (!ctx->copy_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+  while ((int)ctx->blk_ev.size() < nblk) {
+    hipEvent_t e = nullptr;
+    HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    ctx->blk_ev.push_back(e);
+  }
+  return NLS_OK;
+}
+__global__ void k_conj_block(double2* A, long ld, long r0, long c0, long rows, long cols) {
+  const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (idx >= rows * cols) return;
+  double2* p = A + (r0 + idx % rows) + (c0 + idx / rows) * ld;
+  p->y = -p->y;
+}
+static int download_block_columns(nls_ctx* ctx, void* host, void* dev, int n, long ld_dev, size_t elem_bytes, int nbk, bool conj) {
+  const int nblk = (n + nbk - 1) / nbk;
+  const size_t spitch = (size_t)ld_dev * elem_bytes, dpitch = (size_t)n * elem_bytes;
+  for (int b = 0; b < nblk; ++b) {
+    const long k0 = (long)b * nbk, w = std::min<long>(nbk, n - k0), rows = n - k0;
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->blk_ev[b], 0));
+    if (conj) {
+      hipLaunchKernelGGL(k_conj_block, dim3((unsigned)((rows * w + 255) / 256)), dim3(256), 0, ctx->copy_stream, static_cast<double2*>(dev), ld_dev, k0, k0, rows, w);
+      HIPCHK(ctx, hipGetLastError());
+    }
+    HIPCHK(ctx, hipMemcpy2DAsync(static_cast<char*>(host) + ((size_t)k0 + (size_t)k0 * n) * elem_bytes, dpitch,
+                                 static_cast<const char*>(dev) + ((size_t)k0 + (size_t)k0 * ld_dev) * elem_bytes, spitch, (size_t)rows * elem_bytes, (size_t)w,
+                                 hipMemcpyDeviceToHost, ctx->copy_stream));
+  }
+  return NLS_OK;
+}
+// infos[b] (relative to block b, 0 = fine) -> out = the first failure as a global 1-based index
+__global__ void k_merge_block_info(const int* infos, int nblk, int nbk, int* out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int r = 0;
+  for (int b = 0; b < nblk && r == 0; ++b)
+    if (infos[b] != 0) r = b * nbk + infos[b];
+  *out = r;
 }
 
 static int check_info(nls_ctx* ctx, rocblas_int* dinfo, const char* what) {

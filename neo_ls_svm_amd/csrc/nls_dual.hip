@@ -14,11 +14,13 @@ constexpr size_t SMEM_REAL_D = 2 * 2 * TILE_DOUBLES * sizeof(double);
 
 // A = L L^T in place (lower, column-major): nls_potrf.h; NLS_POTRF=rocsolver takes rocsolver_dpotrf instead (diagnostic).  info: device word,
 // 0 or the 1-based index of the first non-positive pivot.
-static int potrf_lower_real(nls_ctx* ctx, double* A, int n, long lda, rocblas_int* dinfo) {
+static int potrf_lower_real(nls_ctx* ctx, double* A, int n, long lda, rocblas_int* dinfo, int event_cols = 0) {
   using namespace potrf;
   const char* m = std::getenv("NLS_POTRF");
   if (m && std::string(m) == "rocsolver") {
     BLASCHK(ctx, rocsolver_dpotrf(ctx->blas, rocblas_fill_lower, (rocblas_int)n, A, (rocblas_int)lda, dinfo));
+    if (event_cols > 0)
+      for (int b = 0; b < (n + event_cols - 1) / event_cols; ++b) HIPCHK(ctx, hipEventRecord(ctx->blk_ev[b], ctx->stream));
     return NLS_OK;
   }
   double* Sinv = nullptr;
@@ -42,6 +44,8 @@ static int potrf_lower_real(nls_ctx* ctx, double* A, int n, long lda, rocblas_in
                          lda);
     }
     HIPCHK(ctx, hipGetLastError());
+    // event_cols > 0 (a multiple of NB): block column b of that width is final and no longer read once its last panel's update has run
+    if (event_cols > 0 && ((k0 + NB) % event_cols == 0 || k0 + NB >= n)) HIPCHK(ctx, hipEventRecord(ctx->blk_ev[k0 / event_cols], ctx->stream));
   }
   return NLS_OK;
 }
@@ -280,6 +284,13 @@ extern "C" int nls_dual_fit(nls_ctx* ctx, const nls_dual_fit_args* a) {
 
   // ---- D5: Cholesky re-solve, residuals, sigma -----------------------------------------------------
   double* M2 = Q;  // n x n with leading dimension n_pad; Q (n_pad x n_pad) is dead
+  bool pipelined_L = false;
+  struct CopyJoin {  // an early (error) return must not leave the copy stream writing into the caller's L
+    hipStream_t s = nullptr;
+    ~CopyJoin() {
+      if (s) (void)hipStreamSynchronize(s);
+    }
+  } copy_join;
   // alpha(gamma*) = M^-1 y = sn W (gamma* + Lam)^-1 W^T sn y is the selected column of AG, which the sweep has already formed for the whole
   // grid (_neo_ls_svm.py:313-316 solve it with the Cholesky factor: two n x n triangular solves, 10.6 ms at n = 10^4).  The factorisation
   // itself only produces the L_ output and is skipped when the caller does not ask for it.
@@ -291,7 +302,15 @@ extern "C" int nls_dual_fit(nls_ctx* ctx, const nls_dual_fit_args* a) {
     HIPCHK(ctx, hipGetLastError());
     // own factorisation (nls_potrf.h): 24.7 ms at n = 10^4 against rocsolver_dpotrf's 42.5 (a blocked variant on rocBLAS trsm / syrk with
     // rocSOLVER leaves had given 49.7 against 52.7 with the triangular solves still inside)
-    NLSCHK(potrf_lower_real(ctx, M2, (int)n, n_pad, dinfo));  // leading dimension n_pad: the rank-128 update reads whole 128-row blocks
+    // (leading dimension n_pad: the rank-128 update reads whole 128-row blocks.)  Into page-locked memory the finished block columns of 512
+    // travel on the copy stream while the following ones are factored; pageable outputs are downloaded afterwards in one piece.
+    pipelined_L = pinL.p != nullptr;
+    if (pipelined_L) {
+      NLSCHK(ensure_copy_stream(ctx, (int)((n + 511) / 512)));
+      copy_join.s = ctx->copy_stream;
+    }
+    NLSCHK(potrf_lower_real(ctx, M2, (int)n, n_pad, dinfo, pipelined_L ? 512 : 0));
+    if (pipelined_L) NLSCHK(download_block_columns(ctx, a->L, M2, (int)n, n_pad, sizeof(double), 512, false));
     NLSCHK(check_info(ctx, dinfo, "Cholesky factorisation (potrf)"));
   }
   {
@@ -315,7 +334,8 @@ extern "C" int nls_dual_fit(nls_ctx* ctx, const nls_dual_fit_args* a) {
     NLSCHK(d2h(a->loo_std, sig, sizeof(double) * n));
     NLSCHK(d2h(a->residuals, res, sizeof(double) * n));
     // Column-major lower Cholesky factor == row-major upper factor U (M2 = U^T U): scipy's lower=False layout.
-    if (a->L) NLSCHK(download_factor(ctx, a->L, M2, (int)n, n_pad, sizeof(double), ctx->stream, pinL.p != nullptr));
+    if (a->L && !pipelined_L) NLSCHK(download_factor(ctx, a->L, M2, (int)n, n_pad, sizeof(double), ctx->stream, false));
+    if (pipelined_L) HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));
   }
   NLSCHK(spans_collect(ctx, tm));
   if (a->loo_errors) std::memcpy(a->loo_errors, herrs.data(), sizeof(double) * G);

@@ -373,7 +373,8 @@ def main():
                                          allreduce_sum=allreduce_sum if world > 1 else None)  # fmt: skip
             best = g["best"] or {}
             return {"opt": g["gamma_index"], "sigma_index": g["sigma_index"], "loo_score": best.get("loo_score"), "timings": g["timings"]}
-        return hp.primal_fit(X_, y_, s_, shift, scale, B, False, gammas=gammas, ctx=ctx)
+        # row-sharded fit: every rank ends with the same beta / lam / curve; the factor L_ (an output only) is produced and downloaded by rank 0
+        return hp.primal_fit(X_, y_, s_, shift, scale, B, False, gammas=gammas, ctx=ctx, want_L=(rank == 0))
 
     for _ in range(args.warmup):
         step()

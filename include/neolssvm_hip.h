@@ -150,6 +150,9 @@ int nls_eigh_only(nls_ctx* ctx, void* A, int n, int is_complex, double* lam);
  * nls_twostage_rescues: eigendecompositions of this context whose band reduction met a panel it could not orthogonalise (columns dependent to
  * working precision) and went through at the second attempt, every panel perturbed by 1e-13 of its norm (csrc/nls_sb.h, k_sb_perturb);
  * nls_twostage_fallbacks: those that failed again (zero panels) and fell back from the two-stage to the one-stage reduction. */
+/* The dual fit's own Cholesky factorisation (csrc/nls_potrf.h; cho_factor(gamma* diag(sn^-2) + K), _neo_ls_svm.py:313-314) on host data (tests,
+ * profiling): A (n x n column-major doubles, lower triangle) is overwritten by L; *info = 0 or the 1-based index of the first non-positive pivot. */
+int nls_cholesky_only(nls_ctx* ctx, double* A, int n, int* info);
 int nls_twostage_stage(nls_ctx* ctx, int stage, void* A, int n, int is_complex, int bw, void* aux, double* d, double* e, int ncols,
                        int* info);
 long nls_twostage_fallbacks(const nls_ctx* ctx);

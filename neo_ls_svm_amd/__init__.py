@@ -19,6 +19,7 @@ from .hotpath import (  # noqa: F401
     primal_predict,
     rotate,
     tridiagonalize,
+    cholesky,
     twostage_stage,
 )
 
@@ -46,5 +47,6 @@ __all__ = [
     "exact_complexity_matrix",
     "eigh",
     "tridiagonalize",
+    "cholesky",
     "twostage_stage",
 ]

@@ -151,6 +151,7 @@ SIGNATURES = {
     "nls_tridiag_only": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nls_eigh_only": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "nls_twostage_stage": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "nls_cholesky_only": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "nls_twostage_fallbacks": (C.c_long, [C.c_void_p]),
     "nls_twostage_rescues": (C.c_long, [C.c_void_p]),
     "nls_primal_fit": (C.c_int, [C.c_void_p, C.POINTER(PrimalFitArgs)]),

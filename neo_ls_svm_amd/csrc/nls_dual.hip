@@ -94,6 +94,29 @@ int rbf_block(nls_ctx* ctx, const double* Xa_pad, const double* XbT_pad, const d
 
 }  // namespace
 
+// Hook (tests / profiling): the dual path's own Cholesky factorisation on host data.  A: n x n column-major, lower triangle in, L out (the strict
+// upper triangle is returned as it came); *info = 0 or the 1-based index of the first non-positive pivot (the factor is then garbage).
+extern "C" int nls_cholesky_only(nls_ctx* ctx, double* A, int n, int* info) {
+  if (!ctx) return NLS_ERR_ARG;
+  if (!A || !info || n < 1) return fail(ctx, NLS_ERR_ARG, "nls_cholesky_only: null pointer or n < 1");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const long ld = round_up(n, BM);
+  double* dA = nullptr;
+  rocblas_int* dinfo = nullptr;
+  NLSCHK(ws_get_t(ctx, "hook.chol", (size_t)ld * ld, &dA));
+  NLSCHK(ws_get_t(ctx, "chol.info", 4, &dinfo));
+  HIPCHK(ctx, hipMemsetAsync(dA, 0, sizeof(double) * (size_t)ld * ld, ctx->stream));
+  HIPCHK(ctx, hipMemcpy2DAsync(dA, sizeof(double) * ld, A, sizeof(double) * n, sizeof(double) * n, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  BLASCHK(ctx, rocblas_set_stream(ctx->blas, ctx->stream));
+  NLSCHK(potrf_lower_real(ctx, dA, n, ld, dinfo));
+  rocblas_int hinfo = 0;
+  HIPCHK(ctx, hipMemcpy2DAsync(A, sizeof(double) * n, dA, sizeof(double) * ld, sizeof(double) * n, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(&hinfo, dinfo, sizeof(hinfo), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  *info = (int)hinfo;
+  return NLS_OK;
+}
+
 extern "C" int nls_dual_fit(nls_ctx* ctx, const nls_dual_fit_args* a) {
   if (!ctx) return NLS_ERR_ARG;
   if (!a) return fail(ctx, NLS_ERR_ARG, "args is NULL");

@@ -196,6 +196,22 @@ def eigh(A, ctx: Context | None = None):
     return lam, Af
 
 
+def cholesky(A, ctx: Context | None = None):
+    """Lower Cholesky factor of a real symmetric positive definite matrix by the dual path's own factorisation (test / profiling hook,
+    ``nls_cholesky_only``); raises ``numpy.linalg.LinAlgError`` with the index of the first non-positive pivot, as ``numpy.linalg.cholesky`` would."""
+    ctx = ctx or default_context()
+    A = np.asarray(A, dtype=np.float64)
+    if A.ndim != 2 or A.shape[0] != A.shape[1] or A.shape[0] < 1:
+        raise ValueError("A must be a non-empty square matrix")
+    n = A.shape[0]
+    Af = np.asfortranarray(np.tril(A))
+    info = C.c_int(0)
+    ctx._check(ctx.lib.nls_cholesky_only(ctx.handle, Af.ctypes.data, n, C.byref(info)))
+    if info.value != 0:
+        raise np.linalg.LinAlgError(f"matrix is not positive definite: pivot {info.value} <= 0")
+    return np.tril(Af)
+
+
 def twostage_stage(stage: int, A, bw: int, aux=None, ctx: Context | None = None):
     """One stage of the two-stage reduction behind ``eigh`` on host data (test / profiling hook, ``nls_twostage_stage``):
     1: dense -> band ``(A_out, tau1, failed, columns_reduced)``; 2: band -> tridiagonal ``(d, e, V2, timed_out)``;

@@ -89,17 +89,44 @@ def _blas_info():
         return os.cpu_count(), "unknown"
 
 
-def cpu_baseline(cfg, shift, scale, B, gammas):
-    """The oracle (NumPy restatement of the reference's algorithm, ``kind: port``) timed on this box's host cores.
+def _parity(gpu, ref, rows):
+    """BASELINE.json's second metric half: GPU fit against the float64 oracle fit on the SAME rows -
+    max |e - e_ref| / max |e_ref| on ``loo_residuals_`` at the reference's argmin, ||beta - beta_ref|| / ||beta_ref||,
+    max-rel on the whole per-gamma error curve (``_neo_ls_svm.py:146-167``).  Bar: 1e-5."""
+    import numpy as np
 
-    * Mode S ("simplified, row-streamed schedule" = what the HIP library implements) on a bounded row sample of the
-      workload at full d, D, G, scaled to n rows, PLUS the n-independent ``eigh`` / ``cho_factor`` measured at full size.
+    def mx(a, b):
+        return float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(float(np.max(np.abs(b))), 1e-300))
+
+    return {
+        "rows": int(rows),
+        "argmin_equal": bool(gpu["opt"] == ref["opt"]),
+        "argmin_gpu_ref": [int(gpu["opt"]), int(ref["opt"])],
+        "loo_residuals_max_rel_err": mx(gpu["loo_residuals"], ref["loo_residuals"]),
+        "beta_rel_err": float(np.linalg.norm(gpu["beta"] - ref["beta"]) / np.linalg.norm(ref["beta"])),
+        "loo_errors_max_rel_err": mx(gpu["loo_errors_gammas"], ref["loo_errors_gammas"]),
+        "loo_leverage_max_rel_err": mx(gpu["loo_leverage"], ref["loo_leverage"]),
+        "loo_std_max_rel_err": mx(gpu["loo_std"], ref["loo_std"]),
+        "residuals_max_rel_err": mx(gpu["residuals"], ref["residuals"]),
+        "bar": 1e-5,
+    }
+
+
+def cpu_baseline(cfg, shift, scale, B, gammas, gpu_fit, gpu_full=None):
+    """The oracle (NumPy restatement of the reference's algorithm, ``kind: port``) timed on this box's host cores, and the
+    parity of the GPU fit against it on the same rows.
+
     * Where the reference's own schedule fits host RAM (n (D+1) 16 B of phi and its five zgemm-class products: c2),
-      Mode R (``primal_fit_faithful``, the schedule of ``_neo_ls_svm.py:112-187``) and Mode S are both run at FULL size.
-    BLAS threads are pinned with threadpoolctl and stated.
+      Mode R (``primal_fit_faithful``, the schedule of ``_neo_ls_svm.py:112-187``) and Mode S (``primal_fit_streamed``, the
+      simplified row-streamed schedule the HIP library implements) are both run at FULL size; parity = the timed GPU
+      step's outputs (``gpu_full``) against Mode S on all rows.
+    * Otherwise (c3 / c5: phi alone is 65.5 GB) a REAL oracle fit - ``primal_fit_streamed``: feature map, Gram, ``eigh`` of the
+      (D+1)^2 matrix, rotation, full gamma sweep, selection, ``cho_factor`` / ``cho_solve`` - runs on a bounded row sample of the
+      workload at full d, D, G; its n-proportional stage times are scaled to n rows and the n-independent ``eigh`` /
+      Cholesky added unscaled; parity = ``gpu_fit(X, y, s)`` on the same sample against that oracle fit.
+    BLAS threads are pinned with threadpoolctl and stated.  Returns (cpu_baseline dict, parity dict).
     """
     import numpy as np
-    import scipy.linalg as sla
     from threadpoolctl import threadpool_limits
 
     sys.path.insert(0, str(ROOT / "oracle"))
@@ -130,32 +157,42 @@ def cpu_baseline(cfg, shift, scale, B, gammas):
                 value_mode_S=1.0 / tS,
                 sample=f"all {n} rows, both schedules at full size; argmin R/S {rR['opt']}/{rS['opt']}",
             )
-            return out
+            g = gpu_full if gpu_full is not None and "loo_residuals" in gpu_full else gpu_fit(X, y, s, None)
+            if g["opt"] != rS["opt"]:
+                g = gpu_fit(X, y, s, int(rS["opt"]))
+            par = _parity(g, rS, n)
+            par["argmin_equal"] = bool((gpu_full or g)["opt"] == rS["opt"])
+            par["against"] = "oracle primal_fit_streamed on ALL rows of the timed workload"
+            return out, par
         n_s = min(n, 65_536)
         X, y = synth(n, d, 0, n_s)
-        t = orc.time_primal_row_stages(X, y, np.ones(n_s), shift, scale, B, gammas, row_tile=8192)
-        # n-independent serial section at full size: eigh of a (D+1)^2 Hermitian matrix and one Cholesky factorisation
-        rng = np.random.default_rng(1)
-        M = rng.standard_normal((D1, 2 * D1)) + 1j * rng.standard_normal((D1, 2 * D1))
-        A = M @ M.conj().T / (2 * D1)
+        s = np.ones(n_s)
+        tm = {}
         t0 = time.perf_counter()
-        sla.eigh(A)
-        t_evd = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        sla.cho_factor(A)
-        t_chol = time.perf_counter() - t0
-        est = t["seconds"] * n / n_s + t_evd + t_chol
+        o = orc.primal_fit_streamed(X, y, s, shift, scale, B, False, gammas=gammas, row_tile=8192, timings=tm)
+        t_fit = time.perf_counter() - t0
+        serial = tm.get("eigh", 0.0) + tm.get("cholesky", 0.0)  # n-independent: eigh of the (D+1)^2 matrix, cho_factor + cho_solve
+        est = (t_fit - serial) * n / n_s + serial
         out.update(
             value=1.0 / est,
-            mode="S (simplified row-streamed schedule), row sample scaled to n + eigh / cho_factor measured at full (D+1)",
-            sample=f"n-proportional stages (feature map x2, Gram, rotation, sweep, LOO) on the first {n_s} of {n} rows at full d, D, G: "
-            f"{t['seconds']:.2f} s, scaled x{n / n_s:.2f}; eigh({D1}) {t_evd:.2f} s + cho_factor {t_chol:.2f} s added unscaled",
+            mode="S (simplified row-streamed schedule): a real oracle fit on a row sample; row stages scaled to n, eigh / Cholesky unscaled",
+            sample=f"oracle primal_fit_streamed (feature map x3, Gram, eigh({D1}), rotation, sweep over G = {len(gammas)}, selection, "
+            f"cho_factor / cho_solve, residuals) on the first {n_s} of {n} rows at full d, D, G: {t_fit:.2f} s, of which eigh "
+            f"{tm.get('eigh', 0.0):.2f} s + Cholesky {tm.get('cholesky', 0.0):.2f} s do not scale with n; the rest x{n / n_s:.2f}",
             seconds_estimated=est,
-            stage_seconds={**{k: round(v, 3) for k, v in t["stages"].items()}, "eigh_full": round(t_evd, 3), "cho_factor_full": round(t_chol, 3)},
+            seconds_sample_fit=t_fit,
+            stage_seconds={k: round(v, 3) for k, v in tm.items()},
             note="the reference itself cannot run this size (phi alone is 65.5 GB); Mode R at the largest size it can run "
             "(c2) is in profiles/ (bench.py --config c2)",
         )
-    return out
+    g = gpu_fit(X, y, s, None)
+    argmin_equal = g["opt"] == o["opt"]
+    if not argmin_equal:
+        g = gpu_fit(X, y, s, int(o["opt"]))
+    par = _parity(g, o, n_s)
+    par["argmin_equal"] = bool(argmin_equal)
+    par["against"] = f"oracle primal_fit_streamed on the first {n_s} rows of the workload at full d, D, G (the same fit the cpu_baseline times)"
+    return out, par
 
 
 def synth_clf(n, d):
@@ -167,6 +204,39 @@ def synth_clf(n, d):
     w = rng.standard_normal(d) / np.sqrt(d)
     y01 = (X @ w + 0.3 * rng.standard_normal(n) > 0).astype(np.float64)
     return X, y01
+
+
+def end_to_end_fit(cfg, ctx, dual=False):
+    """Wall time of the user-visible ``NeoLSSVM.fit`` on the bench workload ("report end-to-end fit() separately"):
+    host X, y in; input validation, the supervised affine pre-step on ALL rows (AffineSeparator: GPU bin statistics + the
+    separator's small products; ORF frequency matrix), one upload, the solver call that ``value`` times, download of every
+    fitted attribute, the calibration split of ``_neo_ls_svm.py:405-441``.  The estimator runs on the bench's own context
+    (one fitting context per process and GPU).  One untimed call first (workspace arena), then the timed one."""
+    import neo_ls_svm_amd as hp
+    from neo_ls_svm_amd import _lib
+
+    n, d = cfg["n"], cfg["d"]
+    _lib.set_default_context(ctx)
+    if dual:
+        X, y01 = synth_clf(n, d)
+        y = y01
+        est = hp.NeoLSSVM(dual=True, device=ctx.device)
+    else:
+        X, y = synth(n, d, 0, n)
+        est = hp.NeoLSSVM(primal_feature_map=hp.OrthogonalRandomFourierFeatures(num_features=cfg["D"]), dual=False, device=ctx.device)
+    est.fit(X, y)
+    t0 = time.perf_counter()
+    est.fit(X, y)
+    t = time.perf_counter() - t0
+    return {
+        "seconds": t,
+        "fits_per_s": 1.0 / t,
+        "stage_seconds": {k: round(v, 4) for k, v in est.fit_wall_.items()},
+        "solver_seconds_inside": round(est.fit_timings_["total"], 4),
+        "gamma_index": int(list(est.γs_).index(est.γ_)) if est.γ_ in est.γs_ else None,
+        "note": "NeoLSSVM.fit(X, y) from host arrays, pre-step fitted on all rows (the timed solver step above uses the pre-step of the "
+        "first 2e5 rows, SURVEY 8(d)); second of two calls",
+    }
 
 
 def run_dual(args, cfg):
@@ -267,7 +337,7 @@ def run_dual(args, cfg):
                 k: round(1e3 * stage.get(k, 0.0) / args.steps, 3)
                 for k in ("upload", "gram", "evd", "rotate", "sweep", "loo", "cholesky", "residuals", "download", "total")
             },
-            "evd_stage_ms": ctx.evd_stage_ms() if hasattr(ctx, "evd_stage_ms") else None,
+            "evd_stage_ms": ctx.evd_stage_ms(),
         }
         if not args.no_cpu_baseline and world == 1:
             from threadpoolctl import threadpool_limits
@@ -288,8 +358,27 @@ def run_dual(args, cfg):
                 "argmin_cpu_gpu": [int(o["opt"]), int(r["opt"])],
                 "gpu_over_cpu": (args.steps / elapsed) * tc,
             }  # fmt: skip
+            g = r if r["opt"] == o["opt"] else hp.dual_fit(Xt, y, s, True, gammas=gammas, gamma_index=int(o["opt"]), ctx=ctx)
+
+            def mx(a, b):
+                return float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(float(np.max(np.abs(b))), 1e-300))
+
+            out["parity"] = {  # _neo_ls_svm.py:270-323: the GPU fit against the oracle's fit on all rows
+                "rows": n, "argmin_equal": bool(r["opt"] == o["opt"]), "argmin_gpu_ref": [int(r["opt"]), int(o["opt"])],
+                "loo_residuals_max_rel_err": mx(g["loo_residuals"], o["loo_residuals"]),
+                "alpha_rel_err": float(np.linalg.norm(g["alpha"] - o["alpha"]) / np.linalg.norm(o["alpha"])),
+                "loo_errors_max_rel_err": mx(g["loo_errors_gammas"], o["loo_errors_gammas"]),
+                "loo_std_max_rel_err": mx(g["loo_std"], o["loo_std"]),
+                "residuals_max_rel_err": mx(g["residuals"], o["residuals"]),
+                "bar": 1e-5, "against": "oracle dual_fit_reduced on ALL rows of the timed workload",
+            }  # fmt: skip
         else:
             out["cpu_baseline"] = None
+            out["parity"] = None
+        if world == 1 and not args.no_end_to_end:
+            ctx.release_workspace()
+            out["end_to_end"] = end_to_end_fit(cfg, ctx, dual=True)
+            out["value_end_to_end"] = out["end_to_end"]["fits_per_s"]
         print(json.dumps(out), flush=True)
     if cctx is not None:
         cctx.close()
@@ -323,6 +412,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the NeoLSSVM.fit wall-time leg (pre-step + solver + calibration split)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -405,15 +495,29 @@ def main():
         rot_alg_tflops = stage["rotate_flops"] / max(stage["rotate"], 1e-12) / 1e12
         # Traffic past L2 comes from separate rocprofv3 PMC passes (it cannot be read live); per row because every launch
         # streams (rows x panels) with the same reuse pattern.
-        traffic = k1_traffic = None
-        for name in ("r02_pmc_summary.json", "r01b_pmc_summary.json"):
+        traffic = k1_traffic = traffic_src = None
+        try:  # this round's passes (tools/pmc_passes_r04.sh -> profiles/r04_pmc_summary.json, same layout as r02's)
+            pmc = json.loads((ROOT / "profiles" / "r04_pmc_summary.json").read_text())
+            pr = pmc["k_rotate3"]
+            if pr["D"] == D and pr["d"] == d:
+                traffic = (pr["fetch_bytes_x2"] + pr["write_bytes"]) * (rot_rows / rot_launches) / pr["rows_per_launch"]
+                traffic_src = "profiles/r04_pmc_summary.json"
+            pk = pmc.get("k_featuremap")
+            if pk and pk["D"] == D and pk["d"] == d:
+                k1_traffic = pk["hbm_bytes_per_row"]
+        except Exception:
+            pass
+        if traffic is None and D == 4096 and d == 128:
+            try:  # round 3's passes of the XCD-patch order that is the default now (8 x 5 at D = 4096): 333 440 rows per launch
+                pr = json.loads((ROOT / "profiles" / "r03_pmc_rotate.json").read_text())["p8x5"]["k_rotate3"]
+                traffic = (pr["fetch_bytes_x2_per_launch"] + pr["write_bytes_per_launch"]) * (rot_rows / rot_launches) / 333440.0
+                traffic_src = "profiles/r03_pmc_rotate.json (p8x5)"
+            except Exception:
+                pass
+        if k1_traffic is None:
             try:
-                pmc = json.loads((ROOT / "profiles" / name).read_text())
-                pr = pmc["k_rotate3"]
-                if traffic is None and pr["D"] == D and pr["d"] == d:
-                    traffic = (pr["fetch_bytes_x2"] + pr["write_bytes"]) * (rot_rows / rot_launches) / pr["rows_per_launch"]
-                pk = pmc.get("k_featuremap")
-                if k1_traffic is None and pk and pk["D"] == D and pk["d"] == d:
+                pk = json.loads((ROOT / "profiles" / "r02_pmc_summary.json").read_text()).get("k_featuremap")
+                if pk and pk["D"] == D and pk["d"] == d:
                     k1_traffic = pk["hbm_bytes_per_row"]
             except Exception:
                 pass
@@ -451,6 +555,9 @@ def main():
                 "affine": f"package pre-step (AffineSeparator + ORF RandomState 42) fitted on the first {min(n, PRESTEP_PREFIX)} rows (SURVEY 8d)",
                 "gamma_index": r["opt"],
                 "loo_score": r["loo_score"],
+                "generator": "SURVEY 8(d) (X ~ N(0,1), w ~ N(0,1)/sqrt(d), y = sin(Xw) + 0.1 eps) with w from default_rng(0) and the rows of "
+                "block k (65 536 rows) from the child stream default_rng([0, k]) - not the single default_rng(0) stream - so that a rank "
+                "generates just its shard",
             },
             "roofline": {
                 "kernel": "k_rotate3",
@@ -460,7 +567,9 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": rot_exec_tflops / FP64_MFMA_PEAK_TFLOPS,
                 "traffic": traffic,
-                "traffic_unit": "bytes/launch beyond L2 (2 x FETCH_SIZE + WRITE_SIZE, Infinity-Cache hits included), profiles/*_pmc_summary.md",
+                "traffic_unit": "bytes/launch beyond L2 (2 x FETCH_SIZE + WRITE_SIZE, Infinity-Cache hits included), from separate rocprofv3 --pmc passes",
+                "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": (rot_rows / rot_launches) * 16.0 * (Kf + Np) + 16.0 * Kf * Np,
                 "note": "achieved = EXECUTED MFMA flops (3M complex product: 6 rows Kf Np, Kf = ceil(D/128)*128, Np = ceil((D+1)/64)*64) / kernel "
                 "time, so frac is the matrix-pipe utilisation; the algorithmic 8 rows (D+1)^2 of the four-product form is reported beside it",
                 "algorithmic_tflops": rot_alg_tflops,
@@ -486,13 +595,24 @@ def main():
                 k: round(1e3 * stage.get(k, 0.0) / args.steps, 3)
                 for k in ("upload", "featuremap", "gram", "allreduce", "evd", "rotate", "sweep", "loo", "cholesky", "residuals", "download", "total")
             },
+            "evd_stage_ms": ctx.evd_stage_ms(),
         }
         if not args.no_cpu_baseline and world == 1:
             ctx.release_workspace()
-            out["cpu_baseline"] = cpu_baseline(cfg, shift, scale, B, gammas)
+
+            def gpu_fit(Xh, yh, sh, gamma_index):
+                return hp.primal_fit(Xh, yh, sh, shift, scale, B, False, gammas=gammas, gamma_index=gamma_index, ctx=ctx)
+
+            out["cpu_baseline"], out["parity"] = cpu_baseline(cfg, shift, scale, B, gammas, gpu_fit, None if grid_mode else r)
             out["cpu_baseline"]["gpu_over_cpu"] = out["value"] * (cfg.get("sigmas", 1)) / out["cpu_baseline"]["value"]
         else:
             out["cpu_baseline"] = None
+            out["parity"] = None
+        if world == 1 and not args.no_end_to_end:
+            ctx.release_workspace()
+            out["end_to_end"] = None if grid_mode else end_to_end_fit(cfg, ctx)
+            if out["end_to_end"]:
+                out["value_end_to_end"] = out["end_to_end"]["fits_per_s"]
         print(json.dumps(out), flush=True)
     if cctx is not None and cctx is not ctx:
         cctx.close()

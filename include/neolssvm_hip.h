@@ -157,6 +157,12 @@ int nls_twostage_stage(nls_ctx* ctx, int stage, void* A, int n, int is_complex, 
                        int* info);
 long nls_twostage_fallbacks(const nls_ctx* ctx);
 long nls_twostage_rescues(const nls_ctx* ctx);
+/* Stage times (milliseconds, HIP events on the library's stream) of the context's most recent eigendecomposition (P4 `_neo_ls_svm.py:120`,
+ * D2 `:265`).  out[0..7] = {reduction to tridiagonal form (one-stage panel) or to band form (two-stage), bulge chase (two-stage only, else 0),
+ * tridiagonal eigensolver (stedc, incl. its broadcast in a collective fit), second back-transformation Q2 (two-stage only, else 0), first
+ * back-transformation Q1, their sum, n, kind} with kind = 1: one-stage real, 2: one-stage complex, 3: two-stage real, 4: two-stage complex,
+ * 5: rocSOLVER heevd / syevd in one call (only the sum is filled), 0: no eigendecomposition has run (returns NLS_ERR_ARG). */
+int nls_evd_stage_ms(nls_ctx* ctx, double* out8);
 
 /* ---- primal fit ------------------------------------------------------------------------------- */
 typedef struct nls_primal_fit_args {
@@ -206,11 +212,11 @@ typedef struct nls_primal_fit_args {
 #define NLS_T_FEATUREMAP 2   /* all K1 launches                                  */
 #define NLS_T_GRAM 3         /* K2 launches incl. slab reduction                 */
 #define NLS_T_ALLREDUCE 4
-#define NLS_T_EVD 5          /* rocsolver_zheevd + assembly                      */
+#define NLS_T_EVD 5          /* assembly of A / c + eigendecomposition (own tridiagonalisation, stedc, back-transformation) + rotation planes */
 #define NLS_T_ROTATE 6       /* K4: P = phi Q with fused |P|^2, Re(P v) epilogue  */
 #define NLS_T_SWEEP 7        /* K5: the two gamma-sweep GEMMs                     */
 #define NLS_T_LOO 8          /* LOO residual epilogue + weighted reductions       */
-#define NLS_T_CHOLESKY 9     /* zpotrf + zpotrs                                   */
+#define NLS_T_CHOLESKY 9     /* the Cholesky factor L_ (side stream) + the re-solve beta = cho_solve(L_, b)      */
 #define NLS_T_RESIDUALS 10   /* Re(phi beta) - y                                  */
 #define NLS_T_DOWNLOAD 11
 #define NLS_T_ROTATE_LAUNCHES 12 /* number of K4 launches (for the per-launch roofline)       */

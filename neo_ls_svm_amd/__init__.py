@@ -4,7 +4,7 @@ Host code is Python + NumPy marshalling over a ctypes C ABI (``include/neolssvm_
 hand-written HIP kernels for gfx950 plus rocSOLVER for the dense EVD / Cholesky.  No CPU fallback.
 """
 
-from ._lib import Context, DeviceArray, Factor, NlsError, default_context, load_library  # noqa: F401
+from ._lib import Context, DeviceArray, Factor, NlsError, default_context, load_library, set_default_context  # noqa: F401
 from .hotpath import (  # noqa: F401
     dual_fit,
     dual_predict,
@@ -23,12 +23,23 @@ from .hotpath import (  # noqa: F401
     twostage_stage,
 )
 
-from .estimator import AffineSeparator, NeoLSSVM, OrthogonalRandomFourierFeatures  # noqa: E402,F401
+from .estimator import (  # noqa: E402,F401
+    AffineFeatureMap,
+    AffineNormalizer,
+    AffineSeparator,
+    NeoLSSVM,
+    OrthogonalRandomFourierFeatures,
+    RandomFourierFeatures,
+)
 
 __all__ = [
     "NeoLSSVM",
     "OrthogonalRandomFourierFeatures",
+    "RandomFourierFeatures",
     "AffineSeparator",
+    "AffineNormalizer",
+    "AffineFeatureMap",
+    "set_default_context",
     "Context",
     "DeviceArray",
     "Factor",

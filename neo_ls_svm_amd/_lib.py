@@ -154,6 +154,7 @@ SIGNATURES = {
     "nls_cholesky_only": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "nls_twostage_fallbacks": (C.c_long, [C.c_void_p]),
     "nls_twostage_rescues": (C.c_long, [C.c_void_p]),
+    "nls_evd_stage_ms": (C.c_int, [C.c_void_p, C.c_void_p]),
     "nls_primal_fit": (C.c_int, [C.c_void_p, C.POINTER(PrimalFitArgs)]),
     "nls_sweep_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
     "nls_primal_predict": (
@@ -296,7 +297,6 @@ class Factor:
         h = C.c_void_p()
         ctx._check(ctx.lib.nls_factor_create(ctx.handle, L.ctypes.data, self.D, C.byref(h)))
         self.handle = h
-        self.comm_world = 1  # world size of the native communicator this context has joined (1: none or one rank)
 
     def close(self):
         if getattr(self, "handle", None) and getattr(self.ctx, "handle", None):
@@ -385,6 +385,29 @@ class Context:
     def comm_barrier(self):
         self.comm_allreduce([0.0])
 
+    _EVD_KINDS = {1: "one-stage real", 2: "one-stage complex", 3: "two-stage real", 4: "two-stage complex", 5: "rocsolver heevd / syevd"}
+
+    def evd_stage_ms(self) -> dict | None:
+        """Stage times (ms) of this context's most recent eigendecomposition (``nls_evd_stage_ms``), or None when none has run."""
+        out = np.zeros(8)
+        if self.lib.nls_evd_stage_ms(self.handle, out.ctypes.data) != NLS_OK:
+            return None
+        kind = int(out[7])
+        two = kind in (3, 4)
+        d = {"kind": self._EVD_KINDS.get(kind, str(kind)), "n": int(out[6])}
+        if kind == 5:
+            d["total"] = round(float(out[5]), 3)
+            return d
+        d["band" if two else "tridiagonalisation"] = round(float(out[0]), 3)
+        if two:
+            d["chase"] = round(float(out[1]), 3)
+        d["stedc"] = round(float(out[2]), 3)
+        if two:
+            d["q2"] = round(float(out[3]), 3)
+        d["q1" if two else "back_transformation"] = round(float(out[4]), 3)
+        d["total"] = round(float(out[5]), 3)
+        return d
+
     def device_info(self) -> dict:
         name = C.create_string_buffer(256)
         cus, hbm = C.c_int(), C.c_size_t()
@@ -449,6 +472,12 @@ class Context:
 
 
 _default_ctx: dict[int, Context] = {}
+
+
+def set_default_context(ctx: Context) -> None:
+    """Make ``ctx`` the context estimators of its device use (``NeoLSSVM(device=...)``): a program that already owns a context
+    hands it over instead of letting the estimator create a second one on the same GPU."""
+    _default_ctx[ctx.device] = ctx
 
 
 def default_context(device: int = 0) -> Context:

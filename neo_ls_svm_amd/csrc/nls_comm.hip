@@ -12,9 +12,15 @@ const RcclApi* rccl_api(std::string* why) {
   if (!tried) {
     tried = true;
     void* h = nullptr;
-    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-      h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-      if (h) break;
+    // NLS_RCCL_LIB: an explicit path (a non-standard install; the test stand-in of tests/csrc/rccl_shim.cpp) - tried alone when set
+    const char* explicit_lib = std::getenv("NLS_RCCL_LIB");
+    if (explicit_lib && explicit_lib[0]) {
+      h = dlopen(explicit_lib, RTLD_NOW | RTLD_LOCAL);
+    } else {
+      for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (h) break;
+      }
     }
     if (!h) {
       err = std::string("cannot load librccl: ") + dlerror();

@@ -334,7 +334,21 @@ extern "C" int nls_dual_fit(nls_ctx* ctx, const nls_dual_fit_args* a) {
     }
     NLSCHK(potrf_lower_real(ctx, M2, (int)n, n_pad, dinfo, pipelined_L ? 512 : 0));
     if (pipelined_L) NLSCHK(download_block_columns(ctx, a->L, M2, (int)n, n_pad, sizeof(double), 512, false));
+    // alpha = cho_solve(L_, y) (_neo_ls_svm.py:314: "resolve the linear system for better accuracy"): two triangular solves with one right-hand
+    // side against the factor just formed, so that the returned pair satisfies alpha == cho_solve(L_, y) to rounding.  (The selected column of
+    // the sweep's table above is the same vector from the eigendecomposition; it stays the answer when no factor is asked for.)
+    HIPCHK(ctx, hipMemcpyAsync(alpha, dy, sizeof(double) * n, hipMemcpyDeviceToDevice, ctx->stream));
+    BLASCHK(ctx, rocblas_set_stream(ctx->blas, ctx->stream));
+    BLASCHK(ctx, rocblas_dtrsv(ctx->blas, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, (rocblas_int)n, M2, (rocblas_int)n_pad, alpha, 1));
+    BLASCHK(ctx, rocblas_dtrsv(ctx->blas, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, (rocblas_int)n, M2, (rocblas_int)n_pad, alpha, 1));
     NLSCHK(check_info(ctx, dinfo, "Cholesky factorisation (potrf)"));
+  } else {
+    // no factorisation, hence no pivot test: gamma* diag(sn^-2) + K is positive definite iff gamma* + lam_min(sn K sn) > 0
+    double lam_min = 0.0;
+    HIPCHK(ctx, hipMemcpyAsync(&lam_min, lam, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (!(gamma_opt + lam_min > 0.0))
+      return fail(ctx, NLS_ERR_LINALG, "gamma* diag(sn^-2) + K is not positive definite at gamma* = %g (smallest eigenvalue of sn K sn: %g)", gamma_opt, lam_min);
   }
   {
     SpanGuard g(ctx, NLS_T_RESIDUALS);

@@ -415,6 +415,47 @@ static int apply_q2(nls_ctx* ctx, const T* V2, int n, T* C, long ldc, int ncols)
   return NLS_OK;
 }
 
+// Invariants of an orthogonal / unitary similarity A -> T: trace and squared Frobenius norm.  The two-stage reduction is checked with them
+// (evd_two_stage): the chase hands data between workgroups inside one launch, and a hand-off that went wrong must not become silently wrong
+// eigenpairs.  One block per column of the stored lower triangle, per-column partials, then one block adds them in a fixed order.
+template <class T>
+__global__ void __launch_bounds__(256) k_herm_invariants(const T* A, long lda, int n, double* part) {
+  using namespace trd;
+  __shared__ double sh[4];
+  const int c = blockIdx.x;
+  double f = 0.0;
+  for (long r = c + 1 + threadIdx.x; r < n; r += 256) f += 2.0 * abs2_(A[r + (long)c * lda]);
+  f = wave_sum(f);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = f;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double dg = real_(A[c + (long)c * lda]);
+    part[2 * c] = dg;
+    part[2 * c + 1] = ((sh[0] + sh[1]) + (sh[2] + sh[3])) + dg * dg;
+  }
+}
+// out[0..1] = (trace, |.|_F^2) of the matrix whose column partials are `part` (skipped when part == nullptr), out[2..3] = the same of the
+// symmetric tridiagonal matrix (d, e).
+__global__ void __launch_bounds__(256) k_tridiag_invariants(const double* part, const double* d, const double* e, int n, double* out) {
+  using namespace trd;
+  __shared__ double sh[4][4];
+  double v[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int i = threadIdx.x; i < n; i += 256) {
+    if (part) {
+      v[0] += part[2 * i];
+      v[1] += part[2 * i + 1];
+    }
+    v[2] += d[i];
+    v[3] += d[i] * d[i] + (i + 1 < n ? 2.0 * e[i] * e[i] : 0.0);
+  }
+  for (int k = 0; k < 4; ++k) {
+    v[k] = wave_sum(v[k]);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][k] = v[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < 4 && (part || threadIdx.x >= 2)) out[threadIdx.x] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+}
+
 __global__ void k_real_to_complex(const double* src, long n_elems, double2* dst) {
   const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
   if (i < n_elems) dst[i] = make_double2(src[i], 0.0);
@@ -557,27 +598,31 @@ static int evd_two_stage(nls_ctx* ctx, T* A, int n, double* lam, double* e_work,
   HIPCHK(ctx, hipMemsetAsync(dflag, 0, 4 * sizeof(int), ctx->stream));
   int nred = 0;
   unsigned* ctl = nullptr;
-  // NLS_EVD_PROFILE=1: stage times (HIP events, one line on stderr per eigendecomposition)
+  // stage times: nls_evd_stage_ms; NLS_EVD_PROFILE=1 also prints one line on stderr per eigendecomposition
   static const bool prof = [] { const char* m = std::getenv("NLS_EVD_PROFILE"); return m && m[0] == '1'; }();
-  hipEvent_t ev[6] = {};
-  auto mark = [&](int i) {
-    if (prof) {
-      if (!ev[i]) (void)hipEventCreate(&ev[i]);
-      (void)hipEventRecord(ev[i], ctx->stream);
-    }
-  };
+  auto mark = [&](int i) { evd_mark(ctx, i); };
+  ctx->evd_kind = 0;
   mark(0);
   // A panel whose columns are dependent to working precision raises the flag (nls_sb.h).  Second attempt: the saved copy again, every
   // panel perturbed by 1e-13 of its norm (k_sb_perturb); if that fails too (zero panels: a diagonal matrix) the one-stage panel takes over.
   unsigned hctl[2] = {0, 0};
+  double *inv_part = nullptr, *inv = nullptr;  // invariants of the input and of the tridiagonal matrix (k_herm_invariants)
+  NLSCHK(ws_get_t(ctx, "evd2.invpart", (size_t)2 * n, &inv_part));
+  NLSCHK(ws_get_t(ctx, "evd2.inv", 4, &inv));
+  hipLaunchKernelGGL(k_herm_invariants<T>, dim3((unsigned)n), dim3(256), 0, ctx->stream, Acopy, (long)n, n, inv_part);
+  HIPCHK(ctx, hipGetLastError());
+  double hinv[4] = {0.0, 0.0, 0.0, 0.0};
   for (int attempt = 0;; ++attempt) {
     NLSCHK((sy2sb<T, B>(ctx, A, n, n, tau1, dflag, &nred, attempt == 1)));
     if (attempt == 0) mark(1);
     NLSCHK((sb2st<T, B>(ctx, A, n, n, lam, e_work, V2, &ctl)));
     if (attempt == 0) mark(2);
+    hipLaunchKernelGGL(k_tridiag_invariants, dim3(1), dim3(256), 0, ctx->stream, attempt == 0 ? inv_part : (const double*)nullptr, lam, e_work, n, inv);
+    HIPCHK(ctx, hipGetLastError());
     int hflag = 0;
     HIPCHK(ctx, hipMemcpyAsync(&hflag, dflag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(hctl, ctl, sizeof(hctl), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(hinv, inv, sizeof(hinv), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (hflag == 0) {
       if (attempt == 1) ctx->twostage_rescues++;
@@ -590,7 +635,33 @@ static int evd_two_stage(nls_ctx* ctx, T* A, int n, double* lam, double* e_work,
     }
     HIPCHK(ctx, hipMemsetAsync(dflag, 0, 4 * sizeof(int), ctx->stream));
   }
-  if (hctl[1] != 0) return fail(ctx, NLS_ERR_HIP, "band -> tridiagonal chase: a workgroup timed out waiting for its predecessor (n = %d)", n);
+  // The chase hands band data between workgroups of one launch (sc1 stores / loads and a progress word, nls_chase.h).  Two things can go wrong
+  // there and neither may reach the caller as eigenpairs: a workgroup that gave up waiting (hctl[1]: the GPU was shared or pre-empted) and - not
+  // observed, but outside what the compiler's memory model promises - a stale read.  A unitary similarity keeps trace and Frobenius norm:
+  // |sum d - tr A| and | |T|_F^2 - |A|_F^2 | beyond 1e-10 relative (rounding: ~sqrt(n) eps) reject the reduction.  Either way A is restored from
+  // the saved copy and the one-stage panel takes over (counted in nls_twostage_fallbacks).  In a collective fit the ranks decide together.
+  {
+    const double scale = std::max(std::sqrt(std::fabs(hinv[1])) * std::sqrt((double)n), std::fabs(hinv[0]));
+    bool bad = hctl[1] != 0 || !std::isfinite(hinv[2]) || !std::isfinite(hinv[3]) || std::fabs(hinv[2] - hinv[0]) > 1e-10 * scale ||
+               std::fabs(hinv[3] - hinv[1]) > 1e-10 * std::fabs(hinv[1]);
+    if (const char* inj = std::getenv("NLS_CHASE_INJECT_FAILURE"))  // test hook: pretend the check failed
+      if (inj[0] == '1') bad = true;
+    if (collective && multi_rank(ctx)) {
+      double* vote = nullptr;
+      NLSCHK(ws_get_t(ctx, "evd2.vote", 2, &vote));
+      double hv = bad ? 1.0 : 0.0;
+      HIPCHK(ctx, hipMemcpyAsync(vote, &hv, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+      NLSCHK(do_allreduce(ctx, vote, 1));
+      HIPCHK(ctx, hipMemcpyAsync(&hv, vote, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      bad = hv != 0.0;
+    }
+    if (bad) {
+      HIPCHK(ctx, hipMemcpyAsync(A, Acopy, sizeof(T) * (size_t)n * n, hipMemcpyDeviceToDevice, ctx->stream));
+      ctx->twostage_fallbacks++;
+      return NLS_OK;
+    }
+  }
   double* Cr = nullptr;
   if (CPLX)
     NLSCHK(ws_get_t(ctx, "evd2.Cr", (size_t)n * n, &Cr));
@@ -614,14 +685,14 @@ static int evd_two_stage(nls_ctx* ctx, T* A, int n, double* lam, double* e_work,
   mark(4);
   NLSCHK(apply_q_blocked<T>(ctx, A, n, n, tau1, C + c0 * n, n, (int)(c1 - c0), B, nred));
   mark(5);
+  ctx->evd_kind = CPLX ? 4 : 3;
+  ctx->evd_n = n;
   if (prof) {
     (void)hipStreamSynchronize(ctx->stream);
     float t[5] = {0, 0, 0, 0, 0};
-    for (int i = 0; i < 5; ++i) (void)hipEventElapsedTime(&t[i], ev[i], ev[i + 1]);
+    for (int i = 0; i < 5; ++i) (void)hipEventElapsedTime(&t[i], ctx->evd_ev[i], ctx->evd_ev[i + 1]);
     std::fprintf(stderr, "[nls evd two-stage] n=%d %s bw=%d cols=%ld: band %.3f ms, chase %.3f, stedc %.3f, Q2 %.3f, Q1 %.3f, total %.3f\n", n,
                  CPLX ? "complex" : "real", B, c1 - c0, t[0], t[1], t[2], t[3], t[4], t[0] + t[1] + t[2] + t[3] + t[4]);
-    for (auto& e : ev)
-      if (e) (void)hipEventDestroy(e);
   }
   if (split) {
     std::vector<size_t> offs((size_t)ctx->world + 1);
@@ -640,8 +711,12 @@ static int evd_two_stage(nls_ctx* ctx, T* A, int n, double* lam, double* e_work,
 static int evd_hermitian_core(nls_ctx* ctx, double2* A, int n, double* lam, double* e_work, rocblas_int* dinfo, double2** Q, bool collective) {
   BLASCHK(ctx, rocblas_set_stream(ctx->blas, ctx->stream));
   if (evd_use_rocsolver() || n < 3) {
+    for (int i = 0; i < 5; ++i) evd_mark(ctx, i);
     BLASCHK(ctx, rocsolver_zheevd(ctx->blas, rocblas_evect_original, rocblas_fill_lower, n, reinterpret_cast<rocblas_double_complex*>(A), n, lam,
                                   e_work, dinfo));
+    evd_mark(ctx, 5);
+    ctx->evd_kind = 5;
+    ctx->evd_n = n;
     NLSCHK(check_info(ctx, dinfo, "rocsolver_zheevd"));
     *Q = A;
     return NLS_OK;
@@ -658,7 +733,11 @@ static int evd_hermitian_core(nls_ctx* ctx, double2* A, int n, double* lam, doub
       return NLS_OK;
     }
   }
+  ctx->evd_kind = 0;
+  evd_mark(ctx, 0);
   NLSCHK(trd_fused<trd::Z>(ctx, reinterpret_cast<trd::Z*>(A), n, n, lam, e_work, tau));
+  evd_mark(ctx, 1);
+  evd_mark(ctx, 2);
   // The tridiagonal matrix of a Hermitian matrix is REAL (LAPACK convention: the phases live in the reflectors), so its eigenvectors
   // come from dstedc (15 instead of zstedc's 22 ms at n = 4097) and are widened to complex only for the back-transformation.
   // collective: every rank holds the same all-reduced matrix and the tridiagonalisation is bit-reproducible, so the reflectors are
@@ -670,6 +749,8 @@ static int evd_hermitian_core(nls_ctx* ctx, double2* A, int n, double* lam, doub
   double* Cr = nullptr;
   NLSCHK(ws_get_t(ctx, "evd2.Cr", (size_t)n * n, &Cr));
   NLSCHK(stedc_real(ctx, n, lam, e_work, Cr, dinfo, split));
+  evd_mark(ctx, 3);
+  evd_mark(ctx, 4);
   long c0 = 0, c1 = n;
   if (split) {
     c0 = (long)n * ctx->rank / ctx->world;
@@ -687,6 +768,9 @@ static int evd_hermitian_core(nls_ctx* ctx, double2* A, int n, double* lam, doub
   } else {
     NLSCHK(apply_q_blocked<trd::Z>(ctx, reinterpret_cast<trd::Z*>(A), n, n, tau, reinterpret_cast<trd::Z*>(C + c0 * n), n, (int)(c1 - c0)));
   }
+  evd_mark(ctx, 5);
+  ctx->evd_kind = 2;
+  ctx->evd_n = n;
   if (split) {
     std::vector<size_t> offs((size_t)ctx->world + 1);
     for (int r = 0; r <= ctx->world; ++r) offs[r] = (size_t)2 * n * (size_t)((long)n * r / ctx->world);
@@ -699,7 +783,11 @@ static int evd_hermitian_core(nls_ctx* ctx, double2* A, int n, double* lam, doub
 static int evd_symmetric_core(nls_ctx* ctx, double* A, int n, double* lam, double* e_work, rocblas_int* dinfo, double** Q) {
   BLASCHK(ctx, rocblas_set_stream(ctx->blas, ctx->stream));
   if (evd_use_rocsolver() || n < 3) {
+    for (int i = 0; i < 5; ++i) evd_mark(ctx, i);
     BLASCHK(ctx, rocsolver_dsyevd(ctx->blas, rocblas_evect_original, rocblas_fill_lower, n, A, n, lam, e_work, dinfo));
+    evd_mark(ctx, 5);
+    ctx->evd_kind = 5;
+    ctx->evd_n = n;
     NLSCHK(check_info(ctx, dinfo, "rocsolver_dsyevd"));
     *Q = A;
     return NLS_OK;
@@ -718,13 +806,22 @@ static int evd_symmetric_core(nls_ctx* ctx, double* A, int n, double* lam, doubl
       return NLS_OK;
     }
   }
+  ctx->evd_kind = 0;
+  evd_mark(ctx, 0);
   NLSCHK(trd_fused<double>(ctx, A, n, n, lam, e_work, tau));
+  evd_mark(ctx, 1);
+  evd_mark(ctx, 2);
   BLASCHK(ctx, rocsolver_dstedc(ctx->blas, rocblas_evect_tridiagonal, n, lam, e_work, C, n, dinfo));
   NLSCHK(check_info(ctx, dinfo, "rocsolver_dstedc"));
+  evd_mark(ctx, 3);
+  evd_mark(ctx, 4);
   if (evd_rocsolver_backtransform())
     BLASCHK(ctx, rocsolver_dormtr(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, n, n, A, n, tau, C, n));
   else
     NLSCHK(apply_q_blocked<double>(ctx, A, n, n, tau, C, n, n));
+  evd_mark(ctx, 5);
+  ctx->evd_kind = 1;
+  ctx->evd_n = n;
   *Q = C;
   return NLS_OK;
 }
@@ -872,6 +969,27 @@ extern "C" int nls_twostage_stage(nls_ctx* ctx, int stage, void* A, int n, int i
   HIPCHK(ctx, hipSetDevice(ctx->device));
   return is_complex ? twostage_stage_impl<trd::Z>(ctx, stage, A, n, bw, aux, d, e, ncols, info)
                     : twostage_stage_impl<double>(ctx, stage, A, n, bw, aux, d, e, ncols, info);
+}
+
+extern "C" int nls_evd_stage_ms(nls_ctx* ctx, double* out8) {
+  if (!ctx) return NLS_ERR_ARG;
+  if (!out8) return fail(ctx, NLS_ERR_ARG, "nls_evd_stage_ms: out8 is NULL");
+  if (ctx->evd_kind == 0) return fail(ctx, NLS_ERR_ARG, "nls_evd_stage_ms: no eigendecomposition has completed on this context");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  for (int i = 0; i < 6; ++i)
+    if (!ctx->evd_ev[i]) return fail(ctx, NLS_ERR_HIP, "nls_evd_stage_ms: stage events missing");
+  HIPCHK(ctx, hipEventSynchronize(ctx->evd_ev[5]));
+  double sum = 0.0;
+  for (int i = 0; i < 5; ++i) {
+    float ms = 0.f;
+    HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->evd_ev[i], ctx->evd_ev[i + 1]));
+    out8[i] = ms;
+    sum += ms;
+  }
+  out8[5] = sum;
+  out8[6] = (double)ctx->evd_n;
+  out8[7] = (double)ctx->evd_kind;
+  return NLS_OK;
 }
 
 extern "C" long nls_twostage_fallbacks(const nls_ctx* ctx) { return ctx ? ctx->twostage_fallbacks : -1; }

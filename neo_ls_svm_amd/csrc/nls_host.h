@@ -71,10 +71,14 @@ struct nls_ctx {
   long twostage_rescues = 0;    // eigendecompositions whose band reduction met a degenerate panel and succeeded at the second, perturbed attempt
   long twostage_fallbacks = 0;  // eigendecompositions whose band reduction met a degenerate panel and fell back to the one-stage panel
   std::vector<nls_factor*> factors;
+  // stage times of the most recent eigendecomposition (nls_evd_stage_ms): events 0..5 bracket the five stages
+  hipEvent_t evd_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  int evd_kind = 0, evd_n = 0;
   // XCD patch shape of k_rotate3 (NLS_ROT_PATCH=RxC; 0x0 = plain order).  Unset: plain on one GPU, a padding-free patch with a communicator
   // (launch_rotate in nls_lib.hip has the counters)
   int rot_pr = 0, rot_pc = 0;
   bool rot_patch_set = false;
+  bool gram_contig = true;  // k_gram3: contiguous run of the (split, half tile) list per XCD (NLS_GRAM_ORDER=plain: round-robin)
   int k1_stagger_ticks = 0;  // NLS_K1_STAGGER_US: period over which the first-round workgroups of K1 are spread (k1_stagger)
   int rot_kstagger = 0;  // NLS_ROT_KSTAGGER=S: K-walk phase (tr + tc) % S slices per workgroup (see mainloop_3m)
   bool no_resident = false;  // NLS_NO_RESIDENT_PLANES=1: recompute the feature planes per phase even when they would fit
@@ -303,6 +307,16 @@ struct HostPin {
     if (p) (void)hipHostUnregister(p);
   }
 };
+
+// Stage marks of the eigendecomposition (nls_evd_stage_ms): mark i closes stage i - 1.  A stage that does not exist in the path taken is
+// marked twice at the same point (0 ms).
+static inline void evd_mark(nls_ctx* ctx, int i) {
+  if (!ctx->evd_ev[i] && hipEventCreate(&ctx->evd_ev[i]) != hipSuccess) {
+    ctx->evd_ev[i] = nullptr;
+    return;
+  }
+  (void)hipEventRecord(ctx->evd_ev[i], ctx->stream);
+}
 
 static double wall() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();

@@ -311,11 +311,21 @@ static inline long xcd_patch_grid(long tiles_r, long tiles_c, int PR, int PC) {
 // grid.x = nt (nt + 1) * nsplit;  slab[(split * ntri + tile)][{R, I}][128][128].
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(m3::NT3, 1)
-    k_gram3(const double* Fc, const double* Fs, int Kf, long rows_pad, int ntri, long rows_per_split, double* slab) {
+    k_gram3(const double* Fc, const double* Fs, int Kf, long rows_pad, int ntri, long rows_per_split, double* slab, long nblocks, int xcd_contig) {
   using namespace m3;
   extern __shared__ double smem[];
   const int nhalf = 2 * ntri;
-  const int half = blockIdx.x % nhalf, split = blockIdx.x / nhalf;
+  // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  xcd_contig: XCD x takes the CONTIGUOUS run
+  // [x per, (x + 1) per) of the (split, half tile) list, so the ~32 workgroups an XCD runs at a time are neighbours in that list - same
+  // row split, same or adjacent tj - and share their A panel (and most B panels) in that L2, instead of every XCD streaming every panel.
+  // The grid is padded to a multiple of 8; the order never enters the arithmetic (one slab slot per (split, tile)).
+  long lin = blockIdx.x;
+  if (xcd_contig) {
+    const long per = (nblocks + 7) / 8;
+    lin = (long)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (lin >= nblocks) return;
+  }
+  const int half = (int)(lin % nhalf), split = (int)(lin / nhalf);
   int tj = (int)((sqrt(4.0 * half + 1.0) - 1.0) * 0.5);
   while ((tj + 1) * (tj + 2) <= half) ++tj;
   while (tj * (tj + 1) > half) --tj;
@@ -778,6 +788,12 @@ __global__ void k_scale_vec(const double* in, double f, long n, double* out) {
 __global__ void k_add_diag(double2* Acm, long lda, int D1, double v) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < D1) Acm[(long)i * lda + i].x += v;
+}
+
+// dst = conj(src) (complex vectors; dst may be src)
+__global__ void k_conj_vec(const double2* src, int n, double2* dst) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = make_double2(src[i].x, -src[i].y);
 }
 
 // y += alpha x (complex arrays, real alpha)

@@ -96,9 +96,10 @@ static int launch_rotate(nls_ctx* ctx, const MapParams& mp, const double* Fc, co
   // column count DIVIDES the number of column tiles has no padding blocks and costs nothing - 8 x 5: 500 GB past L2 against 932 GB plain
   // (11.9 x the algorithmic bytes against 21.7 x, L2 hit 0.76 against 0.56) at 465.6 against 463.8 ms; the 4 x 8 patch of round 2 (every ninth
   // patch 7/8 empty) took 485.8 ms.  The fabric is shared by the ranks of a node, so with a communicator the order is patched when such a
-  // divisor exists; one GPU keeps the plain order.
+  // divisor exists.  Round 4: the same order on one GPU too (the time is the same and half the traffic past L2 is half the fabric power);
+  // NLS_ROT_PATCH=0x0 restores the plain order.
   int pr = ctx->rot_pr, pc = ctx->rot_pc;
-  if (!ctx->rot_patch_set && multi_rank(ctx)) {
+  if (!ctx->rot_patch_set) {
     pr = pc = 0;
     for (int c : {5, 6, 7, 8, 4, 9, 10, 11, 12, 13})
       if (tiles_c % c == 0) {
@@ -162,6 +163,7 @@ extern "C" int nls_ctx_create(int device, nls_ctx** out) {
   ctx->cus = prop.multiProcessorCount;
   if (const char* ep = std::getenv("NLS_ROT_PATCH")) ctx->rot_patch_set = std::sscanf(ep, "%dx%d", &ctx->rot_pr, &ctx->rot_pc) == 2;
   if (const char* er = std::getenv("NLS_NO_RESIDENT_PLANES")) ctx->no_resident = er[0] == '1';
+  if (const char* eg = std::getenv("NLS_GRAM_ORDER")) ctx->gram_contig = std::string(eg) != "plain";
   if (const char* es = std::getenv("NLS_K1_STAGGER_US")) ctx->k1_stagger_ticks = std::max(0, std::min(100000, (int)(std::atof(es) * 100.0)));
   if (const char* et = std::getenv("NLS_K1_SINCOS")) ctx->k1_table = std::string(et) == "table";
   if (const char* ek = std::getenv("NLS_ROT_KSTAGGER")) ctx->rot_kstagger = std::max(0, std::min(16, std::atoi(ek)));
@@ -230,6 +232,8 @@ extern "C" void nls_ctx_destroy(nls_ctx* ctx) {
   for (auto& kv : ctx->ws)
     if (kv.second.p) (void)hipFree(kv.second.p);
   for (auto ev : ctx->event_pool) (void)hipEventDestroy(ev);
+  for (auto ev : ctx->evd_ev)
+    if (ev) (void)hipEventDestroy(ev);
   if (ctx->blas) rocblas_destroy_handle(ctx->blas);
   if (ctx->blas2) rocblas_destroy_handle(ctx->blas2);
   for (auto e : ctx->side_ev)
@@ -509,8 +513,9 @@ static int primal_gram_phase(nls_ctx* ctx, PrimalState& st, double* timings) {
       SpanGuard g(ctx, NLS_T_GRAM);
       const long rps = round_up((rows_pad + nsplit - 1) / nsplit, BK);
       const long ns = (rows_pad + rps - 1) / rps;
-      hipLaunchKernelGGL(k_gram3, dim3((unsigned)(half_tiles * ns)), dim3(m3::NT3), m3::SMEM3, ctx->stream, planes_c(st, r0),
-                         planes_s(st, r0), mp.Kf, rows_pad, st.ntri, rps, slab);
+      const long gblocks = half_tiles * ns;
+      hipLaunchKernelGGL(k_gram3, dim3((unsigned)(ctx->gram_contig ? round_up(gblocks, 8) : gblocks)), dim3(m3::NT3), m3::SMEM3, ctx->stream,
+                         planes_c(st, r0), planes_s(st, r0), mp.Kf, rows_pad, st.ntri, rps, slab, gblocks, ctx->gram_contig ? 1 : 0);
       HIPCHK(ctx, hipGetLastError());
       hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)((st.tile_elems + 255) / 256)), dim3(256), 0, ctx->stream, slab, (int)ns,
                          (long)st.tile_elems, st.gacc);
@@ -804,10 +809,10 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
       // 6e-14 at -gamma_min / 4 and 5e-10 at -gamma_min / 2 (the pole is then 0.69 from the first Chebyshev piece).  A / c is positive
       // semi-definite, so lam_min >= -eps lam_max ~ -1e-12 for the path's matrices (lam_max ~ D + 1); an eigenvalue below
       // -gamma_min / 8 (degenerate weights: lam_max up to 2 n (D+1)) takes the reference's own formula evaluated directly.
-      double lam_min = 0.0;
-      HIPCHK(ctx, hipMemcpyAsync(&lam_min, lam, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+      double lam0 = 0.0;
+      HIPCHK(ctx, hipMemcpyAsync(&lam0, lam, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
       HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-      if (!(lam_min > -0.125 * a->gammas[0])) compressed = false;
+      if (!(lam0 > -0.125 * a->gammas[0])) compressed = false;
     }
     Gr = compressed ? SWEEP_GN : Gp;
     HIPCHK(ctx, hipMemcpyAsync(dgam, compressed ? hnodes.data() : a->gammas, sizeof(double) * (compressed ? SWEEP_GN : G), hipMemcpyHostToDevice,
@@ -881,7 +886,9 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
     NLSCHK(do_allreduce(ctx, errs, (size_t)3 * Gp));
   }
   std::vector<double> herrs((size_t)3 * Gp), hobj((size_t)G);
+  double lam_min = 0.0;  // smallest eigenvalue of A / c (of C^-1 A for a general C): the positive-definiteness test of gamma* C + A below
   HIPCHK(ctx, hipMemcpyAsync(herrs.data(), errs, sizeof(double) * 3 * Gp, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(&lam_min, lam, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   for (int g = 0; g < G; ++g)  // _neo_ls_svm.py:159-165 (same summation order as the reference)
     hobj[g] = is_clf ? (herrs[Gp + g] + herrs[2 * Gp + g]) + herrs[g] : herrs[g];
@@ -911,6 +918,12 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
     return NLS_OK;
   }
 
+  // gamma* C + A = c Q^-H (gamma* + Lam) Q^-1 is positive definite iff gamma* + lam_min > 0: the test the reference's cho_factor makes
+  // (_neo_ls_svm.py:177 raises LinAlgError otherwise).  It is made here, from the eigenvalues, because the factorisation itself runs only
+  // when the caller asks for L_ (and then beside everything else, on a side stream).
+  if (!(gamma_opt + lam_min > 0.0))
+    return fail(ctx, NLS_ERR_LINALG, "gamma* C + A is not positive definite at gamma* = %g (smallest eigenvalue of A / c: %g)", gamma_opt, lam_min);
+
   // ---- column of the selected gamma (P7 outputs, P9 sigma) -------------------------------------
   double *loo_res = nullptr, *loo_lev = nullptr, *loo_std = nullptr, *res = nullptr, *cpart = nullptr, *csum = nullptr;
   NLSCHK(ws_get_t(ctx, "out.loo_res", (size_t)st.n_pad, &loo_res));
@@ -936,9 +949,12 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
   HIPCHK(ctx, hipMemcpyAsync(hsum, csum, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
 
   // ---- P8: re-solve at gamma* -------------------------------------------------------------------
-  // beta = Q (v / (gamma* + lam)) from the eigendecomposition (exactly (gamma* C + A)^-1 b: A + gamma c I = c Q (Lam + gamma) Q^H): no
-  // factorisation on the critical path.  The Cholesky factor (_neo_ls_svm.py:176-178) is only an OUTPUT (L_): when the caller asks for it,
-  // zpotrf and the 16 (D+1)^2-byte download run on a side stream beside beta and the outputs of the main stream; a->L == NULL skips both.
+  // The reference re-solves with the Cholesky factor at gamma* "for better accuracy" (_neo_ls_svm.py:176-178).  When the caller asks for L_
+  // this does the same: zpotrf and the 16 (D+1)^2-byte download run on a side stream beside the outputs of the main stream, and
+  // beta = cho_solve(L_, b) follows on that stream (two triangular solves against the factor that was just downloaded), so that the returned
+  // pair satisfies beta == cho_solve(L_, b) to rounding.  With a->L == NULL (ranks > 0 of a sharded fit, sigma-grid probes) there is no
+  // factorisation: beta = Q (v / (gamma* + lam)) from the eigendecomposition - the same (gamma* C + A)^-1 b, A + gamma c I = c Q (Lam + gamma) Q^H -
+  // and positive definiteness was checked on the eigenvalues above.  In a collective fit rank 0's beta is broadcast: identical everywhere.
   double2* dbeta = nullptr;
   NLSCHK(ws_get_t(ctx, "chol.beta", (size_t)D1, &dbeta));
   rocblas_int* dinfo2 = nullptr;
@@ -1021,7 +1037,6 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
       if (dst) HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
       return NLS_OK;
     };
-    NLSCHK(d2h(a->beta, dbeta, sizeof(double2) * D1));
     NLSCHK(d2h(a->lam, lam, sizeof(double) * D1));
     NLSCHK(d2h(a->loo_residuals, loo_res, sizeof(double) * n));
     NLSCHK(d2h(a->loo_leverage, loo_lev, sizeof(double) * n));
@@ -1032,6 +1047,31 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
     NLSCHK(download_block_columns(ctx, a->L, Acm, D1, (long)D1, sizeof(double2), 512, true));
     HIPCHK(ctx, hipEventRecord(ctx->side_ev[2], ctx->copy_stream));
   }
+  if (side_copy) {
+    // beta = cho_solve(L_, b) (_neo_ls_svm.py:178).  The copy stream has conjugated the factor in place on its way out (Acm now holds
+    // Lc = conj(L), i.e. scipy's upper factor read column-major), so: L x = b <=> Lc conj(x) = conj(b);  L^H beta = x <=> Lc^T beta = x.
+    hipStream_t s2 = ctx->stream2;
+    double2* tmp = nullptr;
+    NLSCHK(ws_get_t(ctx, "chol.solve", (size_t)D1, &tmp));
+    HIPCHK(ctx, hipStreamWaitEvent(s2, ctx->side_ev[2], 0));
+    const auto* zL = reinterpret_cast<const rocblas_double_complex*>(Acm);
+    hipLaunchKernelGGL(k_conj_vec, dim3((unsigned)((D1 + 255) / 256)), dim3(256), 0, s2, db, D1, tmp);
+    HIPCHK(ctx, hipGetLastError());
+    BLASCHK(ctx, rocblas_ztrsv(ctx->blas2, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, D1, zL, D1,
+                               reinterpret_cast<rocblas_double_complex*>(tmp), 1));
+    hipLaunchKernelGGL(k_conj_vec, dim3((unsigned)((D1 + 255) / 256)), dim3(256), 0, s2, tmp, D1, tmp);
+    HIPCHK(ctx, hipGetLastError());
+    BLASCHK(ctx, rocblas_ztrsv(ctx->blas2, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, D1, zL, D1,
+                               reinterpret_cast<rocblas_double_complex*>(tmp), 1));
+    HIPCHK(ctx, hipEventRecord(ctx->side_ev[3], s2));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_ev[3], 0));
+    HIPCHK(ctx, hipMemcpyAsync(dbeta, tmp, sizeof(double2) * D1, hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  if (multi_rank(ctx)) {
+    SpanGuard g(ctx, NLS_T_ALLREDUCE);
+    NLSCHK(do_broadcast(ctx, reinterpret_cast<double*>(dbeta), (size_t)2 * D1, 0));
+  }
+  if (a->beta) HIPCHK(ctx, hipMemcpyAsync(a->beta, dbeta, sizeof(double2) * D1, hipMemcpyDeviceToHost, ctx->stream));
   if (side) {  // join the side streams; their stage times go into the cholesky / download slots
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream2));
     HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));
@@ -1041,6 +1081,7 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, ctx->side_ev[0], ctx->side_ev[1]) == hipSuccess) tm[NLS_T_CHOLESKY] += ms * 1e-3;
     if (hipEventElapsedTime(&ms, ctx->side_ev[1], ctx->side_ev[2]) == hipSuccess) tm[NLS_T_DOWNLOAD] += ms * 1e-3;
+    if (hipEventElapsedTime(&ms, ctx->side_ev[2], ctx->side_ev[3]) == hipSuccess) tm[NLS_T_CHOLESKY] += ms * 1e-3;
   }
   NLSCHK(spans_collect(ctx, tm));
   if (a->loo_errors) std::memcpy(a->loo_errors, herrs.data(), sizeof(double) * G);

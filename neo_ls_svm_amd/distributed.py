@@ -47,12 +47,14 @@ def _rendezvous_files(key: str | None) -> tuple[Path, Path | None]:
     return base / f"nls_rccl_id_{os.getppid()}_{port}_{run}_{attempt}", base / f"nls_rccl_id_port{port}_{run}_{attempt}"
 
 
-_FRESH_SECONDS = float(os.environ.get("NLS_RENDEZVOUS_FRESH_SECONDS", "600"))
+def _fresh_seconds() -> float:
+    """How long a published id stays joinable (NLS_RENDEZVOUS_FRESH_SECONDS, read at call time; default 900 s)."""
+    return float(os.environ.get("NLS_RENDEZVOUS_FRESH_SECONDS", "900"))
 
 
 def _publish(path: Path, payload: bytes) -> None:
     """Atomic publish: a private temporary file (O_EXCL | O_NOFOLLOW, mode 0600: never through a planted symlink), then rename."""
-    tmp = path.with_suffix(f".tmp{os.getpid()}")
+    tmp = path.with_name(f"{path.name}.tmp{os.getpid()}")  # (not with_suffix: a key such as "job.1" keeps its last dotted part)
     try:
         os.unlink(tmp)
     except FileNotFoundError:
@@ -65,12 +67,27 @@ def _publish(path: Path, payload: bytes) -> None:
     os.replace(tmp, path)
 
 
-def _read_fresh(path: Path) -> bytes | None:
-    """The 128-byte id of a payload `id || repr(time)` that is younger than ``_FRESH_SECONDS``; None otherwise (a file left
-    behind by a launch that died between publishing and the post-barrier unlink is ignored, not joined)."""
+def _read_fresh(path: Path, explicit_key: bool) -> bytes | None:
+    """The 128-byte id of a payload `id || repr(time)`.  A file under an explicit key is the caller's own rendezvous: it is accepted
+    as it is.  An automatic (launcher-derived) name could be a leftover of a launch that died between publishing and the post-barrier
+    unlink, so it is accepted only while fresh - judged by the file's OWN modification time against the clock of the machine that
+    reads it, both taken from the same filesystem view (no assumption that the ranks' clocks agree with the publisher's)."""
     try:
         raw = path.read_bytes()
-        if len(raw) > 128 and abs(time.time() - float(raw[128:].decode())) < _FRESH_SECONDS:
+        if len(raw) <= 128:
+            return None
+        float(raw[128:].decode())  # well-formed payload
+        if explicit_key:
+            return raw[:128]
+        probe = path.with_name(f"{path.name}.probe{os.getpid()}")
+        try:  # "now" as the filesystem that holds the file sees it (a shared directory may be served by another clock)
+            fd = os.open(probe, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, "O_NOFOLLOW", 0), 0o600)
+            os.close(fd)
+            now = os.stat(probe).st_mtime
+            os.unlink(probe)
+        except OSError:
+            now = time.time()
+        if abs(now - path.stat().st_mtime) < _fresh_seconds():
             return raw[:128]
     except (FileNotFoundError, ValueError):
         pass
@@ -88,9 +105,9 @@ def exchange_unique_id(ctx, rank: int, world: int, key: str | None = None, timeo
         return uid
     t0 = time.monotonic()
     while True:
-        uid = _read_fresh(primary)
+        uid = _read_fresh(primary, explicit_key=key is not None)
         if uid is None and secondary is not None and time.monotonic() - t0 > 15.0:  # the parent-pid key found nothing: try the port key
-            uid = _read_fresh(secondary)
+            uid = _read_fresh(secondary, explicit_key=False)
         if uid is not None:
             return uid
         if time.monotonic() - t0 > timeout:

@@ -18,6 +18,8 @@ without the context that fitted it.
 
 from __future__ import annotations
 
+import time
+
 import numpy as np
 from sklearn.base import BaseEstimator, clone
 from sklearn.isotonic import IsotonicRegression
@@ -29,10 +31,79 @@ from . import _prestep, hotpath
 from .conformal import conformal_delta_quantiles
 from ._lib import default_context
 
-__all__ = ["NeoLSSVM", "AffineSeparator", "OrthogonalRandomFourierFeatures"]
+__all__ = ["NeoLSSVM", "AffineFeatureMap", "AffineNormalizer", "AffineSeparator", "RandomFourierFeatures", "OrthogonalRandomFourierFeatures"]
 
 
-class AffineSeparator(BaseEstimator):
+def _affine_params(fm):
+    """(shift, scale, A) of a fitted affine map: the fitted ``*_`` attribute when present, else the constructor parameter
+    of the same name - how the reference reads them (``_affine_feature_map.py:49-51,77-79``).  None when ``fm`` is not an
+    affine map in that sense."""
+    out = []
+    for name in ("shift", "scale", "A"):
+        if hasattr(fm, name + "_"):
+            out.append(getattr(fm, name + "_"))
+        elif hasattr(fm, name):
+            out.append(getattr(fm, name))
+        else:
+            return None
+    if out[0] is None or out[1] is None:
+        return None
+    return tuple(out)
+
+
+class AffineFeatureMap(BaseEstimator):
+    """(x - shift) diag(1/scale) A with GIVEN parameters: reference ``_affine_feature_map.py:17-92`` (``append_features`` is
+    not part of the hot path and not mirrored).  ``fit`` validates as the reference does (``:52-69``); subclasses learn them."""
+
+    def __init__(self, *, scale, shift, A=None):
+        self.scale = scale
+        self.shift = shift
+        self.A = A
+
+    def fit(self, X, y=None, sample_weight=None, ctx=None):
+        X = check_array(X, dtype=np.float64)
+        self.n_features_in_ = X.shape[1]
+        shift, scale, A = _affine_params(self)
+        scale, shift = np.reshape(scale, (-1, X.shape[1])), np.reshape(shift, (-1, X.shape[1]))  # incompatible sizes raise here
+        if np.any(scale == 0) or not np.all(np.isfinite(scale)):
+            raise ValueError("The scale must be finite and non-zero")
+        if not np.all(np.isfinite(shift)):
+            raise ValueError("The shift must be finite")
+        if A is not None and (np.shape(A)[0] != X.shape[1] or not np.all(np.isfinite(A))):
+            raise ValueError("The matrix A must be finite with rows equal to the number of features in X")
+        return self
+
+    def transform(self, X):
+        """Affine map only (used by the dual path: ``_neo_ls_svm.py:394,668``); n x r output, host GEMM, with the
+        reference's memory-order switch (``_affine_feature_map.py:81-89``)."""
+        X = check_array(X, dtype=np.float64)
+        shift, scale, A = _affine_params(self)
+        shift, scale = np.reshape(shift, (1, -1)), np.reshape(scale, (1, -1))
+        if A is None:
+            return (X - shift) / scale
+        As = A / scale.T
+        return X @ As - shift @ As if A.shape[1] < A.shape[0] else (X - shift) @ As
+
+
+class AffineNormalizer(AffineFeatureMap):
+    """Supervised shift / scale from per-bin weighted medians and deviations, A = None: reference ``_affine_normalizer.py:25-117``
+    (the n-proportional bin statistics run on the GPU, ``nls_bin_stats``)."""
+
+    def __init__(self, *, device=0):
+        self.device = device
+
+    def fit(self, X, y, sample_weight=None, ctx=None):
+        X, y = check_X_y(X, y, dtype=np.float64)
+        ctx = ctx or default_context(int(self.device))
+        self.shift_, self.scale_ = _prestep.fit_affine_normalizer(
+            X, np.asarray(y, dtype=np.float64), sample_weight, stats=lambda A, lab, w: hotpath.bin_stats(A, lab, w, ctx=ctx)
+        )
+        self.A_ = None
+        self.n_features_in_ = X.shape[1]
+        return self
+
+
+class AffineSeparator(AffineFeatureMap):
     """(x - shift) diag(1/scale) A with supervised shift/scale/A: reference ``_affine_separator.py:54-210``."""
 
     def __init__(self, *, rank_threshold=2e-2, edge_sample_size=384, edge_search_multiplier=4, random_state=42, device=0):
@@ -64,42 +135,57 @@ class AffineSeparator(BaseEstimator):
         self.n_features_in_ = X.shape[1]
         return self
 
-    def transform(self, X):
-        """Affine map only (used by the dual path: ``_neo_ls_svm.py:394,668``); n x r output, host GEMM."""
-        X = check_array(X, dtype=np.float64)
-        Xs = (X - self.shift_) / self.scale_
-        return Xs if self.A_ is None else Xs @ self.A_
+
+def _fit_affine(fm, X, y, sample_weight, ctx):
+    """Fit a (possibly caller-supplied) affine map; this package's classes take the context so that X is uploaded once.
+    The fitted object must expose (shift, scale, A) - as parameters or fitted attributes, the reference's convention
+    (``_affine_feature_map.py:49-51``) - or it is not an affine map this library can fold into its feature map."""
+    fitted = fm.fit(X, y, sample_weight, ctx=ctx) if isinstance(fm, AffineFeatureMap) else fm.fit(X, y, sample_weight)
+    fitted = fm if fitted is None else fitted
+    if _affine_params(fitted) is None:
+        raise TypeError(f"{type(fm).__name__} is not an affine map: after fit it exposes no shift / scale / A (parameters or fitted attributes)")
+    return fitted
 
 
-class OrthogonalRandomFourierFeatures(BaseEstimator):
-    """phi(x) = [exp(-i Z^T A^T ((x - shift)/scale)) / sqrt(D), 1]: reference ``_feature_maps.py:117-223``.
+class RandomFourierFeatures(BaseEstimator):
+    """phi(x) = [exp(-i Z^T A^T ((x - shift)/scale)) / sqrt(D), 1]: reference ``_feature_maps.py:117-203``.
 
-    ``fit`` learns the separator and folds the ORF matrix Z into its A (``:147-150``); ``transform`` evaluates the
-    map on the GPU (``nls_featuremap``).
+    ``fit`` fits the affine map (default: ``AffineSeparator()``, ``_feature_maps.py:66``; any affine map is honoured - this
+    package's ``AffineFeatureMap`` / ``AffineNormalizer`` / ``AffineSeparator``, upstream's own, or a caller's: ``fit(X, y,
+    sample_weight)`` and shift / scale / A as parameters or fitted attributes) and folds the frequency matrix Z into its A (``:143-150``); ``transform`` evaluates the map on the GPU
+    (``nls_featuremap``).  ``orthogonal=False``: Z = ``RandomState(seed).randn(d', D)`` (``:120-127``); ``orthogonal=True``: each
+    block of d' columns replaced by the Q of its QR and the columns rescaled by chi(d') draws (``:209-223``).
     """
 
-    def __init__(self, affine_feature_map=None, num_features=512, random_state=42, exact_complexity=False):
+    orthogonal_default = False
+
+    def __init__(self, affine_feature_map=None, num_features=512, random_state=42, exact_complexity=False, orthogonal=None):
         self.affine_feature_map = affine_feature_map
         self.num_features = num_features
         self.random_state = random_state
         self.exact_complexity = exact_complexity
+        self.orthogonal = orthogonal
 
     def fit(self, X, y=None, sample_weight=None, ctx=None):
-        self.affine_feature_map_ = clone(self.affine_feature_map) if self.affine_feature_map is not None else AffineSeparator()
-        if isinstance(self.affine_feature_map_, AffineSeparator):
-            self.affine_feature_map_.fit(X, y, sample_weight, ctx=ctx)
-        else:
-            self.affine_feature_map_.fit(X, y, sample_weight)
-        A = self.affine_feature_map_.A_
+        afm = _as_own_affine_map(self.affine_feature_map)
+        self.affine_feature_map_ = _fit_affine(AffineSeparator() if afm is None else clone(afm), X, y, sample_weight, ctx)
+        shift, scale, A = _affine_params(self.affine_feature_map_)
+        A = None if A is None else np.asarray(A, dtype=np.float64)
         d_in = A.shape[1] if A is not None else np.asarray(X).shape[1]
-        self.Z_ = hotpath.orf_frequencies(d_in, self.num_features, self.random_state)
+        orthogonal = self.orthogonal_default if self.orthogonal is None else bool(self.orthogonal)
+        if orthogonal:
+            self.Z_ = hotpath.orf_frequencies(d_in, self.num_features, self.random_state)
+        else:
+            gen = self.random_state if isinstance(self.random_state, np.random.RandomState) else np.random.RandomState(self.random_state)
+            self.Z_ = gen.randn(d_in, self.num_features)
         self.B_ = A @ self.Z_ if A is not None else self.Z_
+        self.shift_, self.scale_ = np.ravel(np.asarray(shift, dtype=np.float64)), np.ravel(np.asarray(scale, dtype=np.float64))
         self.n_features_in_ = np.asarray(X).shape[1]
         return self
 
     @property
     def map_params(self):
-        return np.ravel(self.affine_feature_map_.shift_), np.ravel(self.affine_feature_map_.scale_), self.B_
+        return self.shift_, self.scale_, self.B_
 
     @property
     def complexity_matrix(self):
@@ -113,6 +199,47 @@ class OrthogonalRandomFourierFeatures(BaseEstimator):
     def transform(self, X, ctx=None):
         shift, scale, B = self.map_params
         return hotpath.featuremap(check_array(X, dtype=np.float64), shift, scale, B, ctx=ctx)
+
+
+class OrthogonalRandomFourierFeatures(RandomFourierFeatures):
+    """Orthogonal random Fourier features (the default primal map): reference ``_feature_maps.py:206-223``."""
+
+    orthogonal_default = True
+
+
+def _as_own_feature_map(fm):
+    """The primal plug-in point (``_neo_ls_svm.py:62-75,380-394``).  Honoured: this package's ``RandomFourierFeatures`` /
+    ``OrthogonalRandomFourierFeatures`` (with any affine map inside), and upstream's two classes of the same names, which are
+    translated by their public parameters (``num_features``, ``random_state``, ``affine_feature_map``).  Anything else - a
+    feature map whose transform this library does not implement - is refused: silently fitting a different model is worse."""
+    if isinstance(fm, RandomFourierFeatures):
+        return fm
+    name = type(fm).__name__
+    if name in ("RandomFourierFeatures", "OrthogonalRandomFourierFeatures") and hasattr(fm, "num_features"):
+        cls = OrthogonalRandomFourierFeatures if name.startswith("Orthogonal") else RandomFourierFeatures
+        afm = getattr(fm, "affine_feature_map", None)
+        return cls(affine_feature_map=_as_own_affine_map(afm), num_features=int(fm.num_features), random_state=getattr(fm, "random_state", 42))
+    raise TypeError(
+        f"primal_feature_map must be 'auto', a RandomFourierFeatures / OrthogonalRandomFourierFeatures of neo_ls_svm_amd (or upstream's "
+        f"classes of those names); got {name}: this library evaluates exp(-i T) / sqrt(D) maps only and will not substitute another model"
+    )
+
+
+def _as_own_affine_map(afm):
+    """Upstream's ``AffineSeparator`` / ``AffineNormalizer`` carry numba-jitted pre-steps this package restates itself: they are
+    translated by their public parameters; every other affine map (upstream's fixed ``AffineFeatureMap``, a caller's own) is
+    passed through and fitted as is."""
+    if afm is None or isinstance(afm, AffineFeatureMap):
+        return afm
+    name, module = type(afm).__name__, type(afm).__module__
+    if module.startswith("neo_ls_svm.") and name == "AffineSeparator":
+        keys = ("rank_threshold", "edge_sample_size", "edge_search_multiplier", "random_state")
+        return AffineSeparator(**{k: getattr(afm, k) for k in keys if hasattr(afm, k)})
+    if module.startswith("neo_ls_svm.") and name == "AffineNormalizer":
+        return AffineNormalizer()
+    if callable(getattr(afm, "fit", None)):
+        return afm  # checked for shift / scale / A once fitted (_fit_affine)
+    raise TypeError(f"{name} is not an affine map: it has no fit(X, y, sample_weight)")
 
 
 def _series_like(values, X_in):
@@ -218,29 +345,33 @@ class NeoLSSVM(BaseEstimator):
         self.dual_ = bool(X.shape[0] <= 1024 if self.dual == "auto" else self.dual)  # noqa: PLR2004
         self.primal_ = not self.dual_
         ctx = self._ctx()
+        wall = {}
+        t0 = time.perf_counter()
         if self.primal_:
-            fm = OrthogonalRandomFourierFeatures() if isinstance(self.primal_feature_map, str) else self.primal_feature_map
-            if not isinstance(fm, OrthogonalRandomFourierFeatures):  # e.g. upstream's feature-map object: take its size
-                fm = OrthogonalRandomFourierFeatures(
-                    num_features=int(getattr(fm, "num_features", 512)), random_state=getattr(fm, "random_state", 42)
-                )
+            fm = OrthogonalRandomFourierFeatures() if isinstance(self.primal_feature_map, str) else _as_own_feature_map(self.primal_feature_map)
             with ctx.hold(X):  # one upload of X serves the pre-step's bin statistics and the solver
                 self.primal_feature_map_ = clone(fm).fit(X, y_, sw, ctx=ctx)
                 shift, scale, B = self.primal_feature_map_.map_params
                 Cm = self.primal_feature_map_.complexity_matrix if self.primal_feature_map_.exact_complexity else None
+                wall["prestep"] = time.perf_counter() - t0
+                t0 = time.perf_counter()
                 r = hotpath.primal_fit(X, y_, sw, shift, scale, B, is_clf, ctx=ctx, complexity_matrix=Cm)
             self.β̂_, self.γ_ = r["beta"], r["gamma"]
             self.loo_leverage_ = r["loo_leverage"]
         else:
             nz = sw > 0
             X, y_, sw = X[nz], y_[nz], sw[nz]
-            sep = AffineSeparator() if isinstance(self.dual_feature_map, str) else self.dual_feature_map
-            if not isinstance(sep, AffineSeparator):
-                sep = AffineSeparator()
-            self.dual_feature_map_ = clone(sep).fit(X, y_, sw, ctx=ctx)
-            self.X_ = np.ascontiguousarray(self.dual_feature_map_.transform(X))
+            sep = AffineSeparator() if isinstance(self.dual_feature_map, str) else _as_own_affine_map(self.dual_feature_map)
+            if sep is None:
+                raise TypeError("dual_feature_map must be 'auto' or an affine map")
+            self.dual_feature_map_ = _fit_affine(clone(sep), X, y_, sw, ctx)
+            self.X_ = np.ascontiguousarray(self._dual_transform(X))
+            wall["prestep"] = time.perf_counter() - t0
+            t0 = time.perf_counter()
             r = hotpath.dual_fit(self.X_, y_, sw, is_clf, ctx=ctx)
             self.α̂_, self.γ_ = r["alpha"], r["gamma"]
+        wall["solver"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
         # Attributes the reference's solver sets as side effects (:146-187 / :270-323).
         self.γs_ = r["gammas"]
         self.loo_errors_γs_ = r["loo_errors_gammas"]
@@ -285,7 +416,17 @@ class NeoLSSVM(BaseEstimator):
         # Conformal predictors are fitted lazily per requested quantile tuple (:431-441).
         self.conformal_l1_ = {"Δŷ": {}, "Δŷ/ŷ": {}}
         self.conformal_l2_ = {"Δŷ": {}, "Δŷ/ŷ": {}}
+        wall["calibration"] = time.perf_counter() - t0
+        self.fit_wall_ = wall  # seconds: pre-step (affine map + frequency matrix) / solver call / attributes + calibration split
         return self
+
+    def _dual_transform(self, Xa):
+        """X -> X_ of the dual path (``_neo_ls_svm.py:394,668``) through the fitted affine map (its own ``transform`` when it has one)."""
+        fm = self.dual_feature_map_
+        if callable(getattr(fm, "transform", None)):
+            return np.asarray(fm.transform(Xa), dtype=np.float64)
+        shift, scale, A = _affine_params(fm)
+        return AffineFeatureMap(scale=scale, shift=shift, A=A).transform(Xa)
 
     # ASCII aliases of the Greek attribute names.
     @property
@@ -315,7 +456,7 @@ class NeoLSSVM(BaseEstimator):
             shift, scale, B = self.primal_feature_map_.map_params
             yhat, _ = hotpath.primal_predict(Xa, shift, scale, B, beta=self.β̂_, ctx=self._ctx())
         else:
-            Xq = np.ascontiguousarray(self.dual_feature_map_.transform(Xa))
+            Xq = np.ascontiguousarray(self._dual_transform(Xa))
             yhat, _ = hotpath.dual_predict(Xq, self.X_, alpha=self.α̂_, ctx=self._ctx())
         return _series_like(yhat, X)
 
@@ -327,7 +468,7 @@ class NeoLSSVM(BaseEstimator):
             ctx = self._ctx()
             _, sigma = hotpath.primal_predict(Xa, shift, scale, B, ctx=ctx, factor=self._factor_for(ctx))
         else:
-            Xq = np.ascontiguousarray(self.dual_feature_map_.transform(Xa))
+            Xq = np.ascontiguousarray(self._dual_transform(Xa))
             _, sigma = hotpath.dual_predict(Xq, self.X_, L=self.L_[0], ctx=self._ctx())
         return _series_like(sigma, X)
 
@@ -337,7 +478,7 @@ class NeoLSSVM(BaseEstimator):
             shift, scale, B = self.primal_feature_map_.map_params
             ctx = self._ctx()
             return hotpath.primal_predict(Xa, shift, scale, B, beta=self.β̂_, ctx=ctx, factor=self._factor_for(ctx))
-        Xq = np.ascontiguousarray(self.dual_feature_map_.transform(Xa))
+        Xq = np.ascontiguousarray(self._dual_transform(Xa))
         return hotpath.dual_predict(Xq, self.X_, alpha=self.α̂_, L=self.L_[0], ctx=self._ctx())
 
     def predict_quantiles(self, X, *, quantiles=(0.025, 0.5, 0.975), priority="accuracy"):

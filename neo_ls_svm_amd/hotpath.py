@@ -418,8 +418,11 @@ def primal_fit_sigma_grid(
         table[~owned], objective[~owned] = np.nan, np.nan
     col_min = np.where(owned, np.nanmin(np.where(owned[:, None], objective, np.inf), axis=1), np.inf)
     k_opt = int(np.argmin(col_min))  # first minimum: ties go to the smaller sigma index ...
-    if best is not None and col_min[best[1]] == col_min[k_opt]:
-        k_opt = best[1]  # ... unless this rank's finished incumbent is among the tied: it carries the full result
+    merged_table = allreduce_sum is not None and world > 1
+    if not merged_table and best is not None and col_min[best[1]] == col_min[k_opt]:
+        # ... unless (single rank only) the finished incumbent is among the tied: it carries the full result.  After a merge every rank
+        # sees the same table but a different incumbent, so the rule must not depend on it: all ranks return the smallest tied index.
+        k_opt = best[1]
     g_opt = int(np.argmin(objective[k_opt]))
     return {
         "sigmas": sigmas,

@@ -32,6 +32,7 @@ import scipy.linalg as sla
 __all__ = [
     "gamma_grid",
     "orf_frequencies",
+    "rff_frequencies",
     "fold_projection",
     "affine_project",
     "feature_map",
@@ -76,6 +77,12 @@ def orf_frequencies(d: int, D: int, seed=42, dtype=np.float64) -> np.ndarray:
         start += d
     chi = np.sqrt(gen.chisquare(d, size=(1, D)).astype(dtype))
     return Z * chi
+
+
+def rff_frequencies(d: int, D: int, seed=42, dtype=np.float64) -> np.ndarray:
+    """Plain random Fourier frequencies: ``_feature_maps.py:120-127`` - Z = RandomState(seed).randn(d, D), nothing else."""
+    gen = seed if isinstance(seed, np.random.RandomState) else np.random.RandomState(seed)
+    return gen.randn(d, D).astype(dtype)
 
 
 def fold_projection(A_sep: np.ndarray | None, Z: np.ndarray) -> np.ndarray:
@@ -537,63 +544,3 @@ def dual_predict_std(Xq: np.ndarray, Xt: np.ndarray, L: np.ndarray, lower: bool 
     K = rbf_gram(Xq, Xt)
     return np.sqrt(1.0 - np.sum(K * sla.cho_solve((L, lower), K.T).T, axis=1))
 
-
-# --------------------------------------------------------------------------------------------
-# CPU-baseline timing helper (bench.py's ``cpu_baseline`` leg)
-# --------------------------------------------------------------------------------------------
-def time_primal_row_stages(X, y, s, shift, scale, B, gammas, row_tile: int = 2048, seed: int = 0) -> dict:
-    """Wall time of the n-proportional stages of ``primal_fit_streamed`` on the rows of X.
-
-    Runs feature map (twice, as the streamed schedule does), weighted Gram + right-hand side, the
-    rotation P = phi Q with its |P|^2 / Re(P v) epilogue and the two sweep GEMMs with the LOO residual
-    reduction, with a random (D+1)^2 complex Q and positive lam standing in for the eigen-decomposition:
-    the time of these dense products does not depend on the values.  EVD and Cholesky (O(D^3),
-    n-independent) are deliberately left out, which favours the CPU in any GPU/CPU ratio.
-    Returns {"seconds": total, "stages": {...}, "rows": n}.
-    """
-    import time
-
-    n = X.shape[0]
-    D1 = B.shape[1] + 1
-    rng = np.random.default_rng(seed)
-    Q = (rng.standard_normal((D1, D1)) + 1j * rng.standard_normal((D1, D1))) / np.sqrt(2 * D1)
-    v = rng.standard_normal(D1) + 1j * rng.standard_normal(D1)
-    lam = np.abs(rng.standard_normal(D1)) + 1e-3
-    R = 1.0 / (gammas[None, :] + lam[:, None])
-    sn = s / np.sum(s)
-    c = 1.0 / (n * D1)
-    st = {"feature_map": 0.0, "gram": 0.0, "rotate": 0.0, "sweep": 0.0, "loo": 0.0}
-    A = np.zeros((D1, D1), dtype=np.complex128)
-    b = np.zeros(D1, dtype=np.complex128)
-    errs = np.zeros(gammas.size)
-    t_all = time.perf_counter()
-    for r0 in range(0, n, row_tile):
-        r1 = min(n, r0 + row_tile)
-        t0 = time.perf_counter()
-        phi = feature_map(X[r0:r1], shift, scale, B)
-        st["feature_map"] += time.perf_counter() - t0
-        t0 = time.perf_counter()
-        F = sn[r0:r1, None] * phi
-        A += F.conj().T @ F
-        b += F.conj().T @ (sn[r0:r1] * y[r0:r1])
-        st["gram"] += time.perf_counter() - t0
-    for r0 in range(0, n, row_tile):
-        r1 = min(n, r0 + row_tile)
-        t0 = time.perf_counter()
-        phi = feature_map(X[r0:r1], shift, scale, B)
-        st["feature_map"] += time.perf_counter() - t0
-        t0 = time.perf_counter()
-        P = phi @ Q
-        U = np.ascontiguousarray(np.real(P * v[None, :]))  # np.real is a strided view (:141-143)
-        Gm = np.real(P) ** 2 + np.imag(P) ** 2
-        st["rotate"] += time.perf_counter() - t0
-        t0 = time.perf_counter()
-        num = U @ R
-        hs = (Gm @ R) / c
-        st["sweep"] += time.perf_counter() - t0
-        t0 = time.perf_counter()
-        with np.errstate(divide="ignore", invalid="ignore"):
-            e = (num - y[r0:r1, None]) / (1 - (sn[r0:r1, None] ** 2) * hs)
-        errs += sn[r0:r1] @ np.abs(e)
-        st["loo"] += time.perf_counter() - t0
-    return {"seconds": time.perf_counter() - t_all, "stages": st, "rows": n, "checksum": float(np.sum(errs) + np.abs(A).sum())}

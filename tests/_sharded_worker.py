@@ -18,10 +18,9 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 sys.path[:0] = [str(ROOT), str(ROOT / "oracle"), str(ROOT / "tests")]
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 import numpy as np  # noqa: E402
+
+torch = dist = None  # imported by the gloo modes only (main): the native-communicator modes need no torch at all
 
 
 class FakeLib:
@@ -161,9 +160,73 @@ def run_gpu(rank, world):
     ctx.close()
 
 
+def run_gpu_native(rank, world, expect_failure=False):
+    """All ranks share GPU 0 and join a NATIVE communicator (ctx->comm != NULL: the library's own ncclAllReduce / ncclBroadcast /
+    grouped-broadcast call sites), served by the test stand-in for librccl that NLS_RCCL_LIB points at (tests/csrc/rccl_shim.cpp).
+    Only rank 0 asks for the factor L_ (as bench.py does); every rank must end with the same beta."""
+    import neo_ls_svm_amd as hp
+    from neo_ls_svm_amd._lib import NLS_ERR_COMM, NlsError
+    from neo_ls_svm_amd.distributed import init_from_env, row_shard
+
+    ctx = hp.Context(0)
+    init_from_env(ctx)
+    assert ctx.comm_world == world
+    got = ctx.comm_allreduce([float(rank + 1), 1.0], "sum")
+    assert np.array_equal(got, [world * (world + 1) / 2, float(world)])
+    assert ctx.comm_allreduce([float(rank)], "max")[0] == world - 1
+    for clf in (False, True):
+        X, y, s, shift, scale, B = problem(n=5000, d=12, D=200, clf=clf)
+        lo, hi = row_shard(X.shape[0], rank, world)
+        if expect_failure:
+            try:
+                hp.primal_fit(X[lo:hi], y[lo:hi], s[lo:hi], shift, scale, B, clf, ctx=ctx, want_L=(rank == 0))
+            except NlsError as exc:  # NLS_ERR_COMM -> NlsError (RuntimeError); the message names the RCCL call
+                assert "ncclBroadcast" in str(exc) or "Broadcast" in str(exc), str(exc)
+                ctx.close()
+                return
+            raise AssertionError("the injected ncclBroadcast failure did not surface")
+        r = hp.primal_fit(X[lo:hi], y[lo:hi], s[lo:hi], shift, scale, B, clf, ctx=ctx, want_L=(rank == 0))
+        A, b = hp.gram(X[lo:hi], y[lo:hi], s[lo:hi], shift, scale, B, ctx=ctx)
+        solo = hp.Context(0)  # single-rank reference on all rows, no communicator
+        r1 = hp.primal_fit(X, y, s, shift, scale, B, clf, ctx=solo)
+        A1, b1 = hp.gram(X, y, s, shift, scale, B, ctx=solo)
+        solo.close()
+
+        def rel(a, bb):
+            return float(np.max(np.abs(a - bb)) / np.max(np.abs(bb)))
+
+        assert rel(A, A1) < 1e-12 and rel(b, b1) < 1e-12
+        assert r["opt"] == r1["opt"]
+        assert rel(r["beta"], r1["beta"]) < 1e-8
+        assert rel(r["lam"], r1["lam"]) < 1e-9
+        assert rel(r["loo_errors_gammas"], r1["loo_errors_gammas"]) < 1e-10
+        if rank == 0:
+            iu = np.triu_indices(B.shape[1] + 1)
+            assert rel(r["L"][iu], r1["L"][iu]) < 1e-9
+        else:
+            assert "L" not in r
+        for k in ("loo_residuals", "loo_leverage", "loo_std", "residuals"):
+            assert r[k].shape == (hi - lo,)
+            assert rel(r[k], r1[k][lo:hi]) < 1e-8, k
+        assert abs(r["loo_score"] - r1["loo_score"]) < 1e-10
+        # every rank holds the SAME beta (rank 0's, broadcast): sum over ranks == world x own
+        parts = np.concatenate([r["beta"].real, r["beta"].imag])[:64]
+        tot = ctx.comm_allreduce(parts, "sum")
+        assert np.array_equal(tot, world * parts) or rel(tot, world * parts) < 1e-15
+    ctx.close()
+
+
 if __name__ == "__main__":
     mode = sys.argv[1]
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    if mode in ("gpu_rccl", "gpu_rccl_fail"):
+        run_gpu_native(rank, world, expect_failure=(mode == "gpu_rccl_fail"))
+        print(f"OK {rank}", flush=True)
+        sys.exit(0)
+    import torch  # noqa: F811
+    import torch.distributed as dist  # noqa: F811
+
+    globals().update(torch=torch, dist=dist)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         (run_cpu if mode == "cpu" else run_gpu)(rank, world)

@@ -25,7 +25,11 @@ PRIMAL_CASES = [
     "primal_clf_n3000_d16_D256_wz",
     "primal_clf_n2500_d24_D192",
     "primal_reg_n2000_d48_D32",
+    # the feature-map plug-in point (_neo_ls_svm.py:62-75): plain RandomFourierFeatures; ORF over an AffineNormalizer (A = None)
+    "primal_reg_n2000_d12_RFF256",
+    "primal_clf_n1500_d10_ORF128_normalizer",
 ]
+PLUGIN_CASES = {"primal_reg_n2000_d12_RFF256": "rff", "primal_clf_n1500_d10_ORF128_normalizer": "orf_normalizer"}
 DUAL_CASES = ["dual_reg_n300_d12", "dual_clf_n500_d20_wz", "dual_reg_n1000_d32_w"]
 
 

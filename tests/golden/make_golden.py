@@ -45,7 +45,8 @@ sys.path[:0] = [_shim, str(REF / "src")]
 import neo_ls_svm._neo_ls_svm as ref_mod  # noqa: E402
 from neo_ls_svm import NeoLSSVM  # noqa: E402
 from neo_ls_svm._affine_separator import AffineSeparator  # noqa: E402
-from neo_ls_svm._feature_maps import OrthogonalRandomFourierFeatures  # noqa: E402
+from neo_ls_svm._affine_normalizer import AffineNormalizer  # noqa: E402
+from neo_ls_svm._feature_maps import OrthogonalRandomFourierFeatures, RandomFourierFeatures  # noqa: E402
 
 _captured: dict = {}
 _orig_eigh, _orig_cho = ref_mod.eigh, ref_mod.cho_factor
@@ -86,15 +87,19 @@ def weights(rng, n, kind):
     return s
 
 
-def primal_case(name, n, d, D, task, wkind, seed, nq=257, store_A=False):
+def primal_case(name, n, d, D, task, wkind, seed, nq=257, store_A=False, fm=None):
+    """``fm``: the primal feature map handed to ``NeoLSSVM`` (default: ``OrthogonalRandomFourierFeatures(num_features=D)``) - the
+    plug-in point of ``_neo_ls_svm.py:62-75,380-394``: plain ``RandomFourierFeatures`` or a map with a caller-chosen affine map."""
     rng, X, y = synth(n, d, task, seed)
     s = weights(rng, n, wkind)
     Xq = rng.standard_normal((nq, d))
     _captured.clear()
-    fm = OrthogonalRandomFourierFeatures(num_features=D)
+    fm = OrthogonalRandomFourierFeatures(num_features=D) if fm is None else fm
     m = NeoLSSVM(primal_feature_map=fm, dual=False).fit(X, y, sample_weight=s)
     afm = m.primal_feature_map_.affine_feature_map
     sep = AffineSeparator().fit(X, m.classes_.searchsorted(y) * 2.0 - 1 if task == "clf" else y, s)
+    if not isinstance(afm, AffineSeparator):
+        sep.A_ = np.zeros((0, 0))  # no separator inside this map
     out = dict(
         kind="primal",
         task=task,
@@ -295,6 +300,11 @@ if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[2] == "ames":  # only the ames-shaped case (added in round 2)
         ames_case("primal_reg_ames_n2930_d301_D512")
         raise SystemExit(0)
+    if len(sys.argv) > 2 and sys.argv[2] == "plugins":  # the feature-map plug-in point (added in round 4)
+        primal_case("primal_reg_n2000_d12_RFF256", 2000, 12, 256, "reg", "uniform", seed=11, nq=65, fm=RandomFourierFeatures(num_features=256))
+        primal_case("primal_clf_n1500_d10_ORF128_normalizer", 1500, 10, 128, "clf", "unit", seed=12, nq=65,
+                    fm=OrthogonalRandomFourierFeatures(affine_feature_map=AffineNormalizer(), num_features=128))
+        raise SystemExit(0)
     if len(sys.argv) > 2 and sys.argv[2] == "exactC":  # only the exact-complexity-matrix cases (added in round 2)
         exact_complexity_case("primal_reg_n400_d8_D192_exactC", 400, 8, 192, "reg", seed=9)
         exact_complexity_case("primal_clf_n300_d6_D128_exactC", 300, 6, 128, "clf", seed=10)
@@ -311,3 +321,6 @@ if __name__ == "__main__":
     ames_case("primal_reg_ames_n2930_d301_D512")
     exact_complexity_case("primal_reg_n400_d8_D192_exactC", 400, 8, 192, "reg", seed=9)
     exact_complexity_case("primal_clf_n300_d6_D128_exactC", 300, 6, 128, "clf", seed=10)
+    primal_case("primal_reg_n2000_d12_RFF256", 2000, 12, 256, "reg", "uniform", seed=11, nq=65, fm=RandomFourierFeatures(num_features=256))
+    primal_case("primal_clf_n1500_d10_ORF128_normalizer", 1500, 10, 128, "clf", "unit", seed=12, nq=65,
+                fm=OrthogonalRandomFourierFeatures(affine_feature_map=AffineNormalizer(), num_features=128))

@@ -180,11 +180,25 @@ def test_rendezvous_file_exchange(tmp_path, monkeypatch):
     prim, sec = distributed._rendezvous_files(None)
     assert prim.read_bytes()[:128] == bytes(range(128)) and sec.read_bytes()[:128] == bytes(range(128))
     assert (prim.stat().st_mode & 0o777) == 0o600
-    # a file left behind by a launch that died after publishing is stale: it is not joined
-    stale = bytes(range(128)) + repr(distributed.time.time() - 10 * distributed._FRESH_SECONDS).encode()
-    (tmp_path / "nls_rccl_id_old").write_bytes(stale)
+    # an explicit key is the caller's own rendezvous: joined whatever its age (a rank may arrive long after rank 0 published) ...
+    old = bytes(range(1, 129)) + repr(0.0).encode()
+    (tmp_path / "nls_rccl_id_job.1").write_bytes(old)
+    os.utime(tmp_path / "nls_rccl_id_job.1", (1.0, 1.0))
+    assert distributed.exchange_unique_id(Ctx(), 1, 2, key="job.1", timeout=0.2) == bytes(range(1, 129))
+    # ... and a key with a dot keeps its whole name while it is being published (the temporary file is <name>.tmp<pid>)
+    assert distributed.exchange_unique_id(Ctx(), 0, 2, key="job.1") == bytes(range(128))
+    assert (tmp_path / "nls_rccl_id_job.1").read_bytes()[:128] == bytes(range(128)) and not list(tmp_path.glob("*.tmp*"))
+    # an automatic (launcher-derived) name left behind by a launch that died after publishing is stale - by the FILE's own
+    # modification time, not by a clock reading inside the payload: it is not joined
+    age = 10 * distributed._fresh_seconds()
+    os.utime(prim, (prim.stat().st_mtime - age, prim.stat().st_mtime - age))
+    os.utime(sec, (sec.stat().st_mtime - age, sec.stat().st_mtime - age))
     with pytest.raises(TimeoutError):
-        distributed.exchange_unique_id(Ctx(), 1, 2, key="old", timeout=0.2)
+        distributed.exchange_unique_id(Ctx(), 1, 2, timeout=0.2)
+    monkeypatch.setenv("NLS_RENDEZVOUS_FRESH_SECONDS", str(100 * age))  # read at call time: a wider window accepts it again
+    assert distributed.exchange_unique_id(Ctx(), 1, 2, timeout=0.2) == bytes(range(128))
+    monkeypatch.delenv("NLS_RENDEZVOUS_FRESH_SECONDS")
+    assert distributed.exchange_unique_id(Ctx(), 0, 2) == bytes(range(128))  # published again: fresh
     prim.unlink()  # a rank whose parent pid differs would not find the primary: after 15 s it takes the fresh secondary
     monkeypatch.setattr(distributed.time, "monotonic", iter([0.0, 16.0, 17.0, 18.0]).__next__)
     assert distributed.exchange_unique_id(Ctx(), 1, 2, timeout=100) == bytes(range(128))
@@ -287,6 +301,23 @@ def test_sigma_grid_merge_over_ranks(monkeypatch):
             assert (bound is None) == (best == np.inf)
             assert finished == (curves[k].min() < best)
             best = min(best, curves[k].min()) if finished else best
+    # an exact tie between sigmas owned by different ranks: after the merge every rank must name the SAME winner (the smallest
+    # tied index), whatever its own incumbent is
+    saved = curves.copy()
+    curves[1, 3] = 0.5  # ties with (4, 2); sigma 1 belongs to rank 1, sigma 4 to rank 1 too -> also tie sigma 2 (rank 2)
+    curves[2, 0] = 0.5
+    contribs.clear()
+    for rank in range(world):
+        hotpath.primal_fit_sigma_grid(None, None, None, None, None, B, False, sig, gammas=np.arange(1.0, G + 1), rank=rank, world=world,
+                                      allreduce_sum=lambda a: contribs.append(a.copy()) or a)  # fmt: skip
+    total = sum(contribs)
+    winners = set()
+    for rank in range(world):
+        g = hotpath.primal_fit_sigma_grid(None, None, None, None, None, B, False, sig, gammas=np.arange(1.0, G + 1), rank=rank, world=world,
+                                          allreduce_sum=lambda a: total.copy())  # fmt: skip
+        winners.add((g["sigma_index"], g["gamma_index"]))
+    assert winners == {(1, 3)}
+    curves[:] = saved
     # single rank, no all-reduce: the full table and the winner
     calls.clear()
     g = hotpath.primal_fit_sigma_grid(None, None, None, None, None, B, False, sig, gammas=np.arange(1.0, G + 1))

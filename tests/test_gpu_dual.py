@@ -102,3 +102,21 @@ def test_own_cholesky_reports_the_first_bad_pivot(hp):
     with pytest.raises(np.linalg.LinAlgError) as err:
         hp.cholesky(B)
     assert f"pivot {first_bad} " in str(err.value)
+
+
+@pytest.mark.parametrize("gi", [0, 127])
+def test_alpha_is_the_cholesky_resolve(gi, golden_loader, hp):
+    """``_neo_ls_svm.py:313-314``: alpha = cho_solve(cho_factor(gamma* diag(sn^-2) + K), y): with the factor requested the returned
+    pair satisfies it to rounding, at both edges of the gamma grid; without it alpha comes from the eigendecomposition and agrees
+    far inside the parity bar."""
+    import scipy.linalg as sla
+
+    g = golden_loader("dual_reg_n1000_d32_w")
+    nz = g["nz"]
+    Xt, y, s = g["Xt"], signed_targets(g)[nz], g["s"][nz]
+    r = hp.dual_fit(Xt, y, s, False, gamma_index=gi)
+    a_ref = sla.cho_solve((r["L"], False), y)
+    assert np.linalg.norm(r["alpha"] - a_ref) <= 1e-10 * np.linalg.norm(a_ref)
+    r2 = hp.dual_fit(Xt, y, s, False, gamma_index=gi, want_L=False)
+    assert np.linalg.norm(r2["alpha"] - r["alpha"]) <= 1e-7 * np.linalg.norm(r["alpha"])
+    assert np.array_equal(r2["loo_residuals"], r["loo_residuals"]) and np.array_equal(r2["loo_std"], r["loo_std"])

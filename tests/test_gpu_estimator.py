@@ -6,27 +6,35 @@ import pickle
 
 import numpy as np
 import pytest
-from conftest import DUAL_CASES, PRIMAL_CASES, relerr
+from conftest import DUAL_CASES, PLUGIN_CASES, PRIMAL_CASES, relerr
 
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-5
 
 
-def _fit(g, dual):
+def _fit(g, dual, kind=None):
     from neo_ls_svm_amd import NeoLSSVM, OrthogonalRandomFourierFeatures
 
     sw = g["s"] if bool(g["has_weights"]) else None
     if dual:
         return NeoLSSVM(dual=True).fit(g["X"], g["y"], sample_weight=sw)
     fm = OrthogonalRandomFourierFeatures(num_features=int(g["D"]))
+    if kind == "rff":  # plain random Fourier features (_feature_maps.py:117-151)
+        from neo_ls_svm_amd import RandomFourierFeatures
+
+        fm = RandomFourierFeatures(num_features=int(g["D"]))
+    elif kind == "orf_normalizer":  # a caller-chosen affine map inside the ORF map
+        from neo_ls_svm_amd import AffineNormalizer
+
+        fm = OrthogonalRandomFourierFeatures(affine_feature_map=AffineNormalizer(), num_features=int(g["D"]))
     return NeoLSSVM(primal_feature_map=fm, dual=False).fit(g["X"], g["y"], sample_weight=sw)
 
 
 @pytest.mark.parametrize("name", PRIMAL_CASES)
 def test_primal_estimator_matches_reference(name, golden_loader):
     g = golden_loader(name)
-    m = _fit(g, dual=False)
+    m = _fit(g, dual=False, kind=PLUGIN_CASES.get(name))
     assert m.primal_ and not m.dual_
     assert m._estimator_type == ("classifier" if g["task"] == "clf" else "regressor")
     assert relerr(m.primal_feature_map_.B_, g["B"]) < 1e-9
@@ -133,3 +141,29 @@ def test_sklearn_check_estimator_report():
         print(kind, "passed", passed, "failed", failed)
         assert set(failed) == EXPECTED_CHECK_FAILURES[kind], failed
         assert passed >= 50
+
+
+def test_plugin_points_are_honoured_or_refused():
+    """``primal_feature_map`` / ``dual_feature_map`` (``_neo_ls_svm.py:62-75,380-394``): a caller's affine map is used as given, a feature map
+    this library cannot evaluate raises TypeError - the model is never silently replaced."""
+    from neo_ls_svm_amd import AffineFeatureMap, AffineNormalizer, NeoLSSVM, RandomFourierFeatures
+
+    rng = np.random.default_rng(5)
+    X = rng.standard_normal((1500, 6)) * [1, 2, 3, 4, 5, 6] + 3
+    y = np.sin(X[:, 0]) + 0.1 * rng.standard_normal(1500)
+    with pytest.raises(TypeError, match="primal_feature_map"):
+        NeoLSSVM(primal_feature_map=object(), dual=False).fit(X, y)
+    with pytest.raises(TypeError, match="affine map"):
+        NeoLSSVM(dual_feature_map=object(), dual=True).fit(X[:300], y[:300])
+    # dual path over a caller-chosen affine map: X_ is exactly that map's image
+    m = NeoLSSVM(dual_feature_map=AffineNormalizer(), dual=True).fit(X[:400], y[:400])
+    fm = m.dual_feature_map_
+    assert fm.A_ is None and relerr(m.X_, (X[:400] - fm.shift_) / fm.scale_) < 1e-14
+    assert np.isfinite(m.predict_std(X[400:450])).all() and m.score(X[:400], y[:400]) > 0.5
+    # primal path over FIXED affine parameters: B = A Z with Z = RandomState(42).randn, nothing fitted
+    A = rng.standard_normal((6, 4)) / 6
+    fixed = AffineFeatureMap(scale=X.std(0), shift=X.mean(0), A=A)
+    m = NeoLSSVM(primal_feature_map=RandomFourierFeatures(affine_feature_map=fixed, num_features=96), dual=False).fit(X, y)
+    Z = np.random.RandomState(42).randn(4, 96)
+    assert relerr(m.primal_feature_map_.B_, A @ Z) < 1e-14 and np.array_equal(m.primal_feature_map_.shift_, X.mean(0))
+    assert m.β̂_.shape == (97,) and m.score(X, y) > 0.5

@@ -92,11 +92,16 @@ def test_c4_dual_identities():
     assert np.all(np.isfinite(sigma)) and np.all(sigma >= 0)
 
 
-def test_c5_sigma_grid_fullsize_three_sigmas():
-    """BASELINE config 5 at FULL size (n = 1e6, d = 128, D = 4096, 32 gammas) on three sigmas: the early-out driver
-    (``NLS_FIT_FINISH_IF_BELOW``: a sigma that cannot beat the incumbent stops after the selection) must pick the same (sigma, gamma)
-    and return the same winner as three unconditional fits, and every sigma's curve must satisfy the c3 identities that need no
-    oracle: argmin of its own error curve, trace(A) / c = sum(lam), LOO error = sum s |e_loo| at the selected gamma."""
+def test_c5_sigma_grid_full_16x32():
+    """BASELINE config 5 exactly as ``bench.py --config c5`` runs it: n = 1e6, d = 128, D = 4096, the 16 sigmas
+    ``logspace(1/4, 4, 16)`` x the 32 gammas ``gamma_grid(1024)[::33]``.  Every sigma - the extremes 1/4 (arguments x 4) and 4
+    (features nearly collinear: the most ill-conditioned normal equations of the grid) included - is also fitted UNCONDITIONALLY with
+    its Cholesky factor, and must satisfy the identities of ``test_c3_identities`` that need no oracle:
+      argmin of its own curve; trace(A) / c = sum(lam); LOO error = sum s |e_loo| at gamma*; e_loo (1 - leverage) = residuals_ on all
+      rows; the normal equations (gamma* c I + A) beta = b; beta == cho_solve(L_, b) (``_neo_ls_svm.py:176-178``).
+    The early-out driver's 16 x 32 table must equal the table of those curves bit for bit and name the same winner."""
+    import scipy.linalg as sla
+
     import bench
     import neo_ls_svm_amd as hp
 
@@ -108,25 +113,49 @@ def test_c5_sigma_grid_fullsize_three_sigmas():
     sn = s / s.sum()
     shift, scale, B = bench.affine_params(n, d, D, ctx=ctx)
     dX, dy, ds = ctx.to_device(X), ctx.to_device(y), ctx.to_device(s)
+    del X
     gammas = hp.gamma_grid(1024)[::33]
-    sigmas = np.array([0.5, 1.0, 2.0])
+    sigmas = np.logspace(np.log10(0.25), np.log10(4.0), cfg["sigmas"])
+    assert gammas.size == 32 and sigmas.size == 16
     grid = hp.primal_fit_sigma_grid(dX, dy, ds, shift, scale, B, False, sigmas, gammas=gammas, ctx=ctx)
     c = 1.0 / (n * (D + 1))
-    full = []
+    curves, minima, report = [], [], []
+    best_full = None
     for k, sg in enumerate(sigmas):
         r = hp.primal_fit(dX, y, s, shift, scale, B / sg, False, gammas=gammas, ctx=ctx)
-        full.append(r)
-        # the driver's table row is this fit's curve (bit for bit: same kernels, same inputs)
         assert np.array_equal(grid["loo_errors"][k], r["loo_errors_gammas"]), k
+        assert np.array_equal(grid["objective"][k], r["objective"]), k
         assert r["opt"] == int(np.argmin(r["loo_errors_gammas"]))
-        assert abs(np.sum(sn * np.abs(r["loo_residuals"])) - r["loo_errors_gammas"][r["opt"]]) <= 1e-10 * r["loo_errors_gammas"][r["opt"]]
-        A, _ = hp.gram(dX, y, s, shift, scale, B / sg, ctx=ctx)
-        assert abs(np.trace(A).real / c - r["lam"].sum()) <= 1e-9 * r["lam"].sum()
+        e_opt = r["loo_errors_gammas"][r["opt"]]
+        assert abs(np.sum(sn * np.abs(r["loo_residuals"])) - e_opt) <= 1e-10 * e_opt
         lev = r["loo_leverage"]
+        assert np.all(lev > 0) and np.all(lev < 1)
         assert np.max(np.abs(r["loo_residuals"] * (1.0 - lev) - r["residuals"])) <= 1e-8 * np.max(np.abs(r["residuals"]))
-    k_best = int(np.argmin([r["loo_errors_gammas"].min() for r in full]))
-    assert grid["sigma_index"] == k_best and grid["gamma_index"] == full[k_best]["opt"]
+        A, b = hp.gram(dX, y, s, shift, scale, B / sg, ctx=ctx)
+        lam = r["lam"]
+        assert np.all(np.diff(lam) >= 0) and lam[0] > -1e-9 * lam[-1]
+        assert abs(np.trace(A).real / c - lam.sum()) <= 1e-9 * lam.sum()
+        resid = np.linalg.norm((r["gamma"] * c) * r["beta"] + A @ r["beta"] - b) / np.linalg.norm(b)
+        assert resid <= 1e-9, (k, resid)
+        beta_chol = sla.cho_solve((r["L"], False), b)
+        dbeta = np.linalg.norm(r["beta"] - beta_chol) / np.linalg.norm(beta_chol)
+        assert dbeta <= 1e-9, (k, dbeta)
+        report.append((float(sg), int(r["opt"]), float(e_opt), float(lam[0]), float(lam[-1]), float(resid), float(dbeta)))
+        curves.append(r["loo_errors_gammas"])
+        minima.append(r["objective"].min())
+        if best_full is None or r["objective"].min() < best_full[0]:
+            best_full = (r["objective"].min(), k, {key: r[key].copy() for key in ("beta", "loo_residuals", "loo_leverage", "loo_std", "residuals")}, r["opt"])
+        del r, A
+    k_best = int(np.argmin(minima))
+    assert grid["sigma_index"] == k_best == best_full[1] and grid["gamma_index"] == best_full[3]
     best = grid["best"]
     assert best is not None
     for key in ("beta", "loo_residuals", "loo_leverage", "loo_std", "residuals"):
-        assert np.array_equal(best[key], full[k_best][key]), key
+        assert np.array_equal(best[key], best_full[2][key]), key
+    out = ROOT / "gpurun_out"
+    out.mkdir(exist_ok=True)
+    with open(out / "c5_full_grid_report.txt", "w") as fh:
+        fh.write("sigma gamma_index loo_error lam_min lam_max normal_eq_residual beta_vs_cho_solve\n")
+        for row in report:
+            fh.write(" ".join(f"{v:.6g}" for v in row) + "\n")
+        fh.write(f"winner sigma_index {k_best} gamma_index {best_full[3]}\n")

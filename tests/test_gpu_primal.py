@@ -393,3 +393,25 @@ def test_c_abi_edge_cases_of_the_round2_entry_points(golden_loader, hp):
             ctx.comm_init(b"short", 0, 1)
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("name", ["primal_reg_n3000_d20_D256", "primal_clf_n3000_d16_D256_wz"])
+@pytest.mark.parametrize("gi", [0, 1023])
+def test_beta_is_the_cholesky_resolve(name, gi, golden_loader, hp):
+    """``_neo_ls_svm.py:176-178``: beta = cho_solve(cho_factor(gamma* C + A), b).  At the SMALL-gamma edge of the grid (index 0:
+    gamma = 1e-6, the worst-conditioned system of the sweep) and at the large one, the returned pair must satisfy
+    beta == cho_solve(L_, b) to rounding, and a fit that does not ask for L_ (beta from the eigendecomposition, positive definiteness
+    checked on the eigenvalues) must agree with it far inside the parity bar."""
+    import scipy.linalg as sla
+
+    g = golden_loader(name)
+    y, is_clf = signed_targets(g), g["task"] == "clf"
+    r = hp.primal_fit(g["X"], y, g["s"], g["shift"], g["scale"], g["B"], is_clf, gamma_index=gi)
+    _, b = hp.gram(g["X"], y, g["s"], g["shift"], g["scale"], g["B"])
+    beta_ref = sla.cho_solve((r["L"], False), b)
+    assert np.linalg.norm(r["beta"] - beta_ref) <= 1e-10 * np.linalg.norm(beta_ref)
+    r2 = hp.primal_fit(g["X"], y, g["s"], g["shift"], g["scale"], g["B"], is_clf, gamma_index=gi, want_L=False)
+    assert "L" not in r2
+    assert np.linalg.norm(r2["beta"] - r["beta"]) <= 1e-7 * np.linalg.norm(r["beta"])
+    for k in ("loo_residuals", "loo_leverage", "loo_std", "residuals", "loo_errors_gammas"):
+        assert np.array_equal(r2[k], r[k]), k

@@ -166,3 +166,30 @@ def test_fits_through_the_two_stage_reduction_match_the_reference(hp, monkeypatc
     assert r["opt"] == int(g["opt"])
     for k in ("alpha", "loo_residuals", "loo_std", "residuals", "loo_errors_gammas"):
         assert relerr(r[k], g[k]) < 1e-9, k
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+def test_a_rejected_chase_falls_back_to_the_one_stage_reduction(cplx, hp, monkeypatch):
+    """The band -> tridiagonal chase hands data between workgroups inside one launch; its result is checked through the invariants of
+    a unitary similarity (trace, Frobenius norm) and a time-out word.  A rejected chase (here: injected) must not fail the
+    eigendecomposition: the matrix is restored and the one-stage panel delivers the same decomposition; the fall-back is counted."""
+    monkeypatch.setenv("NLS_EVD", "twostage")
+    ctx = hp.default_context()
+    n = 520
+    A = _herm(n, cplx, 5)
+    lam0, Q0 = hp.eigh(A)  # through the two-stage reduction; the invariants check passes
+    st = ctx.evd_stage_ms()
+    assert st is not None and st["kind"].startswith("two-stage") and st["n"] == n and st["total"] > 0
+    fb = ctx.lib.nls_twostage_fallbacks(ctx.handle)
+    monkeypatch.setenv("NLS_CHASE_INJECT_FAILURE", "1")
+    lam, Q = hp.eigh(A)
+    assert ctx.lib.nls_twostage_fallbacks(ctx.handle) == fb + 1
+    st = ctx.evd_stage_ms()
+    assert st["kind"].startswith("one-stage") and set(st) >= {"tridiagonalisation", "stedc", "back_transformation", "total"}
+    scale = np.max(np.abs(lam0))
+    assert np.max(np.abs(lam - lam0)) <= 1e-13 * n * scale
+    assert np.max(np.abs(A @ Q - Q * lam[None, :])) <= 1e-13 * n * scale
+    assert np.max(np.abs(Q.conj().T @ Q - np.eye(n))) <= 1e-13 * n
+    monkeypatch.delenv("NLS_CHASE_INJECT_FAILURE")
+    lam, _ = hp.eigh(A)
+    assert ctx.lib.nls_twostage_fallbacks(ctx.handle) == fb + 1 and np.array_equal(lam, lam0)

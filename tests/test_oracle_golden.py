@@ -4,7 +4,7 @@ from __future__ import annotations
 
 import numpy as np
 import pytest
-from conftest import DUAL_CASES, PRIMAL_CASES, relerr, signed_targets
+from conftest import DUAL_CASES, PLUGIN_CASES, PRIMAL_CASES, relerr, signed_targets
 
 import neolssvm_oracle as orc
 
@@ -14,9 +14,12 @@ TOL = 1e-8  # oracle vs reference, float64 both sides; the HIP parity bar is 1e-
 @pytest.mark.parametrize("name", PRIMAL_CASES)
 def test_orf_frequencies_and_fold_bitwise(name, golden_loader):
     g = golden_loader(name)
-    Z = orc.orf_frequencies(g["A_sep"].shape[1], int(g["D"]), seed=42)
+    kind = PLUGIN_CASES.get(name)
+    A_sep = None if kind == "orf_normalizer" else g["A_sep"]  # an AffineNormalizer has no matrix: Z acts on the d inputs themselves
+    d_in = g["X"].shape[1] if A_sep is None else A_sep.shape[1]
+    Z = (orc.rff_frequencies if kind == "rff" else orc.orf_frequencies)(d_in, int(g["D"]), seed=42)
     assert np.array_equal(Z, g["Z"])
-    assert np.array_equal(orc.fold_projection(g["A_sep"], Z), g["B"])
+    assert np.array_equal(orc.fold_projection(A_sep, Z), g["B"])
 
 
 @pytest.mark.parametrize("name", PRIMAL_CASES)

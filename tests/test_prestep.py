@@ -4,7 +4,7 @@ from __future__ import annotations
 
 import numpy as np
 import pytest
-from conftest import DUAL_CASES, PRIMAL_CASES, relerr, signed_targets
+from conftest import DUAL_CASES, PLUGIN_CASES, PRIMAL_CASES, relerr, signed_targets
 
 from neo_ls_svm_amd import _prestep
 
@@ -17,11 +17,75 @@ def test_separator_matches_reference(name, golden_loader):
         nz = g["nz"]
         X, y, s = X[nz], y[nz], s[nz]
     sw = s if bool(g["has_weights"]) else None
+    if PLUGIN_CASES.get(name) == "orf_normalizer":  # the fixture's affine map is an AffineNormalizer: shift / scale only, A = None
+        shift, scale = _prestep.fit_affine_normalizer(X, y, sw)
+        assert relerr(np.ravel(shift), g["shift"]) < 1e-12 and relerr(np.ravel(scale), g["scale"]) < 1e-12
+        assert g["B"].shape == (X.shape[1], int(g["D"])) and np.array_equal(g["B"], g["Z"])  # B = Z: nothing to fold
+        return
     shift, scale, A = _prestep.fit_affine_separator(X, y, sw)
     assert relerr(np.ravel(shift), g["shift"]) < 1e-12
     assert relerr(np.ravel(scale), g["scale"]) < 1e-12
     assert A.shape == g["A_sep"].shape
     assert relerr(A, g["A_sep"]) < 1e-9
+
+
+def test_plain_rff_frequencies_are_the_reference_stream(golden_loader):
+    """RandomFourierFeatures (``_feature_maps.py:120-127``): Z = RandomState(42).randn(d', D), no QR, no chi rescaling; B = A Z."""
+    g = golden_loader("primal_reg_n2000_d12_RFF256")
+    Z = np.random.RandomState(42).randn(*g["Z"].shape)
+    assert np.array_equal(Z, g["Z"])
+    assert relerr(g["A_sep"] @ Z, g["B"]) < 1e-13
+
+
+def test_foreign_feature_maps_are_translated_or_refused():
+    """The primal / dual plug-in points (``_neo_ls_svm.py:62-75,380-394``): upstream's classes are translated by name and public
+    parameters, own classes pass, anything else raises TypeError - never a silent substitution."""
+    from neo_ls_svm_amd import estimator as est
+
+    class OrthogonalRandomFourierFeatures:  # stands in for upstream's class (same name, public parameters)
+        def __init__(self):
+            self.num_features, self.random_state, self.affine_feature_map = 192, 7, None
+
+    class RandomFourierFeatures(OrthogonalRandomFourierFeatures):
+        pass
+
+    fm = est._as_own_feature_map(OrthogonalRandomFourierFeatures())
+    assert type(fm) is est.OrthogonalRandomFourierFeatures and (fm.num_features, fm.random_state) == (192, 7)
+    fm = est._as_own_feature_map(RandomFourierFeatures())
+    assert type(fm) is est.RandomFourierFeatures and fm.orthogonal is None and not fm.orthogonal_default
+    own = est.RandomFourierFeatures(num_features=64, orthogonal=True)
+    assert est._as_own_feature_map(own) is own
+
+    class Nystroem:
+        num_features = 10
+
+    with pytest.raises(TypeError, match="primal_feature_map"):
+        est._as_own_feature_map(Nystroem())
+    with pytest.raises(TypeError, match="not an affine map"):
+        est._as_own_affine_map(object())
+
+    class MyAffine:  # a caller's affine map: fit + shift / scale / A attributes
+        def fit(self, X, y=None, sample_weight=None):
+            self.shift_, self.scale_, self.A_ = X.mean(0), X.std(0), None
+            return self
+
+    a = MyAffine()
+    assert est._as_own_affine_map(a) is a
+    X = np.random.default_rng(0).standard_normal((50, 3))
+    fitted = est._fit_affine(a, X, None, None, None)
+    sh, sc, A = est._affine_params(fitted)
+    assert np.allclose(sh, X.mean(0)) and A is None
+
+    class NotAffine:
+        def fit(self, X, y=None, sample_weight=None):
+            return self
+
+    with pytest.raises(TypeError, match="exposes no shift"):
+        est._fit_affine(NotAffine(), X, None, None, None)
+    fixed = est.AffineFeatureMap(scale=np.array([1.0, 2.0, 4.0]), shift=np.zeros(3), A=np.eye(3)[:, :2])
+    assert np.allclose(fixed.fit(X).transform(X), (X / [1.0, 2.0, 4.0])[:, :2])
+    with pytest.raises(ValueError):
+        est.AffineFeatureMap(scale=np.array([1.0, 0.0, 4.0]), shift=np.zeros(3)).fit(X)
 
 
 def test_target_bins_regression_and_classes():

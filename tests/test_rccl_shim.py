@@ -1,0 +1,106 @@
+"""The library's NATIVE collective path (``ctx->comm != NULL``) with more than one rank, on ONE GPU.
+
+RCCL refuses two ranks per device and the pool's boxes have one GPU, so without this the ``ncclAllReduce`` / ``ncclBroadcast`` /
+grouped-broadcast call sites of ``csrc/nls_host.h`` and ``csrc/nls_evd.hip`` would first run with world > 1 on an 8-GPU node.
+``tests/csrc/rccl_shim.cpp`` is a test stand-in for ``librccl.so.1`` (shared-memory staging between processes that share GPU 0);
+the library finds it through ``NLS_RCCL_LIB``.  The shim itself is checked on the CPU first (host-only build)."""
+
+from __future__ import annotations
+
+import os
+import socket
+import subprocess
+import sys
+import tempfile
+from pathlib import Path
+
+import pytest
+
+HERE = Path(__file__).resolve().parent
+SHIM_SRC = HERE / "csrc" / "rccl_shim.cpp"
+SHIM_DIR = HERE / "csrc" / "_shim"
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+def build_shim(host_only: bool) -> Path:
+    out = SHIM_DIR / ("librccl_hostonly.so" if host_only else "librccl.so.1")
+    if not out.exists() or out.stat().st_mtime < SHIM_SRC.stat().st_mtime:
+        SHIM_DIR.mkdir(exist_ok=True)
+        cmd = [HIPCC, "-shared", "-fPIC", "-O2", "-std=c++17", str(SHIM_SRC), "-o", str(out), "-lrt"] + (["-DSHIM_HOST_ONLY"] if host_only else [])
+        subprocess.run(cmd, check=True, capture_output=True, text=True)
+    return out
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run_ranks(argv, world, env_extra, timeout):
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, **env_extra, RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="2", OPENBLAS_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")  # fmt: skip
+        procs.append(subprocess.Popen([sys.executable] + argv, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"OK {rank}" in out, f"rank {rank} failed:\n{out[-3000:]}"
+
+
+@pytest.mark.parametrize("world, fail_at", [(2, 0), (3, 0), (3, 1), (3, 3)])
+def test_shim_protocol_cpu(world, fail_at):
+    """The stand-in itself: chunked in-place sum, out-of-place max, broadcast from a non-zero root, a group of unequal
+    broadcasts, and the injected failure (alone and inside a group) - on host buffers, N processes."""
+    lib = build_shim(host_only=True)
+    with tempfile.TemporaryDirectory() as td:
+        env = {"NLS_SHIM_SLOT_BYTES": "8192", "NLS_SHIM_TIMEOUT_S": "30"}
+        if fail_at:
+            env["NLS_SHIM_FAIL_BROADCAST"] = str(fail_at)
+        _run_ranks([str(HERE / "_shim_worker.py"), str(lib), str(Path(td) / "id")], world, env, timeout=120)
+
+
+def _launch_native(mode, world, extra_env=None, timeout=900):
+    lib = build_shim(host_only=False)
+    with tempfile.TemporaryDirectory() as td:
+        env = {"NLS_RCCL_LIB": str(lib), "NLS_RENDEZVOUS_DIR": td, "NLS_SHIM_SLOT_BYTES": str(1 << 20), "NLS_SHIM_TIMEOUT_S": "300", **(extra_env or {})}
+        _run_ranks([str(HERE / "_sharded_worker.py"), mode], world, env, timeout)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_native_communicator_world_n_one_gpu(world):
+    """Row-sharded fits (regression and classification) through the library's own RCCL call sites, world 2 and 3: equal to the
+    single-rank fit; ``L_`` only on rank 0; beta identical on every rank; one-stage eigendecomposition (rank-0 ``stedc`` + real
+    broadcast + column-split back-transformation + grouped all-gather of unequal blocks)."""
+    _launch_native("gpu_rccl", world)
+
+
+@pytest.mark.gpu
+def test_native_communicator_two_stage_evd():
+    """The same with the two-stage reduction forced: both back-transformations split by columns, the ranks vote on the
+    chase's invariants check (one more all-reduce)."""
+    _launch_native("gpu_rccl", 3, {"NLS_EVD": "twostage"})
+
+
+@pytest.mark.gpu
+def test_native_communicator_failure_is_an_error_on_every_rank():
+    """Failure injection: the 2nd ``ncclBroadcast`` of every rank (the eigenvalues, after the status flag of the rank-0 ``stedc``)
+    returns an error: every rank must get NLS_ERR_COMM (``NlsError``) - nobody hangs."""
+    _launch_native("gpu_rccl_fail", 2, {"NLS_SHIM_FAIL_BROADCAST": "2"}, timeout=300)
+
+
+@pytest.mark.gpu
+def test_native_communicator_failure_inside_the_group():
+    """... and inside the grouped all-gather (broadcasts 4.. of a fit: flag, lam, eigenvectors come first): the group is closed,
+    the error surfaces, nobody hangs."""
+    _launch_native("gpu_rccl_fail", 2, {"NLS_SHIM_FAIL_BROADCAST": "5"}, timeout=300)

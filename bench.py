@@ -233,6 +233,9 @@ def end_to_end_fit(cfg, ctx, dual=False):
         "fits_per_s": 1.0 / t,
         "stage_seconds": {k: round(v, 4) for k, v in est.fit_wall_.items()},
         "solver_seconds_inside": round(est.fit_timings_["total"], 4),
+        "solver_stage_ms": {k: round(1e3 * v, 3) for k, v in est.fit_timings_.items() if k in (
+            "upload", "featuremap", "gram", "evd", "rotate", "sweep", "loo", "cholesky", "residuals", "download")},
+        "evd_stage_ms": ctx.evd_stage_ms(),
         "gamma_index": int(list(est.γs_).index(est.γ_)) if est.γ_ in est.γs_ else None,
         "note": "NeoLSSVM.fit(X, y) from host arrays, pre-step fitted on all rows (the timed solver step above uses the pre-step of the "
         "first 2e5 rows, SURVEY 8(d)); second of two calls",

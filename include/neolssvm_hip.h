@@ -32,8 +32,11 @@
  *     which (hipPointerGetAttributes).  Device-resident inputs are used in place, host inputs are
  *     staged with one H2D copy.  Small parameter arrays (shift, scale, B, gammas, beta, L, alpha) and
  *     all outputs are host pointers.  Nothing is retained after a call returns.
- *   - Calls are blocking; one host thread per context, and ONE fitting context per process and GPU at a time: two contexts of one process
- *     running fits concurrently is not a supported mode (profiles/r03_sigma_overlap.log).  The library never uses a CPU fallback.
+ *   - Calls are blocking; one host thread per context.  Several contexts of one process may run fits on the same GPU at the same time (each
+ *     owns its streams, handles and workspace): tests/test_gpu_two_contexts.py holds two contexts with fits in flight to the bits of the same fits
+ *     run alone.  (Round 3's failures in this mode were rocsolver_zpotrf, which is not safe on two handles at once in this ROCm build -
+ *     profiles/r04_two_contexts.md; the fit path no longer calls it.  NLS_POTRF=rocsolver, a diagnostic knob, brings it back: single context only.)
+ *     The library never uses a CPU fallback.
  *   - Multi-GPU: one process and one context per GPU, rows sharded by the caller.  The path exchanges data at
  *     four points: {sum s, sum s*y, n}, the Hermitian block A||b (sum all-reduce), the eigenvectors (rank 0 runs the
  *     tridiagonal eigensolver and broadcasts; every rank back-transforms one column block; all-gather) and the
@@ -153,6 +156,9 @@ int nls_eigh_only(nls_ctx* ctx, void* A, int n, int is_complex, double* lam);
 /* The dual fit's own Cholesky factorisation (csrc/nls_potrf.h; cho_factor(gamma* diag(sn^-2) + K), _neo_ls_svm.py:313-314) on host data (tests,
  * profiling): A (n x n column-major doubles, lower triangle) is overwritten by L; *info = 0 or the 1-based index of the first non-positive pivot. */
 int nls_cholesky_only(nls_ctx* ctx, double* A, int n, int* info);
+/* The primal fit's own complex Cholesky factorisation (csrc/nls_zpotrf.h; cho_factor(gamma* C + A), _neo_ls_svm.py:176-177) on host data (tests,
+ * profiling): A (n x n column-major, interleaved re / im, lower triangle) is overwritten by L; *info as above. */
+int nls_zcholesky_only(nls_ctx* ctx, double* A, int n, int* info);
 int nls_twostage_stage(nls_ctx* ctx, int stage, void* A, int n, int is_complex, int bw, void* aux, double* d, double* e, int ncols,
                        int* info);
 long nls_twostage_fallbacks(const nls_ctx* ctx);

@@ -152,6 +152,7 @@ SIGNATURES = {
     "nls_eigh_only": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "nls_twostage_stage": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "nls_cholesky_only": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "nls_zcholesky_only": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "nls_twostage_fallbacks": (C.c_long, [C.c_void_p]),
     "nls_twostage_rescues": (C.c_long, [C.c_void_p]),
     "nls_evd_stage_ms": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -17,9 +17,20 @@ It is O(n d log n) sort/select work on the CPU - SURVEY.md 8(f) lists it as the 
 from __future__ import annotations
 
 import numpy as np
-from threadpoolctl import threadpool_limits
+from threadpoolctl import ThreadpoolController
 
-__all__ = ["target_bins", "weighted_median_columns", "fit_affine_normalizer", "fit_affine_separator"]
+__all__ = ["target_bins", "weighted_median_columns", "fit_affine_normalizer", "fit_affine_separator", "blas_threads"]
+
+_controller = None
+
+
+def blas_threads(limit: int):
+    """Context manager capping the BLAS threads (threadpoolctl).  The controller is built ONCE: ``threadpool_limits(...)`` re-discovers the
+    process's shared objects on every call - ~70 ms each with the ROCm libraries loaded, more than the whole pre-step of a 1e5-row fit."""
+    global _controller
+    if _controller is None:
+        _controller = ThreadpoolController()
+    return _controller.limit(limits=limit, user_api="blas")
 
 
 # --------------------------------------------------------------------------------------------
@@ -233,7 +244,14 @@ def fit_affine_normalizer(X: np.ndarray, y: np.ndarray, sample_weight: np.ndarra
 # Separator matrix
 # --------------------------------------------------------------------------------------------
 def _sq_dists(P, Q):
-    return np.sum(P * P, axis=1, keepdims=True) - 2 * P @ Q.T + np.sum(Q * Q, axis=1, keepdims=True).T
+    """||p_i - q_j||^2 by the expansion (|p|^2 - 2 p.q) + |q|^2, in the reference's order of operations (``_affine_separator.py:24-29``:
+    the nearest-neighbour argmin over near-ties depends on the rounding) but in ONE buffer: the three n x m temporaries of the plain
+    expression cost more than the product itself at these sizes (384 ... 1536 rows)."""
+    D = P @ Q.T
+    D *= 2.0  # exact
+    np.subtract(np.sum(P * P, axis=1, keepdims=True), D, out=D)
+    D += np.sum(Q * Q, axis=1, keepdims=True).T
+    return D
 
 
 def _nearest_rows(P, Q):
@@ -283,7 +301,7 @@ def fit_affine_separator(
     shift, scale = (normalizer or fit_affine_normalizer)(X, y, sample_weight)
     # The edge-sample products below are a few hundred rows wide: on a 64-thread BLAS they spend their time in thread
     # hand-offs (13 ms per 1536 x 128 x 1536 product against 3 ms on 8 threads).
-    with threadpool_limits(limits=8, user_api="blas"):
+    with blas_threads(8):
         return _separator_directions(X, y, sample_weight, shift, scale, rank_threshold, edge_sample_size, edge_search_multiplier, random_state)
 
 

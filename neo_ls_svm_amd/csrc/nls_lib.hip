@@ -3,6 +3,7 @@
 #include "nls_host.h"
 #include "nls_kernels.h"
 #include "nls_dual_kernels.h"
+#include "nls_zpotrf.h"
 
 using namespace nls;
 
@@ -703,6 +704,107 @@ extern "C" int nls_sweep_weights(const double* gammas, int G, double* nodes, dou
   return NLS_OK;
 }
 
+// A = L L^H in place (lower triangle, column-major interleaved complex, leading dimension lda >= n) on `stream`: nls_zpotrf.h.
+// NLS_POTRF=rocsolver takes rocSOLVER / rocBLAS in block columns of 512 instead (round 3's form; `blas` must be bound to `stream`).
+// event_cols > 0 (a multiple of 256): blk_ev[b] is recorded on `stream` when block column b of that width is final and no longer read.
+// info: device word, 0 or the 1-based index of the first non-positive pivot.
+static int zpotrf_lower(nls_ctx* ctx, hipStream_t stream, rocblas_handle blas, double2* A, int n, long lda, int* dinfo, int event_cols) {
+  using namespace zpotrf;
+  const char* mode = std::getenv("NLS_POTRF");
+  if (mode && std::string(mode) == "rocsolver") {
+    constexpr int NBK = 512;
+    const int nblk = (n + NBK - 1) / NBK;
+    int* binfo = nullptr;
+    NLSCHK(ws_get_t(ctx, "chol.binfo", (size_t)nblk, &binfo));
+    HIPCHK(ctx, hipMemsetAsync(binfo, 0, sizeof(int) * nblk, stream));
+    const rocblas_double_complex z_one(1.0, 0.0);
+    const double h_minus = -1.0, h_one = 1.0;
+    for (int b = 0; b < nblk; ++b) {
+      const int k0 = b * NBK, w = std::min(NBK, n - k0), mrows = n - k0 - w;
+      rocblas_double_complex* A11 = reinterpret_cast<rocblas_double_complex*>(A) + k0 + (long)k0 * lda;
+      BLASCHK(ctx, rocsolver_zpotrf(blas, rocblas_fill_lower, w, A11, (rocblas_int)lda, reinterpret_cast<rocblas_int*>(binfo + b)));
+      if (mrows > 0) {
+        BLASCHK(ctx, rocblas_ztrsm(blas, rocblas_side_right, rocblas_fill_lower, rocblas_operation_conjugate_transpose, rocblas_diagonal_non_unit, mrows, w,
+                                   &z_one, A11, (rocblas_int)lda, A11 + w, (rocblas_int)lda));
+        BLASCHK(ctx, rocblas_zherk(blas, rocblas_fill_lower, rocblas_operation_none, mrows, w, &h_minus, A11 + w, (rocblas_int)lda, &h_one,
+                                   A11 + w + (long)w * lda, (rocblas_int)lda));
+      }
+      if (event_cols > 0) {
+        if (event_cols != NBK) return fail(ctx, NLS_ERR_ARG, "zpotrf_lower(rocsolver): block-column events come in columns of %d", NBK);
+        HIPCHK(ctx, hipEventRecord(ctx->blk_ev[b], stream));
+      }
+    }
+    hipLaunchKernelGGL(k_merge_block_info, dim3(1), dim3(64), 0, stream, binfo, nblk, NBK, dinfo);
+    HIPCHK(ctx, hipGetLastError());
+    return NLS_OK;
+  }
+  const long ldp = round_up(n, BM);
+  double *planes = nullptr, *oplanes = nullptr;
+  double2* L11w = nullptr;
+  NLSCHK(ws_get_t(ctx, "zpotrf.planes", (size_t)3 * NBZ * ldp, &planes));
+  NLSCHK(ws_get_t(ctx, "zpotrf.oplanes", (size_t)3 * NBO * ldp, &oplanes));
+  NLSCHK(ws_get_t(ctx, "zpotrf.L11", (size_t)NBZ * NBZ, &L11w));
+  double *Pr = planes, *Pi = planes + (size_t)NBZ * ldp, *Pn = planes + (size_t)2 * NBZ * ldp;
+  double *Or = oplanes, *Oi = oplanes + (size_t)NBO * ldp, *On = oplanes + (size_t)2 * NBO * ldp;
+  HIPCHK(ctx, hipMemsetAsync(dinfo, 0, sizeof(int), stream));
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_zpotrf_panel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZP_LDS) != hipSuccess ||
+      hipFuncSetAttribute(reinterpret_cast<const void*>(k_zpotrf_herk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_REAL) != hipSuccess)
+    return fail(ctx, NLS_ERR_HIP, "complex Cholesky kernels: %zu / %zu bytes of LDS refused", ZP_LDS, SMEM_REAL);
+  if (event_cols > 0 && event_cols % NBO != 0) return fail(ctx, NLS_ERR_ARG, "zpotrf_lower: block-column events come in multiples of %d columns", NBO);
+  for (int K0 = 0; K0 < n; K0 += NBO) {
+    const int W = std::min(NBO, n - K0), below = n - K0 - W;  // outer block column, rows below it
+    if (below > 0) HIPCHK(ctx, hipMemsetAsync(oplanes, 0, sizeof(double) * (size_t)3 * NBO * ldp, stream));
+    for (int k0 = K0; k0 < K0 + W; k0 += NBZ) {
+      const int w = std::min(NBZ, K0 + W - k0), mrows = n - k0 - w;  // panel, rows below its diagonal block
+      double2* D = A + (long)k0 + (long)k0 * lda;
+      const int m_pad = (int)round_up(mrows, BM);
+      const int pgrid = std::max(1, (m_pad + ZP_ROWS - 1) / ZP_ROWS);
+      const long ko = (long)(k0 - K0) * ldp;  // this panel's 32 k-rows of the outer planes
+      hipLaunchKernelGGL(k_zpotrf_panel, dim3((unsigned)pgrid), dim3(ZP_ROWS), ZP_LDS, stream, D, lda, w, k0, mrows, m_pad, Pr, Pi, Pn, ldp, Or + ko, Oi + ko,
+                         On + ko, K0 + W - (k0 + w), L11w, dinfo);
+      const int icols = K0 + W - (k0 + w);  // columns of the outer block right of the panel: the panel's own (tall) update
+      if (icols > 0) {
+        const int nt = m_pad / BM, nct = std::min(nt, (icols + BM - 1) / BM);
+        const int tiles = nct * (nct + 1) / 2 + (nt - nct) * nct;
+        hipLaunchKernelGGL(k_zpotrf_herk, dim3((unsigned)tiles, 2), dim3(Cfg4::NTHREADS), SMEM_REAL, stream, D + w + (long)w * lda, lda, mrows, icols, nct,
+                           NBZ / BK, Pr, Pi, Pn, ldp, pgrid > 1 ? L11w : (const double2*)nullptr, D, w);
+      } else if (pgrid > 1) {
+        hipLaunchKernelGGL(k_zpotrf_putback, dim3(1), dim3(256), 0, stream, L11w, D, lda, w);
+      }
+      HIPCHK(ctx, hipGetLastError());
+    }
+    if (below > 0) {  // the trailing matrix beyond the outer block column, once, with K = W
+      const int nt = (int)(round_up(below, BM) / BM);
+      hipLaunchKernelGGL(k_zpotrf_herk, dim3((unsigned)(nt * (nt + 1) / 2), 2), dim3(Cfg4::NTHREADS), SMEM_REAL, stream, A + (long)(K0 + W) + (long)(K0 + W) * lda,
+                         lda, below, below, nt, (int)(round_up(W, BK) / BK), Or, Oi, On, ldp, (const double2*)nullptr, (double2*)nullptr, 0);
+      HIPCHK(ctx, hipGetLastError());
+    }
+    if (event_cols > 0 && ((K0 + NBO) % event_cols == 0 || K0 + NBO >= n)) HIPCHK(ctx, hipEventRecord(ctx->blk_ev[K0 / event_cols], stream));
+  }
+  return NLS_OK;
+}
+
+// Hook (tests / profiling): the primal path's own complex Cholesky factorisation on host data.  A: n x n column-major interleaved complex, lower
+// triangle in, L out (the strict upper triangle is returned as it came); *info = 0 or the 1-based index of the first non-positive pivot.
+extern "C" int nls_zcholesky_only(nls_ctx* ctx, double* A, int n, int* info) {
+  if (!ctx) return NLS_ERR_ARG;
+  if (!A || !info || n < 1) return fail(ctx, NLS_ERR_ARG, "nls_zcholesky_only: null pointer or n < 1");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  double2* dA = nullptr;
+  int* dinfo = nullptr;
+  NLSCHK(ws_get_t(ctx, "hook.zchol", (size_t)n * n, &dA));
+  NLSCHK(ws_get_t(ctx, "chol.info2", 4, &dinfo));
+  HIPCHK(ctx, hipMemcpyAsync(dA, A, sizeof(double2) * (size_t)n * n, hipMemcpyHostToDevice, ctx->stream));
+  BLASCHK(ctx, rocblas_set_stream(ctx->blas, ctx->stream));
+  NLSCHK(zpotrf_lower(ctx, ctx->stream, ctx->blas, dA, n, n, dinfo, 0));
+  int hinfo = 0;
+  HIPCHK(ctx, hipMemcpyAsync(A, dA, sizeof(double2) * (size_t)n * n, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(&hinfo, dinfo, sizeof(hinfo), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  *info = hinfo;
+  return NLS_OK;
+}
+
 extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
   if (!ctx) return NLS_ERR_ARG;
   if (!a) return fail(ctx, NLS_ERR_ARG, "args is NULL");
@@ -987,32 +1089,16 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
       hipLaunchKernelGGL(k_add_diag, dim3((unsigned)((D1 + 255) / 256)), dim3(256), 0, s2, Acm, (long)D1, D1, gamma_opt * st.c);
     }
     HIPCHK(ctx, hipGetLastError());
-    // Blocked right-looking factorisation in block columns of 512 (rocSOLVER on the diagonal blocks, rocBLAS ztrsm / zherk): a block column is
-    // final once its trailing update has run, and travels to the host on the copy stream - conjugated there: the column-major lower factor L
+    // Own blocked right-looking factorisation (nls_zpotrf.h: panels of 64, three launches per panel).  A block column of 512 is final once
+    // its last panel's trailing update has run, and travels to the host on the copy stream - conjugated there: the column-major lower factor L
     // (A = L L^H) is, byte for byte, the conjugate of the row-major upper factor U = L^H that scipy's cho_factor(lower=False) returns - while
-    // the following block columns are factored.  (Monolithic rocsolver_zpotrf: 16.5 ms + 12.7 ms of download in sequence at D + 1 = 4097.)
+    // the following block columns are factored.  (Round 3: rocsolver_zpotrf on 512-wide diagonal blocks + rocBLAS ztrsm / zherk, 18 ms at
+    // D + 1 = 4097; a monolithic rocsolver_zpotrf 16.5 ms + 12.7 ms of download in sequence.)
     constexpr int NBK = 512;
     const int nblk = (D1 + NBK - 1) / NBK;
     NLSCHK(ensure_copy_stream(ctx, nblk));
     side_join.s2 = ctx->copy_stream;
-    int* binfo = nullptr;
-    NLSCHK(ws_get_t(ctx, "chol.binfo", (size_t)nblk, &binfo));
-    HIPCHK(ctx, hipMemsetAsync(binfo, 0, sizeof(int) * nblk, s2));
-    const rocblas_double_complex z_one(1.0, 0.0);
-    const double h_minus = -1.0, h_one = 1.0;
-    for (int b = 0; b < nblk; ++b) {
-      const int k0 = b * NBK, w = std::min(NBK, D1 - k0), mrows = D1 - k0 - w;
-      rocblas_double_complex* A11 = reinterpret_cast<rocblas_double_complex*>(Acm) + k0 + (long)k0 * D1;
-      BLASCHK(ctx, rocsolver_zpotrf(ctx->blas2, rocblas_fill_lower, w, A11, D1, reinterpret_cast<rocblas_int*>(binfo + b)));
-      if (mrows > 0) {
-        BLASCHK(ctx, rocblas_ztrsm(ctx->blas2, rocblas_side_right, rocblas_fill_lower, rocblas_operation_conjugate_transpose, rocblas_diagonal_non_unit, mrows, w,
-                                   &z_one, A11, D1, A11 + w, D1));
-        BLASCHK(ctx, rocblas_zherk(ctx->blas2, rocblas_fill_lower, rocblas_operation_none, mrows, w, &h_minus, A11 + w, D1, &h_one, A11 + w + (long)w * D1, D1));
-      }
-      HIPCHK(ctx, hipEventRecord(ctx->blk_ev[b], s2));
-    }
-    hipLaunchKernelGGL(k_merge_block_info, dim3(1), dim3(64), 0, s2, binfo, nblk, NBK, reinterpret_cast<int*>(dinfo2));
-    HIPCHK(ctx, hipGetLastError());
+    NLSCHK(zpotrf_lower(ctx, s2, ctx->blas2, Acm, D1, (long)D1, reinterpret_cast<int*>(dinfo2), NBK));
     HIPCHK(ctx, hipEventRecord(ctx->side_ev[1], s2));
     side_copy = true;
   }
@@ -1077,7 +1163,7 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
     HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));
     rocblas_int info2 = 0;
     HIPCHK(ctx, hipMemcpy(&info2, dinfo2, sizeof(info2), hipMemcpyDeviceToHost));
-    if (info2 != 0) return fail(ctx, NLS_ERR_LINALG, "rocsolver_zpotrf: info = %d (matrix not positive definite / no convergence)", (int)info2);
+    if (info2 != 0) return fail(ctx, NLS_ERR_LINALG, "Cholesky factorisation of gamma* C + A: pivot %d is not positive (matrix not positive definite)", (int)info2);
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, ctx->side_ev[0], ctx->side_ev[1]) == hipSuccess) tm[NLS_T_CHOLESKY] += ms * 1e-3;
     if (hipEventElapsedTime(&ms, ctx->side_ev[1], ctx->side_ev[2]) == hipSuccess) tm[NLS_T_DOWNLOAD] += ms * 1e-3;

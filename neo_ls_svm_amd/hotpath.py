@@ -13,9 +13,9 @@ from __future__ import annotations
 import ctypes as C
 
 import numpy as np
-from threadpoolctl import threadpool_limits
 
 from . import _lib
+from ._prestep import blas_threads
 from ._lib import Context, DeviceArray, DualFitArgs, Factor, PrimalFitArgs, default_context
 
 __all__ = [
@@ -50,13 +50,27 @@ def orf_frequencies(d: int, D: int, random_state=42) -> np.ndarray:
     """
     gen = random_state if isinstance(random_state, np.random.RandomState) else np.random.RandomState(random_state)
     Z = gen.randn(d, D)
-    # A d x d QR on 64+ BLAS threads spends its time in thread hand-offs (0.20 s per 896 x 896 block on the GPU box's
-    # host against 0.03 s on 8 threads; the rounding pattern depends on the thread count either way).
-    with threadpool_limits(limits=8, user_api="blas"):
-        for j in range(0, D, d):
-            block = Z[:, j : j + d]
-            q, _ = np.linalg.qr(block)
-            Z[:, j : j + block.shape[1]] = q[:, : block.shape[1]]
+    starts = list(range(0, D, d))
+
+    def block_q(j):
+        q, _ = np.linalg.qr(Z[:, j : j + d])
+        return q
+
+    # The ceil(D / d) blocks are independent.  A d x d QR on 64+ BLAS threads spends its time in thread hand-offs (0.20 s per 896 x 896 block on
+    # the GPU box's host against 0.03 s on 8 threads), and five of them in a row are 0.16 s of a 2.4 s fit: with single-threaded BLAS the
+    # blocks run side by side on host threads instead (LAPACK releases the GIL).  The rounding pattern of a block does not depend on how many
+    # run at once, only on the BLAS thread count of its own call - fixed at one here when there are several blocks.
+    if len(starts) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+
+        with blas_threads(1), ThreadPoolExecutor(max_workers=min(len(starts), 16)) as pool:
+            qs = list(pool.map(block_q, starts))
+    else:
+        with blas_threads(8):
+            qs = [block_q(0)]
+    for j, q in zip(starts, qs):
+        w = min(d, D - j)
+        Z[:, j : j + w] = q[:, :w]
     Z *= np.sqrt(gen.chisquare(d, size=(1, D)))
     return Z
 
@@ -197,16 +211,19 @@ def eigh(A, ctx: Context | None = None):
 
 
 def cholesky(A, ctx: Context | None = None):
-    """Lower Cholesky factor of a real symmetric positive definite matrix by the dual path's own factorisation (test / profiling hook,
-    ``nls_cholesky_only``); raises ``numpy.linalg.LinAlgError`` with the index of the first non-positive pivot, as ``numpy.linalg.cholesky`` would."""
+    """Lower Cholesky factor of a real symmetric / complex Hermitian positive definite matrix by the library's own factorisations (test /
+    profiling hooks ``nls_cholesky_only``: the dual path's, ``nls_zcholesky_only``: the primal path's); only the lower triangle is read.  Raises
+    ``numpy.linalg.LinAlgError`` with the index of the first non-positive pivot, as ``numpy.linalg.cholesky`` would."""
     ctx = ctx or default_context()
-    A = np.asarray(A, dtype=np.float64)
+    A = np.asarray(A)
+    cplx = np.iscomplexobj(A)
     if A.ndim != 2 or A.shape[0] != A.shape[1] or A.shape[0] < 1:
         raise ValueError("A must be a non-empty square matrix")
     n = A.shape[0]
-    Af = np.asfortranarray(np.tril(A))
+    Af = np.asfortranarray(np.tril(A), dtype=np.complex128 if cplx else np.float64)
     info = C.c_int(0)
-    ctx._check(ctx.lib.nls_cholesky_only(ctx.handle, Af.ctypes.data, n, C.byref(info)))
+    fn = ctx.lib.nls_zcholesky_only if cplx else ctx.lib.nls_cholesky_only
+    ctx._check(fn(ctx.handle, Af.ctypes.data, n, C.byref(info)))
     if info.value != 0:
         raise np.linalg.LinAlgError(f"matrix is not positive definite: pivot {info.value} <= 0")
     return np.tril(Af)

@@ -76,32 +76,51 @@ def test_dual_rejects_zero_weights(hp):
         hp.dual_fit(Xt, y, s, False)
 
 
-@pytest.mark.parametrize("n", [1, 5, 31, 32, 33, 127, 128, 129, 300, 640, 1000, 1537])
-def test_own_cholesky_factorisation_matches_numpy(n, hp):
-    """The dual fit's L_ comes from the library's own Cholesky factorisation (csrc/nls_potrf.h: 128 x 128 leaf in LDS, blocked forward
-    substitution, rank-128 update): against numpy.linalg.cholesky on sizes around the leaf / sub-block / tile edges."""
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("n", [1, 5, 31, 32, 33, 63, 64, 65, 127, 128, 129, 300, 640, 1000, 1025, 1537])
+def test_own_cholesky_factorisation_matches_numpy(n, cplx, hp):
+    """L_ comes from the library's own Cholesky factorisations - real (dual fit, csrc/nls_potrf.h: 128 x 128 leaf in LDS, blocked forward
+    substitution, rank-128 update) and complex (primal fit, csrc/nls_zpotrf.h: 32 x 32 leaf, row-wise forward substitution, rank-32 update through
+    real planes): against numpy.linalg.cholesky on sizes around the leaf / panel / tile edges."""
     rng = np.random.default_rng(n)
-    M = rng.standard_normal((n, n + 3))
-    A = M @ M.T / n + 0.5 * np.eye(n)
+    M = rng.standard_normal((n, n + 3)) + (1j * rng.standard_normal((n, n + 3)) if cplx else 0)
+    A = M @ M.conj().T / n + 0.5 * np.eye(n)
     L = hp.cholesky(A)
     L0 = np.linalg.cholesky(A)
+    assert L.dtype == L0.dtype
     assert np.max(np.abs(L - L0)) <= 1e-12 * np.max(np.abs(L0))
-    assert np.max(np.abs(L @ L.T - A)) <= 1e-13 * n * np.max(np.abs(A))
+    assert np.max(np.abs(L @ L.conj().T - A)) <= 1e-13 * n * np.max(np.abs(A))
+    if cplx:
+        assert np.all(np.diag(L).imag == 0.0) and np.all(np.diag(L).real > 0.0)
 
 
-def test_own_cholesky_reports_the_first_bad_pivot(hp):
+@pytest.mark.parametrize("cplx", [False, True])
+def test_own_cholesky_reports_the_first_bad_pivot(cplx, hp):
     """LAPACK semantics: info = 1-based index of the first non-positive pivot -> LinAlgError."""
     rng = np.random.default_rng(3)
     n = 400
-    M = rng.standard_normal((n, n))
-    A = M @ M.T / n + np.eye(n)
+    M = rng.standard_normal((n, n)) + (1j * rng.standard_normal((n, n)) if cplx else 0)
+    A = M @ M.conj().T / n + np.eye(n)
     v = np.linalg.eigh(A[:251, :251])[1][:, 0]
     B = A.copy()
-    B[:251, :251] -= 1.001 * np.linalg.eigvalsh(A[:251, :251])[0] * np.outer(v, v)  # leading 251 x 251 minor just indefinite, 250 x 250 fine or not: find the index
+    B[:251, :251] -= 1.001 * np.linalg.eigvalsh(A[:251, :251])[0] * np.outer(v, v.conj())  # the leading 251 x 251 minor just indefinite: find the index
     first_bad = next(k for k in range(1, n + 1) if np.linalg.eigvalsh(B[:k, :k])[0] <= 0)
     with pytest.raises(np.linalg.LinAlgError) as err:
         hp.cholesky(B)
     assert f"pivot {first_bad} " in str(err.value)
+
+
+def test_own_complex_cholesky_is_the_one_the_fit_returns(golden_loader, hp, monkeypatch):
+    """The factor L_ of the primal fit against the reference's own (``primal_reg_n3000_d20_D256.L``, scipy ``cho_factor(lower=False)`` layout),
+    through the library's factorisation and - NLS_POTRF=rocsolver - through rocSOLVER / rocBLAS: both to 1e-12."""
+    g = golden_loader("primal_reg_n3000_d20_D256")
+    iu = np.triu_indices(int(g["D"]) + 1)
+    for mode in (None, "rocsolver"):
+        if mode:
+            monkeypatch.setenv("NLS_POTRF", mode)
+        r = hp.primal_fit(g["X"], g["y"], g["s"], g["shift"], g["scale"], g["B"], False, gamma_index=int(g["opt"]))
+        assert relerr(r["L"][iu], g["L"][iu]) < 1e-12, mode
+        assert relerr(r["beta"], g["beta"]) < 1e-9, mode
 
 
 @pytest.mark.parametrize("gi", [0, 127])

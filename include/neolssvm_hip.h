@@ -169,6 +169,10 @@ long nls_twostage_rescues(const nls_ctx* ctx);
  * back-transformation Q1, their sum, n, kind} with kind = 1: one-stage real, 2: one-stage complex, 3: two-stage real, 4: two-stage complex,
  * 5: rocSOLVER heevd / syevd in one call (only the sum is filled), 0: no eigendecomposition has run (returns NLS_ERR_ARG). */
 int nls_evd_stage_ms(nls_ctx* ctx, double* out8);
+/* The tridiagonal eigensolver of both eigendecompositions alone, on host data (tests, profiling): the library's own divide and conquer
+ * (csrc/nls_stedc.h; NLS_STEDC=rocsolver: rocsolver_dstedc).  d[n]: diagonal in, eigenvalues ascending out; e[n - 1]: off-diagonal; Q: n x n
+ * column-major eigenvectors out.  LAPACK's dstedc with compz = 'I' (what scipy / numpy eigh run under _neo_ls_svm.py:120 / :265). */
+int nls_stedc_only(nls_ctx* ctx, double* d, const double* e, int n, double* Q);
 
 /* ---- primal fit ------------------------------------------------------------------------------- */
 typedef struct nls_primal_fit_args {

@@ -18,6 +18,7 @@ from .hotpath import (  # noqa: F401
     primal_fit_sigma_grid,
     primal_predict,
     rotate,
+    stedc,
     tridiagonalize,
     cholesky,
     twostage_stage,
@@ -58,6 +59,7 @@ __all__ = [
     "exact_complexity_matrix",
     "eigh",
     "tridiagonalize",
+    "stedc",
     "cholesky",
     "twostage_stage",
 ]

@@ -156,6 +156,7 @@ SIGNATURES = {
     "nls_twostage_fallbacks": (C.c_long, [C.c_void_p]),
     "nls_twostage_rescues": (C.c_long, [C.c_void_p]),
     "nls_evd_stage_ms": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "nls_stedc_only": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "nls_primal_fit": (C.c_int, [C.c_void_p, C.POINTER(PrimalFitArgs)]),
     "nls_sweep_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
     "nls_primal_predict": (

@@ -7,6 +7,7 @@
 #include "nls_sb.h"
 #include "nls_chase.h"
 #include "nls_q2.h"
+#include "nls_stedc.h"
 
 namespace nls {
 
@@ -552,30 +553,127 @@ static int evd_unscale(nls_ctx* ctx, double* lam, int n, double factor) {
   return NLS_OK;
 }
 
+// The library's own divide and conquer (nls_stedc.h): d (n: diagonal in, eigenvalues ascending out), e (n - 1: off-diagonal, read only),
+// C (n x n column-major, leading dimension n: eigenvectors out).  A fixed launch sequence, no host synchronisation.  dinfo: raised (leaf index + 1)
+// when a leaf's QL iteration does not converge.
+static int stedc_dc(nls_ctx* ctx, int n, double* d, const double* e, double* C, rocblas_int* dinfo) {
+  using namespace dc;
+  hipStream_t st = ctx->stream;
+  HIPCHK(ctx, hipMemsetAsync(dinfo, 0, sizeof(rocblas_int), st));
+  if (n == 1) {
+    const double one = 1.0;
+    HIPCHK(ctx, hipMemcpyAsync(C, &one, sizeof(double), hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    return NLS_OK;
+  }
+  int nlev = 0;
+  size_t slot = 0;
+  for (long S = LEAF; S < n; S *= 2) {
+    ++nlev;
+    const long nm = (n + 2 * S - 1) / (2 * S), P = round_up(std::min<long>(2 * S, n), BM);
+    slot = std::max(slot, (size_t)(nm * P * P));
+  }
+  const int nm_max = (n + 2 * LEAF - 1) / (2 * LEAF);
+  double *lam2 = nullptr, *Q2 = nullptr, *ds = nullptr, *zs = nullptr, *dl = nullptr, *w = nullptr, *dorg = nullptr, *mu = nullptr, *lamnew = nullptr, *zhat = nullptr;
+  double *U = nullptr, *G = nullptr, *R = nullptr;
+  int *src = nullptr, *kidx = nullptr, *didx = nullptr, *pos = nullptr;
+  Rot* rots = nullptr;
+  MergeInfo* info = nullptr;
+  NLSCHK(ws_get_t(ctx, "dc.lam2", (size_t)n, &lam2));
+  NLSCHK(ws_get_t(ctx, "dc.ds", (size_t)n, &ds));
+  NLSCHK(ws_get_t(ctx, "dc.zs", (size_t)n, &zs));
+  NLSCHK(ws_get_t(ctx, "dc.dl", (size_t)n, &dl));
+  NLSCHK(ws_get_t(ctx, "dc.w", (size_t)n, &w));
+  NLSCHK(ws_get_t(ctx, "dc.dorg", (size_t)n, &dorg));
+  NLSCHK(ws_get_t(ctx, "dc.mu", (size_t)n, &mu));
+  NLSCHK(ws_get_t(ctx, "dc.lamnew", (size_t)n, &lamnew));
+  NLSCHK(ws_get_t(ctx, "dc.zhat", (size_t)n, &zhat));
+  NLSCHK(ws_get_t(ctx, "dc.src", (size_t)n, &src));
+  NLSCHK(ws_get_t(ctx, "dc.kidx", (size_t)n, &kidx));
+  NLSCHK(ws_get_t(ctx, "dc.didx", (size_t)n, &didx));
+  NLSCHK(ws_get_t(ctx, "dc.pos", (size_t)n, &pos));
+  NLSCHK(ws_get_t(ctx, "dc.rots", (size_t)n, &rots));
+  NLSCHK(ws_get_t(ctx, "dc.info", (size_t)nm_max, &info));
+  if (nlev > 0) {
+    NLSCHK(ws_get_t(ctx, "dc.Q2", (size_t)n * n, &Q2));
+    NLSCHK(ws_get_t(ctx, "dc.U", slot, &U));
+    NLSCHK(ws_get_t(ctx, "dc.G", slot, &G));
+    NLSCHK(ws_get_t(ctx, "dc.R", slot, &R));
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_dc_gemm), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * 2 * TILE_DOUBLES * sizeof(double))) != hipSuccess)
+      return fail(ctx, NLS_ERR_HIP, "k_dc_gemm: dynamic LDS refused");
+  }
+  // Ping-pong between C and Q2 so that the last level writes C.  Both start as zero: a level reads the whole square of a merge, whose
+  // off-diagonal blocks nobody has written.
+  double* Qbuf[2] = {(nlev % 2 == 0) ? C : Q2, (nlev % 2 == 0) ? Q2 : C};
+  double* Lbuf[2] = {(nlev % 2 == 0) ? d : lam2, (nlev % 2 == 0) ? lam2 : d};
+  HIPCHK(ctx, hipMemsetAsync(C, 0, sizeof(double) * (size_t)n * n, st));
+  if (nlev > 0) HIPCHK(ctx, hipMemsetAsync(Q2, 0, sizeof(double) * (size_t)n * n, st));
+  // (the leaves read d: when the eigenvalues start in d itself, read a copy)
+  double* dsrc = d;
+  if (Lbuf[0] == d) {
+    HIPCHK(ctx, hipMemcpyAsync(lam2, d, sizeof(double) * n, hipMemcpyDeviceToDevice, st));
+    dsrc = lam2;
+  }
+  hipLaunchKernelGGL(k_dc_leaf, dim3((unsigned)((n + LEAF - 1) / LEAF)), dim3(64), 0, st, n, dsrc, e, Lbuf[0], Qbuf[0], (long)n, reinterpret_cast<int*>(dinfo));
+  HIPCHK(ctx, hipGetLastError());
+  int cur = 0;
+  for (long S = LEAF; S < n; S *= 2) {
+    Level L{n, (int)S, (long)round_up(std::min<long>(2 * S, n), BM)};
+    const unsigned nm = (unsigned)((n + 2 * S - 1) / (2 * S));
+    const unsigned mmax = (unsigned)std::min<long>(2 * S, n);
+    const double* Qc = Qbuf[cur];
+    double* Qn = Qbuf[cur ^ 1];
+    hipLaunchKernelGGL(k_dc_setup, dim3(nm), dim3(256), 0, st, L, Lbuf[cur], Qc, (long)n, e, ds, zs, src, dl, w, kidx, didx, rots, info);
+    hipLaunchKernelGGL(k_dc_rotate, dim3((mmax + 255) / 256, nm), dim3(256), 0, st, L, Qbuf[cur], (long)n, rots, info);
+    hipLaunchKernelGGL(k_dc_gather, dim3((unsigned)((L.P + 255) / 256), (mmax + 15) / 16, nm), dim3(256), 0, st, L, Qc, (long)n, src, kidx, info, G);
+    hipLaunchKernelGGL(k_dc_secular, dim3((mmax + 4 * RW - 1) / (4 * RW), nm), dim3(256), 0, st, L, dl, w, info, dorg, mu, lamnew);
+    hipLaunchKernelGGL(k_dc_zhat, dim3((mmax + 3) / 4, nm), dim3(256), 0, st, L, dl, w, dorg, mu, info, zhat);
+    hipLaunchKernelGGL(k_dc_vectors, dim3(mmax, nm), dim3(256), 0, st, L, dl, zhat, dorg, mu, info, U);
+    hipLaunchKernelGGL(k_dc_gemm, dim3((unsigned)(L.P / BN), (unsigned)(L.P / BM), nm), dim3(Cfg4::NTHREADS), 2 * 2 * TILE_DOUBLES * sizeof(double), st, L, U, G, R, info);
+    hipLaunchKernelGGL(k_dc_place, dim3((mmax + 255) / 256, nm), dim3(256), 0, st, L, lamnew, ds, didx, info, pos, Lbuf[cur ^ 1]);
+    hipLaunchKernelGGL(k_dc_scatter, dim3((mmax + 255) / 256, (mmax + 7) / 8, nm), dim3(256), 0, st, L, R, Qc, Qn, (long)n, src, didx, pos, info);
+    HIPCHK(ctx, hipGetLastError());
+    cur ^= 1;
+  }
+  return NLS_OK;
+}
+
+static bool stedc_use_rocsolver() {  // NLS_STEDC=rocsolver: rocsolver_dstedc instead of the library's own divide and conquer (diagnostic)
+  const char* m = std::getenv("NLS_STEDC");
+  return m && std::string(m) == "rocsolver";
+}
+static int stedc_any(nls_ctx* ctx, int n, double* lam, double* e_work, double* Cr, rocblas_int* dinfo) {
+  if (stedc_use_rocsolver()) {
+    BLASCHK(ctx, rocsolver_dstedc(ctx->blas, rocblas_evect_tridiagonal, n, lam, e_work, Cr, n, dinfo));
+    return NLS_OK;
+  }
+  return stedc_dc(ctx, n, lam, e_work, Cr, dinfo);
+}
+
 // stedc on the (real) tridiagonal matrix.  collective: rank 0 computes, everybody receives (lam, Cr) - the ranks then pair the same
 // eigenvalues with the same basis whatever stedc does on clustered spectra.  A failure on rank 0 (API error or info != 0) travels to all
 // ranks through the broadcast flag instead of leaving them blocked in the collective.
 static int stedc_real(nls_ctx* ctx, int n, double* lam, double* e_work, double* Cr, rocblas_int* dinfo, bool collective) {
   if (!(collective && multi_rank(ctx))) {
-    BLASCHK(ctx, rocsolver_dstedc(ctx->blas, rocblas_evect_tridiagonal, n, lam, e_work, Cr, n, dinfo));
-    return check_info(ctx, dinfo, "rocsolver_dstedc");
+    NLSCHK(stedc_any(ctx, n, lam, e_work, Cr, dinfo));
+    return check_info(ctx, dinfo, "tridiagonal eigensolver (stedc)");
   }
   double* flag = nullptr;
   NLSCHK(ws_get_t(ctx, "evd.flag", 2, &flag));
   double hflag = 0.0;
   if (ctx->rank == 0) {
-    const rocblas_status st = rocsolver_dstedc(ctx->blas, rocblas_evect_tridiagonal, n, lam, e_work, Cr, n, dinfo);
+    const int st = stedc_any(ctx, n, lam, e_work, Cr, dinfo);
     rocblas_int info = 0;
     const hipError_t h1 = hipMemcpyAsync(&info, dinfo, sizeof(info), hipMemcpyDeviceToHost, ctx->stream);
     const hipError_t h2 = hipStreamSynchronize(ctx->stream);
-    hflag = st != rocblas_status_success ? -1.0 : ((h1 != hipSuccess || h2 != hipSuccess) ? -2.0 : (double)info);
+    hflag = st != NLS_OK ? -1.0 : ((h1 != hipSuccess || h2 != hipSuccess) ? -2.0 : (double)info);
   }
   HIPCHK(ctx, hipMemcpyAsync(flag, &hflag, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   NLSCHK(do_broadcast(ctx, flag, 1, 0));
   HIPCHK(ctx, hipMemcpyAsync(&hflag, flag, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   if (hflag != 0.0)
-    return fail(ctx, NLS_ERR_LINALG, "rocsolver_dstedc on rank 0: %s (code %d)", hflag > 0 ? "no convergence" : "API failure", (int)hflag);
+    return fail(ctx, NLS_ERR_LINALG, "tridiagonal eigensolver (stedc) on rank 0: %s (code %d)", hflag > 0 ? "no convergence" : "API failure", (int)hflag);
   NLSCHK(do_broadcast(ctx, lam, (size_t)n, 0));
   NLSCHK(do_broadcast(ctx, Cr, (size_t)n * n, 0));
   return NLS_OK;
@@ -811,8 +909,8 @@ static int evd_symmetric_core(nls_ctx* ctx, double* A, int n, double* lam, doubl
   NLSCHK(trd_fused<double>(ctx, A, n, n, lam, e_work, tau));
   evd_mark(ctx, 1);
   evd_mark(ctx, 2);
-  BLASCHK(ctx, rocsolver_dstedc(ctx->blas, rocblas_evect_tridiagonal, n, lam, e_work, C, n, dinfo));
-  NLSCHK(check_info(ctx, dinfo, "rocsolver_dstedc"));
+  NLSCHK(stedc_any(ctx, n, lam, e_work, C, dinfo));
+  NLSCHK(check_info(ctx, dinfo, "tridiagonal eigensolver (stedc)"));
   evd_mark(ctx, 3);
   evd_mark(ctx, 4);
   if (evd_rocsolver_backtransform())
@@ -896,6 +994,30 @@ extern "C" int nls_eigh_only(nls_ctx* ctx, void* A, int n, int is_complex, doubl
   }
   HIPCHK(ctx, hipMemcpyAsync(A, Q, esz * (size_t)n * n, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipMemcpyAsync(lam, dlam, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return NLS_OK;
+}
+
+// Hook (tests / profiling): the tridiagonal eigensolver alone on host data.  d[n] in: diagonal, out: eigenvalues ascending; e[n - 1]; Q: n x n
+// column-major eigenvectors out.
+extern "C" int nls_stedc_only(nls_ctx* ctx, double* d, const double* e, int n, double* Q) {
+  if (!ctx) return NLS_ERR_ARG;
+  if (!d || !Q || n < 1 || (n > 1 && !e)) return fail(ctx, NLS_ERR_ARG, "nls_stedc_only: null pointer or n < 1");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  double *dd = nullptr, *de = nullptr, *dQ = nullptr;
+  rocblas_int* dinfo = nullptr;
+  NLSCHK(ws_get_t(ctx, "hook.d", (size_t)n, &dd));
+  NLSCHK(ws_get_t(ctx, "hook.e", (size_t)n, &de));
+  NLSCHK(ws_get_t(ctx, "hook.A", (size_t)n * n, &dQ));
+  NLSCHK(ws_get_t(ctx, "evd.info", 4, &dinfo));
+  HIPCHK(ctx, hipMemcpyAsync(dd, d, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(de, 0, sizeof(double) * n, ctx->stream));
+  if (n > 1) HIPCHK(ctx, hipMemcpyAsync(de, e, sizeof(double) * (n - 1), hipMemcpyHostToDevice, ctx->stream));
+  BLASCHK(ctx, rocblas_set_stream(ctx->blas, ctx->stream));
+  NLSCHK(stedc_any(ctx, n, dd, de, dQ, dinfo));
+  NLSCHK(check_info(ctx, dinfo, "tridiagonal eigensolver (stedc)"));
+  HIPCHK(ctx, hipMemcpyAsync(d, dd, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(Q, dQ, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return NLS_OK;
 }

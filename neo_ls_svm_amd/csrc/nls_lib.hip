@@ -708,8 +708,12 @@ extern "C" int nls_sweep_weights(const double* gammas, int G, double* nodes, dou
 // NLS_POTRF=rocsolver takes rocSOLVER / rocBLAS in block columns of 512 instead (round 3's form; `blas` must be bound to `stream`).
 // event_cols > 0 (a multiple of 256): blk_ev[b] is recorded on `stream` when block column b of that width is final and no longer read.
 // info: device word, 0 or the 1-based index of the first non-positive pivot.
-static int zpotrf_lower(nls_ctx* ctx, hipStream_t stream, rocblas_handle blas, double2* A, int n, long lda, int* dinfo, int event_cols) {
+// rhs / ysol (device, n complex numbers each; or NULL): the forward substitution L y = rhs is carried along (k_zpotrf_panel) - the first half of
+// beta = cho_solve(L, rhs); zpotrf_solve_conj_tail below is the second.  Not available with NLS_POTRF=rocsolver (returns *ysol_valid = false).
+static int zpotrf_lower(nls_ctx* ctx, hipStream_t stream, rocblas_handle blas, double2* A, int n, long lda, int* dinfo, int event_cols,
+                        const double2* rhs = nullptr, double2* ysol = nullptr, bool* ysol_valid = nullptr) {
   using namespace zpotrf;
+  if (ysol_valid) *ysol_valid = false;
   const char* mode = std::getenv("NLS_POTRF");
   if (mode && std::string(mode) == "rocsolver") {
     constexpr int NBK = 512;
@@ -741,46 +745,70 @@ static int zpotrf_lower(nls_ctx* ctx, hipStream_t stream, rocblas_handle blas, d
   const long ldp = round_up(n, BM);
   double *planes = nullptr, *oplanes = nullptr;
   double2* L11w = nullptr;
-  NLSCHK(ws_get_t(ctx, "zpotrf.planes", (size_t)3 * NBZ * ldp, &planes));
-  NLSCHK(ws_get_t(ctx, "zpotrf.oplanes", (size_t)3 * NBO * ldp, &oplanes));
+  const size_t ssz = (size_t)2 * NBZ * ldp, osz = (size_t)2 * NBO * ldp;  // one stacked pair of planes: inner (32 columns), outer (256)
+  NLSCHK(ws_get_t(ctx, "zpotrf.planes", 3 * ssz, &planes));
+  NLSCHK(ws_get_t(ctx, "zpotrf.oplanes", 3 * osz, &oplanes));
   NLSCHK(ws_get_t(ctx, "zpotrf.L11", (size_t)NBZ * NBZ, &L11w));
-  double *Pr = planes, *Pi = planes + (size_t)NBZ * ldp, *Pn = planes + (size_t)2 * NBZ * ldp;
-  double *Or = oplanes, *Oi = oplanes + (size_t)NBO * ldp, *On = oplanes + (size_t)2 * NBO * ldp;
+  double *S1 = planes, *S2 = planes + ssz, *S3 = planes + 2 * ssz;
+  double *O1 = oplanes, *O2 = oplanes + osz, *O3 = oplanes + 2 * osz;
   HIPCHK(ctx, hipMemsetAsync(dinfo, 0, sizeof(int), stream));
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_zpotrf_panel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZP_LDS) != hipSuccess ||
       hipFuncSetAttribute(reinterpret_cast<const void*>(k_zpotrf_herk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_REAL) != hipSuccess)
     return fail(ctx, NLS_ERR_HIP, "complex Cholesky kernels: %zu / %zu bytes of LDS refused", ZP_LDS, SMEM_REAL);
   if (event_cols > 0 && event_cols % NBO != 0) return fail(ctx, NLS_ERR_ARG, "zpotrf_lower: block-column events come in multiples of %d columns", NBO);
+  const bool carry = rhs != nullptr && ysol != nullptr;
+  double2* rhs_run = nullptr;  // the running right-hand side of the carried forward substitution
+  if (carry) {
+    NLSCHK(ws_get_t(ctx, "zpotrf.rhs", (size_t)n, &rhs_run));
+    HIPCHK(ctx, hipMemcpyAsync(rhs_run, rhs, sizeof(double2) * n, hipMemcpyDeviceToDevice, stream));
+  }
   for (int K0 = 0; K0 < n; K0 += NBO) {
     const int W = std::min(NBO, n - K0), below = n - K0 - W;  // outer block column, rows below it
-    if (below > 0) HIPCHK(ctx, hipMemsetAsync(oplanes, 0, sizeof(double) * (size_t)3 * NBO * ldp, stream));
+    if (below > 0) HIPCHK(ctx, hipMemsetAsync(oplanes, 0, sizeof(double) * 3 * osz, stream));
     for (int k0 = K0; k0 < K0 + W; k0 += NBZ) {
       const int w = std::min(NBZ, K0 + W - k0), mrows = n - k0 - w;  // panel, rows below its diagonal block
       double2* D = A + (long)k0 + (long)k0 * lda;
       const int m_pad = (int)round_up(mrows, BM);
       const int pgrid = std::max(1, (m_pad + ZP_ROWS - 1) / ZP_ROWS);
-      const long ko = (long)(k0 - K0) * ldp;  // this panel's 32 k-rows of the outer planes
-      hipLaunchKernelGGL(k_zpotrf_panel, dim3((unsigned)pgrid), dim3(ZP_ROWS), ZP_LDS, stream, D, lda, w, k0, mrows, m_pad, Pr, Pi, Pn, ldp, Or + ko, Oi + ko,
-                         On + ko, K0 + W - (k0 + w), L11w, dinfo);
+      const long ko = (long)(k0 - K0) * ldp;  // this panel's 32 k-rows inside the halves of the outer stacks
+      hipLaunchKernelGGL(k_zpotrf_panel, dim3((unsigned)pgrid), dim3(ZP_ROWS), ZP_LDS, stream, D, lda, w, k0, mrows, m_pad, S1, S2, S3, ldp, O1 + ko, O2 + ko,
+                         O3 + ko, (long)NBO, K0 + W - (k0 + w), L11w, rhs_run, ysol, dinfo);
       const int icols = K0 + W - (k0 + w);  // columns of the outer block right of the panel: the panel's own (tall) update
       if (icols > 0) {
         const int nt = m_pad / BM, nct = std::min(nt, (icols + BM - 1) / BM);
         const int tiles = nct * (nct + 1) / 2 + (nt - nct) * nct;
         hipLaunchKernelGGL(k_zpotrf_herk, dim3((unsigned)tiles, 2), dim3(Cfg4::NTHREADS), SMEM_REAL, stream, D + w + (long)w * lda, lda, mrows, icols, nct,
-                           NBZ / BK, Pr, Pi, Pn, ldp, pgrid > 1 ? L11w : (const double2*)nullptr, D, w);
+                           2 * NBZ / BK, S1, S2, S3, ldp, pgrid > 1 ? L11w : (const double2*)nullptr, D, w);
       } else if (pgrid > 1) {
         hipLaunchKernelGGL(k_zpotrf_putback, dim3(1), dim3(256), 0, stream, L11w, D, lda, w);
       }
       HIPCHK(ctx, hipGetLastError());
     }
-    if (below > 0) {  // the trailing matrix beyond the outer block column, once, with K = W
+    if (below > 0) {  // the trailing matrix beyond the outer block column, once, with K = 2 x 256 (stacked planes)
       const int nt = (int)(round_up(below, BM) / BM);
       hipLaunchKernelGGL(k_zpotrf_herk, dim3((unsigned)(nt * (nt + 1) / 2), 2), dim3(Cfg4::NTHREADS), SMEM_REAL, stream, A + (long)(K0 + W) + (long)(K0 + W) * lda,
-                         lda, below, below, nt, (int)(round_up(W, BK) / BK), Or, Oi, On, ldp, (const double2*)nullptr, (double2*)nullptr, 0);
+                         lda, below, below, nt, 2 * NBO / BK, O1, O2, O3, ldp, (const double2*)nullptr, (double2*)nullptr, 0);
       HIPCHK(ctx, hipGetLastError());
     }
     if (event_cols > 0 && ((K0 + NBO) % event_cols == 0 || K0 + NBO >= n)) HIPCHK(ctx, hipEventRecord(ctx->blk_ev[K0 / event_cols], stream));
   }
+  if (ysol_valid) *ysol_valid = carry;
+  return NLS_OK;
+}
+
+// Second half of beta = cho_solve(L, b): L^H beta = y in place in `y`, where `Lc` holds conj(L) (the factor after the download's conjugation).
+static int zpotrf_solve_conj_tail(nls_ctx* ctx, hipStream_t stream, const double2* Lc, int n, long lda, double2* y) {
+  using namespace zpotrf;
+  double2* sums = nullptr;
+  NLSCHK(ws_get_t(ctx, "zpotrf.sums", (size_t)NBO, &sums));
+  const int nblk = (n + NBO - 1) / NBO;
+  for (int b = nblk - 1; b >= 0; --b) {
+    const int K0 = b * NBO, W = std::min(NBO, n - K0);
+    const bool tail = K0 + W < n;
+    if (tail) hipLaunchKernelGGL(k_ztrsv_outer_sum, dim3((unsigned)W), dim3(256), 0, stream, Lc, lda, n, K0, W, y, sums);
+    hipLaunchKernelGGL(k_ztrsv_block, dim3(1), dim3(256), 0, stream, Lc, lda, K0, W, y, tail ? sums : (const double2*)nullptr);
+  }
+  HIPCHK(ctx, hipGetLastError());
   return NLS_OK;
 }
 
@@ -1068,7 +1096,8 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
       if (s2) (void)hipStreamSynchronize(s2);
     }
   } side_join;
-  bool side_copy = false;
+  bool side_copy = false, y_carried = false;
+  double2* ysolve = nullptr;  // beta = cho_solve(L_, b): L y = b is carried through the factorisation, L^H beta = y follows the download
   if (a->L) {
     if (!ctx->stream2) {
       HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
@@ -1098,7 +1127,8 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
     const int nblk = (D1 + NBK - 1) / NBK;
     NLSCHK(ensure_copy_stream(ctx, nblk));
     side_join.s2 = ctx->copy_stream;
-    NLSCHK(zpotrf_lower(ctx, s2, ctx->blas2, Acm, D1, (long)D1, reinterpret_cast<int*>(dinfo2), NBK));
+    NLSCHK(ws_get_t(ctx, "chol.solve", (size_t)D1, &ysolve));
+    NLSCHK(zpotrf_lower(ctx, s2, ctx->blas2, Acm, D1, (long)D1, reinterpret_cast<int*>(dinfo2), NBK, db, ysolve, &y_carried));
     HIPCHK(ctx, hipEventRecord(ctx->side_ev[1], s2));
     side_copy = true;
   }
@@ -1137,18 +1167,21 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
     // beta = cho_solve(L_, b) (_neo_ls_svm.py:178).  The copy stream has conjugated the factor in place on its way out (Acm now holds
     // Lc = conj(L), i.e. scipy's upper factor read column-major), so: L x = b <=> Lc conj(x) = conj(b);  L^H beta = x <=> Lc^T beta = x.
     hipStream_t s2 = ctx->stream2;
-    double2* tmp = nullptr;
-    NLSCHK(ws_get_t(ctx, "chol.solve", (size_t)D1, &tmp));
+    double2* tmp = ysolve;
     HIPCHK(ctx, hipStreamWaitEvent(s2, ctx->side_ev[2], 0));
-    const auto* zL = reinterpret_cast<const rocblas_double_complex*>(Acm);
-    hipLaunchKernelGGL(k_conj_vec, dim3((unsigned)((D1 + 255) / 256)), dim3(256), 0, s2, db, D1, tmp);
-    HIPCHK(ctx, hipGetLastError());
-    BLASCHK(ctx, rocblas_ztrsv(ctx->blas2, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, D1, zL, D1,
-                               reinterpret_cast<rocblas_double_complex*>(tmp), 1));
-    hipLaunchKernelGGL(k_conj_vec, dim3((unsigned)((D1 + 255) / 256)), dim3(256), 0, s2, tmp, D1, tmp);
-    HIPCHK(ctx, hipGetLastError());
-    BLASCHK(ctx, rocblas_ztrsv(ctx->blas2, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, D1, zL, D1,
-                               reinterpret_cast<rocblas_double_complex*>(tmp), 1));
+    if (y_carried) {  // y = L^-1 b came out of the factorisation: L^H beta = y against the conjugated factor
+      NLSCHK(zpotrf_solve_conj_tail(ctx, s2, Acm, D1, (long)D1, tmp));
+    } else {  // (NLS_POTRF=rocsolver)
+      const auto* zL = reinterpret_cast<const rocblas_double_complex*>(Acm);
+      hipLaunchKernelGGL(k_conj_vec, dim3((unsigned)((D1 + 255) / 256)), dim3(256), 0, s2, db, D1, tmp);
+      HIPCHK(ctx, hipGetLastError());
+      BLASCHK(ctx, rocblas_ztrsv(ctx->blas2, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, D1, zL, D1,
+                                 reinterpret_cast<rocblas_double_complex*>(tmp), 1));
+      hipLaunchKernelGGL(k_conj_vec, dim3((unsigned)((D1 + 255) / 256)), dim3(256), 0, s2, tmp, D1, tmp);
+      HIPCHK(ctx, hipGetLastError());
+      BLASCHK(ctx, rocblas_ztrsv(ctx->blas2, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, D1, zL, D1,
+                                 reinterpret_cast<rocblas_double_complex*>(tmp), 1));
+    }
     HIPCHK(ctx, hipEventRecord(ctx->side_ev[3], s2));
     HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_ev[3], 0));
     HIPCHK(ctx, hipMemcpyAsync(dbeta, tmp, sizeof(double2) * D1, hipMemcpyDeviceToDevice, ctx->stream));

@@ -27,73 +27,106 @@ constexpr int NBO = 256;  // outer block column: the trailing matrix beyond it i
 // 32 x 32 diagonal block itself, in LDS - redundantly: a few microseconds of work against a kernel boundary (the panel is a chain of dependent
 // launches, and a launch costs more than the block) - then solves its rows: L21 = A21 L11^-H by forward substitution along the row,
 // x[c] = (a[c] - sum_{t < c} x[t] conj(L[c][t])) / L[c][c], one row per thread, the row in LDS ([t][thread]: conflict-free), the factor's
-// entries the same for every lane (broadcast reads).  Plain loops, a dozen registers (a register-resident form with v_readlane broadcasts
-// - the real leaf's design - spills ~1400 scalar registers here: every lane predicate r == k, c <= r is a 64-bit mask).
+// entries the same for every lane (broadcast reads).  The block is factored by WAVE 0 alone (lane = (row, column parity); LDS operations of one
+// wave complete in order, so its 32 steps need no workgroup barrier) while all waves' row loads are in flight.  Plain loops, a dozen registers
+// (a register-resident form with v_readlane broadcasts - the real leaf's design - spills ~1400 scalar registers here: every lane predicate
+// r == k, c <= r is a 64-bit mask).
 // Workgroup 0 hands L11 over (strict upper part untouched; see L11out below) and raises info (0 or the global 1-based index of the first bad pivot).
-// Out besides L21 (in place): Pr, Pi, Pn: [NBZ][ldp] planes (Re, Im, -Im of L21, row index fastest), zero for k >= w and for rows m .. m_pad - 1.
+// With `rhs_run` the right-hand side of beta = cho_solve(L, b) is carried along (the forward substitution of _neo_ls_svm.py:178 without a
+// separate pass over L, and without reading finished columns of L, which the download may already be conjugating): rhs_run holds the running
+// right-hand side b - L[:, :k0] y[:k0]; wave 0 of every workgroup solves the panel's 32 unknowns y[k0 .. k0 + w) against the diagonal block
+// (workgroup 0 stores them in ysol), and every row thread takes its row's share L21[r, :] y off rhs_run[r].
+// Out besides L21 (in place): the planes of L21 as the update kernel reads them, [k][row] with the row index fastest, zero for k >= w and for rows
+// m .. m_pad - 1, stacked in pairs along k (each half padded to NBZ rows): S1 = [Re; Im], S2 = [Re; -Im], S3 = [Im; Re]; and the same entries in
+// the outer block column's stacks O1 .. O3 (halves of ohalf rows; rows below the outer block only, index r - orow0; zeroed by the caller).
 constexpr int ZP_ROWS = 256;
 constexpr size_t ZP_LDS = (size_t)2 * NBZ * (NBZ + 1) * sizeof(double) + (size_t)NBZ * ZP_ROWS * sizeof(double2) + NBZ * sizeof(double);
-__global__ void __launch_bounds__(ZP_ROWS) k_zpotrf_panel(double2* __restrict__ A, long lda, int w, int k0, int m, int m_pad, double* __restrict__ Pr,
-                                                          double* __restrict__ Pi, double* __restrict__ Pn, long ldp, double* __restrict__ Or,
-                                                          double* __restrict__ Oi, double* __restrict__ On, int orow0, double2* __restrict__ L11out,
-                                                          int* info) {
+__global__ void __launch_bounds__(ZP_ROWS) k_zpotrf_panel(double2* __restrict__ A, long lda, int w, int k0, int m, int m_pad, double* __restrict__ S1,
+                                                          double* __restrict__ S2, double* __restrict__ S3, long ldp, double* __restrict__ O1,
+                                                          double* __restrict__ O2, double* __restrict__ O3, long ohalf, int orow0,
+                                                          double2* __restrict__ L11out, double2* __restrict__ rhs_run, double2* __restrict__ ysol, int* info) {
   extern __shared__ __attribute__((aligned(16))) unsigned char zp_smem[];
   double(*Lr)[NBZ + 1] = reinterpret_cast<double(*)[NBZ + 1]>(zp_smem);
   double(*Li)[NBZ + 1] = reinterpret_cast<double(*)[NBZ + 1]>(zp_smem + (size_t)NBZ * (NBZ + 1) * sizeof(double));
   double2(*xs)[ZP_ROWS] = reinterpret_cast<double2(*)[ZP_ROWS]>(zp_smem + (size_t)2 * NBZ * (NBZ + 1) * sizeof(double));
   double* dv = reinterpret_cast<double*>(zp_smem + (size_t)2 * NBZ * (NBZ + 1) * sizeof(double) + (size_t)NBZ * ZP_ROWS * sizeof(double2));
+  __shared__ double2 ysh[NBZ];
   const int tid = threadIdx.x;
+  const long r = (long)blockIdx.x * ZP_ROWS + tid;
+  const bool live = r < m;
+  double2* A21 = A + w;
+  // ---- this thread's row of the panel: loads in flight while the block is factored ----
+  for (int c = 0; c < NBZ; ++c) xs[c][tid] = (live && c < w) ? A21[r + (long)c * lda] : make_double2(0.0, 0.0);
   // ---- the diagonal block (rows / columns k0 .. k0 + w of A), identity-padded to 32 x 32 ----
   for (int idx = tid; idx < NBZ * NBZ; idx += ZP_ROWS) {
-    const int r = idx % NBZ, c = idx / NBZ;
-    double2 v = make_double2(r == c ? 1.0 : 0.0, 0.0);
-    if (r < w && c < w && r >= c) v = A[r + (long)c * lda];
-    Lr[r][c] = v.x;
-    Li[r][c] = r == c ? 0.0 : v.y;  // the diagonal of a Hermitian matrix is real (LAPACK ignores its imaginary part too)
+    const int rr = idx % NBZ, c = idx / NBZ;
+    double2 v = make_double2(rr == c ? 1.0 : 0.0, 0.0);
+    if (rr < w && c < w && rr >= c) v = A[rr + (long)c * lda];
+    Lr[rr][c] = v.x;
+    Li[rr][c] = rr == c ? 0.0 : v.y;  // the diagonal of a Hermitian matrix is real (LAPACK ignores its imaginary part too)
   }
   __syncthreads();
   int bad = 0;
-  for (int k = 0; k < NBZ; ++k) {
-    double d = Lr[k][k];
-    if (!(d > 0.0) || !isfinite(d)) {  // uniform
-      if (bad == 0) bad = k + 1;
-      d = 1.0;
-    }
-    const double sq = sqrt(d), inv = 1.0 / sq;
-    __syncthreads();  // everybody has read the pivot
-    if (tid < NBZ && tid >= k) {
-      Lr[tid][k] = tid == k ? sq : Lr[tid][k] * inv;
-      Li[tid][k] = tid == k ? 0.0 : Li[tid][k] * inv;
-    }
-    if (tid == 0) dv[k] = inv;
-    __syncthreads();
-    for (int idx = tid; idx < NBZ * NBZ; idx += ZP_ROWS) {  // a[r][c] -= l[r] conj(l[c]), r >= c > k
-      const int r = idx % NBZ, c = idx / NBZ;
-      if (c > k && r >= c) {
-        const double lr = Lr[r][k], li = Li[r][k], cr = Lr[c][k], ci = Li[c][k];
-        Lr[r][c] -= lr * cr + li * ci;
-        Li[r][c] = c == r ? 0.0 : Li[r][c] - (li * cr - lr * ci);
+  if (tid < 64) {  // wave 0: lane = (row rr, column parity h)
+    const int rr = tid & (NBZ - 1), h = tid >> 5;
+    for (int k = 0; k < NBZ; ++k) {
+      double d = Lr[k][k];
+      if (!(d > 0.0) || !isfinite(d)) {  // uniform
+        if (bad == 0) bad = k + 1;
+        d = 1.0;
       }
+      const double sq = sqrt(d), inv = 1.0 / sq;
+      __builtin_amdgcn_wave_barrier();
+      double lr = 0.0, li = 0.0;
+      if (rr >= k) {
+        lr = rr == k ? sq : Lr[rr][k] * inv;
+        li = rr == k ? 0.0 : Li[rr][k] * inv;
+        if (h == 0) {
+          Lr[rr][k] = lr;
+          Li[rr][k] = li;
+        }
+      }
+      if (tid == 0) dv[k] = inv;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      for (int c = k + 1 + h; c <= rr; c += 2) {  // a[rr][c] -= l[rr] conj(l[c])
+        const double cr = Lr[c][k], ci = Li[c][k];
+        Lr[rr][c] -= lr * cr + li * ci;
+        Li[rr][c] = c == rr ? 0.0 : Li[rr][c] - (li * cr - lr * ci);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
-    __syncthreads();
+    if (rhs_run) {  // y[k0 .. k0 + w): L11 y = (running right-hand side), forward substitution across the lanes
+      double2 acc = (h == 0 && rr < w) ? rhs_run[k0 + rr] : make_double2(0.0, 0.0);
+      for (int t = 0; t < NBZ; ++t) {
+        if (tid == t) ysh[t] = make_double2(acc.x * dv[t], acc.y * dv[t]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (h == 0 && rr > t) {
+          const double2 yt = ysh[t];
+          const double lr = Lr[rr][t], li = Li[rr][t];
+          acc.x -= lr * yt.x - li * yt.y;
+          acc.y -= lr * yt.y + li * yt.x;
+        }
+      }
+      if (blockIdx.x == 0 && h == 0 && rr < w) ysol[k0 + rr] = ysh[rr];
+    }
   }
+  __syncthreads();
   if (blockIdx.x == 0) {
     // L11 goes back into A directly only when no other workgroup exists that may still be reading the un-factored block; otherwise into
     // L11out, from where the update kernel (the next launch) puts it in place.
     double2* dst = gridDim.x == 1 ? A : L11out;
     const long ldd = gridDim.x == 1 ? lda : NBZ;
     for (int idx = tid; idx < NBZ * NBZ; idx += ZP_ROWS) {
-      const int r = idx % NBZ, c = idx / NBZ;
-      if (r < w && c <= r) dst[r + (long)c * ldd] = make_double2(Lr[r][c], Li[r][c]);
+      const int rr = idx % NBZ, c = idx / NBZ;
+      if (rr < w && c <= rr) dst[rr + (long)c * ldd] = make_double2(Lr[rr][c], Li[rr][c]);
     }
     if (bad != 0 && bad <= w && tid == 0) atomicCAS(info, 0, k0 + bad);  // (pivots of the identity padding beyond w cannot fail)
   }
   // ---- this workgroup's rows of the panel below the block ----
-  const long r = (long)blockIdx.x * ZP_ROWS + tid;
   if (r >= m_pad) return;
-  const bool live = r < m;
-  double2* A21 = A + w;
-  for (int c = 0; c < NBZ; ++c) xs[c][tid] = (live && c < w) ? A21[r + (long)c * lda] : make_double2(0.0, 0.0);  // (32 independent loads in flight)
   for (int c = 0; c < NBZ; ++c) {
     double2 x = xs[c][tid];
     double sr = x.x, si = x.y;
@@ -108,19 +141,35 @@ __global__ void __launch_bounds__(ZP_ROWS) k_zpotrf_panel(double2* __restrict__ 
     }
     xs[c][tid] = make_double2(sr * dv[c], si * dv[c]);  // (read back by this thread only: no barrier)
   }
+  if (rhs_run && live) {  // this row's share of the forward substitution: b[r] -= L21[r, :] y
+    double2 acc = rhs_run[k0 + w + r];
+    for (int c = 0; c < w; ++c) {
+      const double2 x = xs[c][tid], yv = ysh[c];
+      acc.x -= x.x * yv.x - x.y * yv.y;
+      acc.y -= x.x * yv.y + x.y * yv.x;
+    }
+    rhs_run[k0 + w + r] = acc;
+  }
+  const long half = (long)NBZ * ldp;
   for (int c = 0; c < NBZ; ++c) {
     const bool keep = live && c < w;
-    const double2 x = xs[c][tid];
+    const double2 x = keep ? xs[c][tid] : make_double2(0.0, 0.0);
     if (keep) A21[r + (long)c * lda] = x;
-    Pr[(long)c * ldp + r] = keep ? x.x : 0.0;
-    Pi[(long)c * ldp + r] = keep ? x.y : 0.0;
-    Pn[(long)c * ldp + r] = keep ? -x.y : 0.0;
-    // the same entries as rows of the OUTER block column's planes (rows below the outer block only: index r - orow0; the caller has
-    // zeroed those planes, padding included; Or .. On already point at this panel's 32 k-rows)
-    if (keep && r >= orow0) {
-      Or[(long)c * ldp + (r - orow0)] = x.x;
-      Oi[(long)c * ldp + (r - orow0)] = x.y;
-      On[(long)c * ldp + (r - orow0)] = -x.y;
+    const long o = (long)c * ldp + r;
+    S1[o] = x.x;
+    S1[half + o] = x.y;
+    S2[o] = x.x;
+    S2[half + o] = -x.y;
+    S3[o] = x.y;
+    S3[half + o] = x.x;
+    if (keep && r >= orow0) {  // (O1 .. O3 already point at this panel's 32 k-rows of the first halves)
+      const long oo = (long)c * ldp + (r - orow0), oh = ohalf * ldp;
+      O1[oo] = x.x;
+      O1[oh + oo] = x.y;
+      O2[oo] = x.x;
+      O2[oh + oo] = -x.y;
+      O3[oo] = x.y;
+      O3[oh + oo] = x.x;
     }
   }
 }
@@ -135,10 +184,13 @@ __global__ void __launch_bounds__(256) k_zpotrf_putback(const double2* L11src, d
 
 // A22 -= L21 L21^H on the lower triangle: 128 x 128 tiles (R, C), R >= C, C < ncol_tiles, of the m x m matrix A22 (interleaved complex, leading
 // dimension lda; only columns < ncols are touched) on the real tile engine.  blockIdx.y = 0: real part, 1: imaginary part.  The tile is formed
-// transposed (A operand: the tile's columns, B operand: its rows), as in k_potrf_syrk.  Planes: [ktiles * 16][ldp], readable (zero) up to a multiple
-// of 128 rows and of 16 k.  ncol_tiles < the number of row tiles gives the tall update inside an outer block column.
-__global__ void __launch_bounds__(Cfg4::NTHREADS, 2) k_zpotrf_herk(double2* A, long lda, int m, int ncols, int ncol_tiles, int ktiles, const double* Pr,
-                                                                   const double* Pi, const double* Pn, long ldp, const double2* L11src, double2* L11dst, int w) {
+// transposed (A operand: the tile's columns, B operand: its rows), as in k_potrf_syrk.  With a = L[r][k], b = L[c][k]:
+//   Re (L L^H)[r][c] = sum_k ar br + ai bi  = [Re; Im] . [Re; Im]      Im = sum_k ai br - ar bi = [Re; -Im](c) . [Im; Re](r)
+// i.e. ONE product over the stacked planes S1 x S1 or S2 x S3 (k_zpotrf_panel), K = 2 x the half height: one main loop, one accumulator set
+// (two passes over separate planes kept both loaders' state alive and spilled 145 registers).  Planes: [2 ktiles_half * 16][ldp], readable
+// (zero) up to a multiple of 128 rows.  ncol_tiles < the number of row tiles gives the tall update inside an outer block column.
+__global__ void __launch_bounds__(Cfg4::NTHREADS, 2) k_zpotrf_herk(double2* A, long lda, int m, int ncols, int ncol_tiles, int ktiles, const double* S1,
+                                                                   const double* S2, const double* S3, long ldp, const double2* L11src, double2* L11dst, int w) {
   using C4 = Cfg4;
   extern __shared__ double smem[];
   if (L11src && blockIdx.x == 0 && blockIdx.y == 0) {  // the panel kernel's factored diagonal block, put in place (k_zpotrf_panel)
@@ -162,18 +214,9 @@ __global__ void __launch_bounds__(Cfg4::NTHREADS, 2) k_zpotrf_herk(double2* A, l
   const int part = blockIdx.y;
   v4d acc[C4::MT][C4::NTL];
   zero_acc(acc);
-  // (L L^H)[r][c] = sum_k (ar br + ai bi) + i (ai br - ar bi) with a = L[r][k], b = L[c][k]; A operand <-> c, B operand <-> r
-  {
-    KMajorLoader<C4::NTHREADS, BM> la{Pr, ldp, (long)C * BM};
-    KMajorLoader<C4::NTHREADS, BN> lb{part == 0 ? Pr : Pi, ldp, (long)R * BN};
-    mainloop_real<C4, true>(acc, la, lb, 0, ktiles, smem);
-  }
-  __syncthreads();
-  {
-    KMajorLoader<C4::NTHREADS, BM> la{part == 0 ? Pi : Pn, ldp, (long)C * BM};
-    KMajorLoader<C4::NTHREADS, BN> lb{part == 0 ? Pi : Pr, ldp, (long)R * BN};
-    mainloop_real<C4, true>(acc, la, lb, 0, ktiles, smem);
-  }
+  KMajorLoader<C4::NTHREADS, BM> la{part == 0 ? S1 : S2, ldp, (long)C * BM};
+  KMajorLoader<C4::NTHREADS, BN> lb{part == 0 ? S1 : S3, ldp, (long)R * BN};
+  mainloop_real<C4, true>(acc, la, lb, 0, ktiles, smem);
   double* Ad = reinterpret_cast<double*>(A) + part;
 #pragma unroll
   for (int mt = 0; mt < C4::MT; ++mt)
@@ -186,6 +229,81 @@ __global__ void __launch_bounds__(Cfg4::NTHREADS, 2) k_zpotrf_herk(double2* A, l
         if (r < m && cc < ncols && (part == 0 ? r >= cc : r > cc)) Ad[2 * (r + cc * lda)] -= acc[mt][nt][reg];
       }
     }
+}
+
+// beta of L^H beta = y, in place in y, where the array holds Lc = conj(L) (column-major lower: what the download's conjugation leaves behind,
+// i.e. scipy's upper factor read column-major): Lc^T beta = y.  Backwards in outer blocks of NBO columns, two launches per block:
+//   k_ztrsv_outer_sum: s[c] = sum_{r >= K0 + W} Lc[r][c] beta[r] for the block's columns - one workgroup per column (a column is contiguous);
+//   k_ztrsv_block    : ONE workgroup finishes the block: panels of 32 columns backwards, per panel the 256 threads form the sums over the
+//                      block's later rows and thread 0 solves the 32 x 32 triangle.
+// (rocblas_ztrsv: 2.2 ms per solve at n = 4097 - 134 MB of matrix at 60 GB/s.)
+__global__ void __launch_bounds__(256) k_ztrsv_outer_sum(const double2* __restrict__ Lc, long lda, int n, int K0, int W, const double2* __restrict__ y,
+                                                         double2* __restrict__ sums) {
+  __shared__ double2 red[4];
+  const int c = K0 + blockIdx.x;
+  double sr = 0.0, si = 0.0;
+  for (int r = K0 + W + threadIdx.x; r < n; r += 256) {
+    const double2 l = Lc[(long)r + (long)c * lda], b = y[r];
+    sr += l.x * b.x - l.y * b.y;
+    si += l.x * b.y + l.y * b.x;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    sr += __shfl_xor(sr, o, 64);
+    si += __shfl_xor(si, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = make_double2(sr, si);
+  __syncthreads();
+  if (threadIdx.x == 0) sums[blockIdx.x] = make_double2((red[0].x + red[1].x) + (red[2].x + red[3].x), (red[0].y + red[1].y) + (red[2].y + red[3].y));
+}
+__global__ void __launch_bounds__(256) k_ztrsv_block(const double2* __restrict__ Lc, long lda, int K0, int W, double2* __restrict__ y,
+                                                     const double2* __restrict__ sums) {
+  __shared__ double2 part[8][NBZ];
+  __shared__ double2 blk[NBZ][NBZ + 1];
+  __shared__ double2 sol[NBZ];
+  const int tid = threadIdx.x, c = tid & (NBZ - 1), g = tid >> 5;
+  const int bend = K0 + W, np = (W + NBZ - 1) / NBZ;
+  for (int p = np - 1; p >= 0; --p) {
+    const int k0 = K0 + p * NBZ, w = min(NBZ, bend - k0), rend = k0 + w;
+    double sr = 0.0, si = 0.0;
+    if (c < w)
+      for (int r = rend + g; r < bend; r += 8) {
+        const double2 l = Lc[(long)r + (long)(k0 + c) * lda], b = y[r];
+        sr += l.x * b.x - l.y * b.y;
+        si += l.x * b.y + l.y * b.x;
+      }
+    part[g][c] = make_double2(sr, si);
+    for (int idx = tid; idx < NBZ * NBZ; idx += 256) {
+      const int rr = idx % NBZ, cc = idx / NBZ;
+      blk[rr][cc] = (rr < w && cc < w && rr >= cc) ? Lc[(long)(k0 + rr) + (long)(k0 + cc) * lda] : make_double2(rr == cc ? 1.0 : 0.0, 0.0);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      for (int cc = w - 1; cc >= 0; --cc) {
+        double2 acc = y[k0 + cc];
+        if (sums) {
+          acc.x -= sums[k0 - K0 + cc].x;
+          acc.y -= sums[k0 - K0 + cc].y;
+        }
+        for (int q = 0; q < 8; ++q) {
+          acc.x -= part[q][cc].x;
+          acc.y -= part[q][cc].y;
+        }
+        for (int rr = cc + 1; rr < w; ++rr) {
+          const double2 l = blk[rr][cc], b = sol[rr];
+          acc.x -= l.x * b.x - l.y * b.y;
+          acc.y -= l.x * b.y + l.y * b.x;
+        }
+        const double dinv = 1.0 / blk[cc][cc].x;  // the diagonal of a Cholesky factor is real
+        acc.x *= dinv;
+        acc.y *= dinv;
+        sol[cc] = acc;
+        y[k0 + cc] = acc;
+      }
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
 }
 
 }  // namespace zpotrf

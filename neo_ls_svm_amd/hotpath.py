@@ -28,6 +28,7 @@ __all__ = [
     "bin_stats",
     "tridiagonalize",
     "eigh",
+    "stedc",
     "primal_fit",
     "primal_fit_sigma_grid",
     "primal_predict",
@@ -208,6 +209,20 @@ def eigh(A, ctx: Context | None = None):
     lam = np.empty(n)
     ctx._check(ctx.lib.nls_eigh_only(ctx.handle, Af.ctypes.data, n, int(cplx), lam.ctypes.data))
     return lam, Af
+
+
+def stedc(d, e, ctx: Context | None = None):
+    """(eigenvalues ascending, eigenvectors in columns) of the symmetric tridiagonal matrix diag(d) + offdiag(e): the tridiagonal stage of both
+    eigendecompositions alone (test / profiling hook ``nls_stedc_only``)."""
+    ctx = ctx or default_context()
+    d = np.array(d, dtype=np.float64)
+    e = np.ascontiguousarray(e, dtype=np.float64)
+    n = d.size
+    if n < 1 or e.size != max(n - 1, 0):
+        raise ValueError("d must have n >= 1 entries and e n - 1")
+    Q = np.empty((n, n), order="F")
+    ctx._check(ctx.lib.nls_stedc_only(ctx.handle, d.ctypes.data, e.ctypes.data if n > 1 else None, n, Q.ctypes.data))
+    return d, Q
 
 
 def cholesky(A, ctx: Context | None = None):

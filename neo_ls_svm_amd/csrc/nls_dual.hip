@@ -3,6 +3,7 @@
 // Reference: NeoLSSVM._optimize_alpha_gamma, _neo_ls_svm.py:191-325; inference :470-477, :666-671.
 #include "nls_dual_kernels.h"
 #include "nls_host.h"
+#include "nls_trsv.h"
 #include "nls_kernels.h"
 #include "nls_potrf.h"
 
@@ -47,6 +48,34 @@ static int potrf_lower_real(nls_ctx* ctx, double* A, int n, long lda, rocblas_in
     // event_cols > 0 (a multiple of NB): block column b of that width is final and no longer read once its last panel's update has run
     if (event_cols > 0 && ((k0 + NB) % event_cols == 0 || k0 + NB >= n)) HIPCHK(ctx, hipEventRecord(ctx->blk_ev[k0 / event_cols], ctx->stream));
   }
+  return NLS_OK;
+}
+
+// x <- L^-T L^-1 x in place (nls_trsv.h): forwards then backwards in outer blocks of 256 unknowns.  NLS_TRSV=rocblas: two rocblas_dtrsv calls.
+static int cho_solve_real(nls_ctx* ctx, const double* L, int n, long ldl, double* x) {
+  using namespace trsv;
+  const char* mode = std::getenv("NLS_TRSV");
+  if (mode && std::string(mode) == "rocblas") {
+    BLASCHK(ctx, rocblas_set_stream(ctx->blas, ctx->stream));
+    BLASCHK(ctx, rocblas_dtrsv(ctx->blas, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, (rocblas_int)n, L, (rocblas_int)ldl, x, 1));
+    BLASCHK(ctx, rocblas_dtrsv(ctx->blas, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, (rocblas_int)n, L, (rocblas_int)ldl, x, 1));
+    return NLS_OK;
+  }
+  double* sums = nullptr;
+  NLSCHK(ws_get_t(ctx, "trsv.sums", (size_t)OB, &sums));
+  const int nblk = (n + OB - 1) / OB;
+  for (int b = 0; b < nblk; ++b) {
+    const int K0 = b * OB, W = std::min(OB, n - K0), below = n - K0 - W;
+    hipLaunchKernelGGL(k_trsv_fwd_block, dim3(1), dim3(256), 0, ctx->stream, L, ldl, K0, W, x);
+    if (below > 0) hipLaunchKernelGGL(k_trsv_fwd_update, dim3((unsigned)((below + 255) / 256)), dim3(256), 0, ctx->stream, L, ldl, n, K0, W, x);
+  }
+  for (int b = nblk - 1; b >= 0; --b) {
+    const int K0 = b * OB, W = std::min(OB, n - K0);
+    const bool tail = K0 + W < n;
+    if (tail) hipLaunchKernelGGL(k_trsv_bwd_outer_sum, dim3((unsigned)W), dim3(256), 0, ctx->stream, L, ldl, n, K0, W, x, sums);
+    hipLaunchKernelGGL(k_trsv_bwd_block, dim3(1), dim3(256), 0, ctx->stream, L, ldl, K0, W, x, tail ? sums : (const double*)nullptr);
+  }
+  HIPCHK(ctx, hipGetLastError());
   return NLS_OK;
 }
 
@@ -338,9 +367,7 @@ extern "C" int nls_dual_fit(nls_ctx* ctx, const nls_dual_fit_args* a) {
     // side against the factor just formed, so that the returned pair satisfies alpha == cho_solve(L_, y) to rounding.  (The selected column of
     // the sweep's table above is the same vector from the eigendecomposition; it stays the answer when no factor is asked for.)
     HIPCHK(ctx, hipMemcpyAsync(alpha, dy, sizeof(double) * n, hipMemcpyDeviceToDevice, ctx->stream));
-    BLASCHK(ctx, rocblas_set_stream(ctx->blas, ctx->stream));
-    BLASCHK(ctx, rocblas_dtrsv(ctx->blas, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, (rocblas_int)n, M2, (rocblas_int)n_pad, alpha, 1));
-    BLASCHK(ctx, rocblas_dtrsv(ctx->blas, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, (rocblas_int)n, M2, (rocblas_int)n_pad, alpha, 1));
+    NLSCHK(cho_solve_real(ctx, M2, (int)n, n_pad, alpha));
     NLSCHK(check_info(ctx, dinfo, "Cholesky factorisation (potrf)"));
   } else {
     // no factorisation, hence no pivot test: gamma* diag(sn^-2) + K is positive definite iff gamma* + lam_min(sn K sn) > 0

@@ -576,7 +576,7 @@ static int stedc_dc(nls_ctx* ctx, int n, double* d, const double* e, double* C, 
   const int nm_max = (n + 2 * LEAF - 1) / (2 * LEAF);
   double *lam2 = nullptr, *Q2 = nullptr, *ds = nullptr, *zs = nullptr, *dl = nullptr, *w = nullptr, *dorg = nullptr, *mu = nullptr, *lamnew = nullptr, *zhat = nullptr;
   double *U = nullptr, *G = nullptr, *R = nullptr;
-  int *src = nullptr, *kidx = nullptr, *didx = nullptr, *pos = nullptr;
+  int *src = nullptr, *kidx = nullptr, *didx = nullptr, *pos = nullptr, *gpos = nullptr;
   Rot* rots = nullptr;
   MergeInfo* info = nullptr;
   NLSCHK(ws_get_t(ctx, "dc.lam2", (size_t)n, &lam2));
@@ -592,6 +592,7 @@ static int stedc_dc(nls_ctx* ctx, int n, double* d, const double* e, double* C, 
   NLSCHK(ws_get_t(ctx, "dc.kidx", (size_t)n, &kidx));
   NLSCHK(ws_get_t(ctx, "dc.didx", (size_t)n, &didx));
   NLSCHK(ws_get_t(ctx, "dc.pos", (size_t)n, &pos));
+  NLSCHK(ws_get_t(ctx, "dc.gpos", (size_t)n, &gpos));
   NLSCHK(ws_get_t(ctx, "dc.rots", (size_t)n, &rots));
   NLSCHK(ws_get_t(ctx, "dc.info", (size_t)nm_max, &info));
   if (nlev > 0) {
@@ -623,12 +624,12 @@ static int stedc_dc(nls_ctx* ctx, int n, double* d, const double* e, double* C, 
     const unsigned mmax = (unsigned)std::min<long>(2 * S, n);
     const double* Qc = Qbuf[cur];
     double* Qn = Qbuf[cur ^ 1];
-    hipLaunchKernelGGL(k_dc_setup, dim3(nm), dim3(256), 0, st, L, Lbuf[cur], Qc, (long)n, e, ds, zs, src, dl, w, kidx, didx, rots, info);
+    hipLaunchKernelGGL(k_dc_setup, dim3(nm), dim3(256), 0, st, L, Lbuf[cur], Qc, (long)n, e, ds, zs, src, dl, w, kidx, didx, gpos, rots, info);
     hipLaunchKernelGGL(k_dc_rotate, dim3((mmax + 255) / 256, nm), dim3(256), 0, st, L, Qbuf[cur], (long)n, rots, info);
-    hipLaunchKernelGGL(k_dc_gather, dim3((unsigned)((L.P + 255) / 256), (mmax + 15) / 16, nm), dim3(256), 0, st, L, Qc, (long)n, src, kidx, info, G);
+    hipLaunchKernelGGL(k_dc_gather, dim3((unsigned)((L.P + 255) / 256), (mmax + 15) / 16, nm), dim3(256), 0, st, L, Qc, (long)n, src, kidx, gpos, info, G);
     hipLaunchKernelGGL(k_dc_secular, dim3((mmax + 4 * RW - 1) / (4 * RW), nm), dim3(256), 0, st, L, dl, w, info, dorg, mu, lamnew);
     hipLaunchKernelGGL(k_dc_zhat, dim3((mmax + 3) / 4, nm), dim3(256), 0, st, L, dl, w, dorg, mu, info, zhat);
-    hipLaunchKernelGGL(k_dc_vectors, dim3(mmax, nm), dim3(256), 0, st, L, dl, zhat, dorg, mu, info, U);
+    hipLaunchKernelGGL(k_dc_vectors, dim3(mmax, nm), dim3(256), 0, st, L, dl, zhat, dorg, mu, gpos, info, U);
     hipLaunchKernelGGL(k_dc_gemm, dim3((unsigned)(L.P / BN), (unsigned)(L.P / BM), nm), dim3(Cfg4::NTHREADS), 2 * 2 * TILE_DOUBLES * sizeof(double), st, L, U, G, R, info);
     hipLaunchKernelGGL(k_dc_place, dim3((mmax + 255) / 256, nm), dim3(256), 0, st, L, lamnew, ds, didx, info, pos, Lbuf[cur ^ 1]);
     hipLaunchKernelGGL(k_dc_scatter, dim3((mmax + 255) / 256, (mmax + 7) / 8, nm), dim3(256), 0, st, L, R, Qc, Qn, (long)n, src, didx, pos, info);

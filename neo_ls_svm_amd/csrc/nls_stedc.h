@@ -12,10 +12,9 @@
 //                  deflation scan (negligible z_i; close poles rotated into one) by one thread over LDS-staged chunks;
 //   k_dc_rotate  : the deflation rotations on the eigenvector columns, rows in parallel, the chain's running column carried in a register;
 //   k_dc_gather  : the k non-deflated columns, contiguous;
-//   k_dc_secular : the roots of 1 + rho sum w_i^2 / (d_i - lam) = 0 by BISECTION in the logarithm of the distance to the nearest pole - one
-//                  wave per 8 roots, the poles spread over its lanes: ~60 evaluations of an O(k) sum instead of dlaed4's 4-6 rational
-//                  interpolation steps, no special cases, and it stops where the computed function changes sign, i.e. at the residual level
-//                  dlaed4's stopping criterion asks for;
+//   k_dc_secular : the roots of 1 + rho sum w_i^2 / (d_i - lam) = 0 as (nearest pole, offset): one wave per 4 roots, the poles spread over its
+//                  lanes; dlaed4's iteration (a two-pole rational model of the function, "the middle way") with its stopping criterion, every
+//                  step that leaves the bracket replaced by a bisection step in the logarithm of the offset: 3 - 6 sweeps over the poles;
 //   k_dc_zhat    : Gu / Eisenstat (dlaed3): z is RECOMPUTED from the computed roots - they are then the exact eigenvalues of
 //                  D + rho zhat zhat^T - so orthogonality does not rest on the accuracy of the roots; every difference d_i - lam_j is formed as
 //                  (d_i - d_origin(j)) - mu_j, never from a rounded lam_j;
@@ -32,12 +31,13 @@ namespace dc {
 
 constexpr int LEAF = 32;
 constexpr int SCAN_CHUNK = 2048;  // poles staged in LDS per step of the deflation scan
-constexpr int RW = 8;             // roots per wave in the secular kernel
+constexpr int RW = 4;             // roots per wave in the secular kernel
 
 struct MergeInfo {
-  int k;      // non-deflated poles
-  int ndefl;  // deflated (their eigenpairs are final)
-  int nrot;   // deflation rotations
+  int k;       // non-deflated poles
+  int ndefl;   // deflated (their eigenpairs are final)
+  int nrot;    // deflation rotations
+  int k1, k2;  // of the k kept columns: k1 live in the upper block only, k2 are dense (rotated across the blocks), the rest in the lower block only
   int pad;
   double rho;  // 2 |e|: the rank-one coefficient after normalising z
 };
@@ -165,8 +165,9 @@ __global__ void __launch_bounds__(64) k_dc_leaf(int n, const double* d_in, const
 //   ds, zs, src : eigenvalues, z components and block-relative source columns in merged ascending order (ds is updated by the rotations);
 //   dl, w, kidx : the k kept poles (ascending), their z components, their sorted positions;   didx: sorted positions of the deflated ones.
 __global__ void __launch_bounds__(256) k_dc_setup(Level L, const double* lam, const double* Q, long ldq, const double* e, double* ds, double* zs, int* src,
-                                                  double* dl, double* w, int* kidx, int* didx, Rot* rots, MergeInfo* info) {
+                                                  double* dl, double* w, int* kidx, int* didx, int* gpos, Rot* rots, MergeInfo* info) {
   __shared__ double sd[SCAN_CHUNK], sz[SCAN_CHUNK];
+  __shared__ int cnt[4];
   __shared__ double red[2][4];
   const int mi = blockIdx.x, tid = threadIdx.x;
   const int b0 = L.b0(mi), mid = L.mid(mi), b1 = L.b1(mi);
@@ -178,7 +179,7 @@ __global__ void __launch_bounds__(256) k_dc_setup(Level L, const double* lam, co
       src[b0 + t] = t;
       didx[b0 + t] = t;
     }
-    if (tid == 0) info[mi] = MergeInfo{0, m, 0, 0, 0.0};
+    if (tid == 0) info[mi] = MergeInfo{0, m, 0, 0, 0, 0, 0.0};
     return;
   }
   const int n1 = mid - b0;
@@ -226,11 +227,87 @@ __global__ void __launch_bounds__(256) k_dc_setup(Level L, const double* lam, co
   const double tol = 8.0 * 2.220446049250313e-16 * fmax(dmax, zmax);
   if (rho * zmax <= tol) {  // the coupling is negligible: the merged spectrum is the union
     for (int t = tid; t < m; t += 256) didx[b0 + t] = t;
-    if (tid == 0) info[mi] = MergeInfo{0, m, 0, 0, rho};
+    if (tid == 0) info[mi] = MergeInfo{0, m, 0, 0, 0, 0, rho};
     return;
   }
   // dlaed2's scan, sequential in the merged order: thread 0, the poles staged through LDS
-  int k = 0, nd = 0, nrot = 0, pj = -1;
+  // Column types as in dlaed2 (the product Q[:, kept] U is block structured): 1 = lives in the upper block only, 3 = in the lower block only,
+  // 2 = dense (a rotation mixed an upper with a lower column).  gpos[i] starts as (type << 28) | ordinal within the type.
+  //
+  // Fast path, all threads: the scan below is sequential only through its rotations.  Every thread takes a contiguous segment of the merged
+  // order; a first pass counts the segment's candidates (components that are not negligible) and remembers its last one, a prefix over the 256
+  // segments gives every thread its offsets and the candidate before its segment, and a second pass writes the kept / deflated lists and
+  // tests every consecutive pair of candidates for the rotation criterion.  No pair passing it means the sequential scan would never rotate -
+  // the lists are then exactly its result; otherwise thread 0 runs the scan (and overwrites them).
+  __shared__ int seg_cnt[256][4];  // candidates of type 1, of type 3, deflated, last candidate (-1: none)
+  __shared__ int any_rot;
+  {
+    const int len = (m + 255) / 256, j0 = min(tid * len, m), j1 = min(j0 + len, m);
+    int c1 = 0, c3 = 0, cd = 0, last = -1;
+    for (int j = j0; j < j1; ++j) {
+      if (rho * fabs(zs[b0 + j]) <= tol) ++cd;
+      else {
+        if (src[b0 + j] < n1) ++c1; else ++c3;
+        last = j;
+      }
+    }
+    seg_cnt[tid][0] = c1;
+    seg_cnt[tid][1] = c3;
+    seg_cnt[tid][2] = cd;
+    seg_cnt[tid][3] = last;
+    if (tid == 0) any_rot = 0;
+    __syncthreads();
+    int o1 = 0, o3 = 0, od = 0, prev = -1;  // exclusive prefix (256 short reads per thread)
+    for (int t = 0; t < tid; ++t) {
+      o1 += seg_cnt[t][0];
+      o3 += seg_cnt[t][1];
+      od += seg_cnt[t][2];
+      if (seg_cnt[t][3] >= 0) prev = seg_cnt[t][3];
+    }
+    int t1 = 0, t3 = 0, td = 0;
+    if (tid == 255) {
+      t1 = o1 + c1;
+      t3 = o3 + c3;
+      td = od + cd;
+    }
+    int ko = o1 + o3;
+    bool rot = false;
+    for (int j = j0; j < j1; ++j) {
+      const double dj = ds[b0 + j], zj = zs[b0 + j];
+      if (rho * fabs(zj) <= tol) {
+        didx[b0 + od++] = j;
+        continue;
+      }
+      if (prev >= 0) {
+        const double zp = zs[b0 + prev], tau = hypot(zj, zp), c = zj / tau, sn = -zp / tau;
+        rot = rot || fabs((dj - ds[b0 + prev]) * c * sn) <= tol;
+      }
+      const int ty = src[b0 + j] < n1 ? 1 : 3;
+      dl[b0 + ko] = dj;
+      w[b0 + ko] = zj;
+      kidx[b0 + ko] = j;
+      gpos[b0 + ko] = (ty << 28) | (ty == 1 ? o1++ : o3++);
+      ++ko;
+      prev = j;
+    }
+    if (rot) any_rot = 1;
+    if (tid == 255) {
+      info[mi] = MergeInfo{t1 + t3, td, 0, t1, 0, 0, rho};
+      cnt[0] = t1 + t3;
+      cnt[1] = t1;
+      cnt[2] = 0;
+    }
+    __syncthreads();
+    if (!any_rot) {
+      for (int i = tid; i < cnt[0]; i += 256) {
+        const int g = gpos[b0 + i], ty = g >> 28, ord = g & 0x0fffffff;
+        gpos[b0 + i] = ord + (ty == 1 ? 0 : cnt[1]);
+      }
+      return;
+    }
+    __syncthreads();
+  }
+  int k = 0, nd = 0, nrot = 0, pj = -1, tpj = 0, nty[4] = {0, 0, 0, 0};
   double dpj = 0.0, zpj = 0.0;
   for (int c0 = 0; c0 < m; c0 += SCAN_CHUNK) {
     const int cn = min(SCAN_CHUNK, m - c0);
@@ -248,10 +325,12 @@ __global__ void __launch_bounds__(256) k_dc_setup(Level L, const double* lam, co
           didx[b0 + nd++] = j;
           continue;
         }
+        const int tj = src[b0 + j] < n1 ? 1 : 3;
         if (pj < 0) {
           pj = j;
           dpj = dj;
           zpj = zj;
+          tpj = tj;
           continue;
         }
         const double tau = hypot(zj, zpj), t = dj - dpj, c = zj / tau, s = -zpj / tau;
@@ -262,13 +341,16 @@ __global__ void __launch_bounds__(256) k_dc_setup(Level L, const double* lam, co
           dpj = dpj * s * s + dj * c * c;
           zpj = tau;
           pj = j;
+          tpj = tpj == tj ? tj : 2;
         } else {
           dl[b0 + k] = dpj;
           w[b0 + k] = zpj;
+          gpos[b0 + k] = (tpj << 28) | nty[tpj]++;
           kidx[b0 + k++] = pj;
           pj = j;
           dpj = dj;
           zpj = zj;
+          tpj = tj;
         }
       }
     }
@@ -277,9 +359,18 @@ __global__ void __launch_bounds__(256) k_dc_setup(Level L, const double* lam, co
     if (pj >= 0) {
       dl[b0 + k] = dpj;
       w[b0 + k] = zpj;
+      gpos[b0 + k] = (tpj << 28) | nty[tpj]++;
       kidx[b0 + k++] = pj;
     }
-    info[mi] = MergeInfo{k, nd, nrot, 0, rho};
+    info[mi] = MergeInfo{k, nd, nrot, nty[1], nty[2], 0, rho};
+    cnt[0] = k;
+    cnt[1] = nty[1];
+    cnt[2] = nty[2];
+  }
+  __syncthreads();
+  for (int i = tid; i < cnt[0]; i += 256) {  // position in the gathered order: type 1, then 2, then 3
+    const int g = gpos[b0 + i], ty = g >> 28, ord = g & 0x0fffffff;
+    gpos[b0 + i] = ord + (ty == 1 ? 0 : ty == 2 ? cnt[1] : cnt[1] + cnt[2]);
   }
 }
 
@@ -311,7 +402,7 @@ __global__ void __launch_bounds__(256) k_dc_rotate(Level L, double* Q, long ldq,
 
 // ---- merge: the kept columns, contiguous (G: P x P slot, column-major; zero in rows m .. and in columns k .. up to the next multiple of 16) ----
 // grid = (row chunks of 256, column groups of 16, merges)
-__global__ void __launch_bounds__(256) k_dc_gather(Level L, const double* Q, long ldq, const int* src, const int* kidx, const MergeInfo* info, double* G) {
+__global__ void __launch_bounds__(256) k_dc_gather(Level L, const double* Q, long ldq, const int* src, const int* kidx, const int* gpos, const MergeInfo* info, double* G) {
   const int mi = blockIdx.z, b0 = L.b0(mi);
   if (b0 >= L.n) return;
   const int k = info[mi].k, m = L.b1(mi) - b0;
@@ -321,10 +412,10 @@ __global__ void __launch_bounds__(256) k_dc_gather(Level L, const double* Q, lon
   if (r >= L.P) return;
   double* Gs = G + (long)mi * L.P * L.P;
 #pragma unroll 4
-  for (int i = i0; i < i0 + 16; ++i) {
+  for (int i = i0; i < i0 + 16; ++i) {  // kept pole i goes to column gpos[i] (columns grouped by type); the padding columns k .. k16 are zeroed
     double v = 0.0;
     if (i < k && r < m) v = Q[(long)(b0 + r) + (long)(b0 + src[b0 + kidx[b0 + i]]) * ldq];
-    Gs[r + (long)i * L.P] = v;
+    Gs[r + (long)(i < k ? gpos[b0 + i] : i) * L.P] = v;
   }
 }
 
@@ -343,7 +434,7 @@ __global__ void __launch_bounds__(256) k_dc_secular(Level L, const double* dl, c
   const double* D = dl + b0;
   const double* W = w + b0;
   const double tiny = 2.2250738585072014e-308;
-  double dj[RW], hi[RW], lo[RW], dor[RW];
+  double dj[RW], hi[RW], dor[RW];
   bool right[RW], live[RW];
   // midpoint values decide the origin; for the last root the bracket is (0, rho |w|^2]
   double acc[RW];
@@ -391,43 +482,81 @@ __global__ void __launch_bounds__(256) k_dc_secular(Level L, const double* dl, c
       }
     }
   }
-  double llo[RW], lhi[RW];
+  // dlaed4's iteration ("the middle way", Li 1994) in the offset tau from the origin pole: with psi = the sum over the poles left of the
+  // root and phi = over those right of it, the function f = 1 / rho + psi + phi is modelled by c + a / (dL - t) + b / (dR - t) (dL, dR: the
+  // two poles that enclose the root) matching value and slope of psi and of phi separately; the model's root inside the interval is the
+  // next iterate.  An iterate that leaves the bracket [tlo, thi] (kept by the sign of f) is replaced by a bisection step in log |tau|.  It
+  // stops by dlaed4's criterion - |f| at the level of its own rounding error - or when the step or the bracket is below rounding:
+  // 3 - 6 sweeps over the poles per root (a plain log-bisection took ~60).
+  double tau[RW], tlo[RW], thi[RW], dL[RW], dR[RW];
+  bool done[RW], lastr[RW];
 #pragma unroll
   for (int r = 0; r < RW; ++r) {
     const double others = rho * wave_sum_d(acc[r]);
     const double wo = wave_sum_d(wo2[r]);
     double l = right[r] ? 0.5 * rho * wo / (1.0 + others) : 0.5 * rho * wo / fmax(others - 1.0, 1.0);
-    l = fmax(fmin(l, hi[r]), tiny);
-    lo[r] = l;
-    llo[r] = log(l);
-    lhi[r] = log(fmax(hi[r], tiny));
+    const double h = fmax(hi[r], tiny);
+    l = fmax(fmin(l, h), tiny);
+    const int j = j0 + r;
+    lastr[r] = j >= k - 1;
+    const double gap = (live[r] && !lastr[r]) ? D[j + 1] - dj[r] : 0.0;
+    dL[r] = right[r] ? 0.0 : -gap;
+    dR[r] = right[r] ? gap : 0.0;
+    tlo[r] = right[r] ? l : -h;
+    thi[r] = right[r] ? h : -l;
+    tau[r] = right[r] ? fmin(2.0 * l, h) : -fmin(2.0 * l, h);
+    done[r] = !live[r];
   }
-  const double eps = 2.220446049250313e-16;
-  for (int it = 0; it < 90; ++it) {
-    double mm[RW];
+  const double eps = 2.220446049250313e-16, rhoinv = 1.0 / rho;
+  for (int it = 0; it < 80; ++it) {
     bool any = false;
 #pragma unroll
-    for (int r = 0; r < RW; ++r) {
-      const double lm = 0.5 * (llo[r] + lhi[r]);
-      mm[r] = exp(lm);
-      acc[r] = 0.0;
-      any = any || (live[r] && (lhi[r] - llo[r] > 2.0 * eps * fmax(1.0, fabs(lm))));
-    }
-    if (!any) break;  // (wave-uniform: every lane holds the same brackets)
+    for (int r = 0; r < RW; ++r) any = any || !done[r];
+    if (!any) break;  // (wave-uniform: every lane holds the same state)
+    double psi[RW], dpsi[RW], phi[RW], dphi[RW];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) psi[r] = dpsi[r] = phi[r] = dphi[r] = 0.0;
     for (int i = lane; i < k; i += 64) {
       const double di = D[i], w2 = W[i] * W[i];
 #pragma unroll
       for (int r = 0; r < RW; ++r) {
-        const double delta = di - dor[r];
-        acc[r] += w2 / (right[r] ? delta - mm[r] : delta + mm[r]);
+        const double rd = 1.0 / ((di - dor[r]) - tau[r]);
+        const double t = w2 * rd, t2 = t * rd;
+        const bool left = i <= j0 + r;
+        psi[r] += left ? t : 0.0;
+        dpsi[r] += left ? t2 : 0.0;
+        phi[r] += left ? 0.0 : t;
+        dphi[r] += left ? 0.0 : t2;
       }
     }
 #pragma unroll
     for (int r = 0; r < RW; ++r) {
-      const double f = 1.0 + rho * wave_sum_d(acc[r]);
-      const bool pole_side = right[r] ? f < 0.0 : f > 0.0;  // still on the origin's side of the root
-      const double lm = 0.5 * (llo[r] + lhi[r]);
-      if (pole_side) llo[r] = lm; else lhi[r] = lm;
+      const double ps = wave_sum_d(psi[r]), dps = wave_sum_d(dpsi[r]), ph = wave_sum_d(phi[r]), dph = wave_sum_d(dphi[r]);
+      if (done[r]) continue;
+      const double f = rhoinv + ps + ph, t0 = tau[r];
+      if (f < 0.0) tlo[r] = t0; else thi[r] = t0;
+      if (fabs(f) <= eps * (8.0 * (ph - ps) + 2.0 * rhoinv + fabs(t0) * (dps + dph))) {
+        done[r] = true;
+        continue;
+      }
+      const double DL = dL[r] - t0;
+      double eta;
+      if (lastr[r]) {  // one pole: c + a / (DL - eta) = 0
+        const double c = f - DL * dps, a = dps * DL * DL;
+        eta = DL + a / c;
+      } else {
+        const double DR = dR[r] - t0;
+        const double c = f - DL * dps - DR * dph, a = dps * DL * DL, b = dph * DR * DR;
+        const double B = c * (DL + DR) + a + b, C = DL * DR * f;
+        const double disc = sqrt(fabs(B * B - 4.0 * c * C));
+        if (c == 0.0) eta = C / B;
+        else if (B <= 0.0) eta = (B - disc) / (2.0 * c);
+        else eta = 2.0 * C / (B + disc);
+      }
+      double tn = t0 + eta;
+      if (!(tn > tlo[r] && tn < thi[r])) tn = (t0 < 0.0 ? -1.0 : 1.0) * sqrt(fabs(tlo[r])) * sqrt(fabs(thi[r]));
+      if (fabs(tn - t0) <= 8.0 * eps * fabs(tn) || fabs(thi[r] - tlo[r]) <= 8.0 * eps * fabs(tn)) done[r] = true;
+      tau[r] = tn;
     }
   }
   if (lane == 0) {
@@ -435,14 +564,12 @@ __global__ void __launch_bounds__(256) k_dc_secular(Level L, const double* dl, c
     for (int r = 0; r < RW; ++r) {
       const int j = j0 + r;
       if (j < k) {
-        const double mval = exp(0.5 * (llo[r] + lhi[r])), mj = right[r] ? mval : -mval;
         dorg[b0 + j] = dor[r];
-        mu[b0 + j] = mj;
-        lamnew[b0 + j] = dor[r] + mj;
+        mu[b0 + j] = tau[r];
+        lamnew[b0 + j] = dor[r] + tau[r];
       }
     }
   }
-  (void)lo;
 }
 
 // ---- merge: zhat (dlaed3), one wave per pole ----------------------------------------------------------------------------------------------
@@ -484,7 +611,8 @@ __global__ void __launch_bounds__(256) k_dc_zhat(Level L, const double* dl, cons
 
 // ---- merge: eigenvectors of the rank-one update, one workgroup per column (U: P x P slot, column-major) -----------------------------------
 // U_ij = zhat_i / (dl_i - lam_j), normalised; rows k .. up to the next multiple of 16 zeroed (the K padding of the product).  grid = (m, merges)
-__global__ void __launch_bounds__(256) k_dc_vectors(Level L, const double* dl, const double* zhat, const double* dorg, const double* mu, const MergeInfo* info, double* U) {
+__global__ void __launch_bounds__(256) k_dc_vectors(Level L, const double* dl, const double* zhat, const double* dorg, const double* mu, const int* gpos, const MergeInfo* info,
+                                                    double* U) {
   __shared__ double red[4];
   const int mi = blockIdx.y, b0 = L.b0(mi);
   if (b0 >= L.n) return;
@@ -494,17 +622,17 @@ __global__ void __launch_bounds__(256) k_dc_vectors(Level L, const double* dl, c
   double* Uc = U + (long)mi * L.P * L.P + (long)j * L.P;
   const double dor = dorg[b0 + j], mj = mu[b0 + j];
   double nrm = 0.0;
-  for (int i = threadIdx.x; i < k16; i += 256) {
+  for (int i = threadIdx.x; i < k16; i += 256) {  // row = the pole's column in the gathered order
     double v = 0.0;
     if (i < k) v = zhat[b0 + i] / ((dl[b0 + i] - dor) - mj);
-    Uc[i] = v;
+    Uc[i < k ? gpos[b0 + i] : i] = v;
     nrm += v * v;
   }
   nrm = wave_sum_d(nrm);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = nrm;
   __syncthreads();
   const double inv = 1.0 / sqrt((red[0] + red[1]) + (red[2] + red[3]));
-  for (int i = threadIdx.x; i < k; i += 256) Uc[i] *= inv;
+  for (int i = threadIdx.x; i < k; i += 256) Uc[i] *= inv;  // (each thread scales the entries it wrote or others wrote: after the barrier)
 }
 
 // ---- merge: R = G U on the tile engine, all merges of the level in one launch ------------------------------------------------------------
@@ -519,11 +647,17 @@ __global__ void __launch_bounds__(Cfg4::NTHREADS, 2) k_dc_gemm(Level L, const do
   const long row0 = (long)blockIdx.y * BM, col0 = (long)blockIdx.x * BN;
   if (row0 >= k || col0 >= m) return;
   const long slot = (long)mi * L.P * L.P;
+  // The kept columns are grouped (k_dc_setup): [upper block only | dense | lower block only].  Rows of the upper block see zeros in the third
+  // group, rows of the lower block in the first: a tile that lies inside one block walks only its part of K (dlaed3's two products).
+  const int n1 = L.mid(mi) - b0, k12 = info[mi].k1 + info[mi].k2;
+  int kb = 0, ke = k;
+  if (col0 + BN <= n1) ke = k12;
+  else if (col0 >= n1) kb = (info[mi].k1 / BK) * BK;
   v4d acc[C::MT][C::NTL];
   zero_acc(acc);
   MMajorLoader<C::NTHREADS, BM> la{U + slot, L.P, row0};
   KMajorLoader<C::NTHREADS, BN> lb{G + slot, L.P, col0};
-  mainloop_real<C, false>(acc, la, lb, 0, (k + BK - 1) / BK, smem);
+  mainloop_real<C, false>(acc, la, lb, (long)kb, (ke - kb + BK - 1) / BK, smem);
 #pragma unroll
   for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll

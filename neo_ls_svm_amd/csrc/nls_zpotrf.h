@@ -67,36 +67,50 @@ __global__ void __launch_bounds__(ZP_ROWS) k_zpotrf_panel(double2* __restrict__ 
   }
   __syncthreads();
   int bad = 0;
-  if (tid < 64) {  // wave 0: lane = (row rr, column parity h)
+  if (tid < 64) {  // wave 0: lane = row rr (lanes 32 .. 63 mirror 0 .. 31), the row in registers, the pivot row travels by v_readlane
     const int rr = tid & (NBZ - 1), h = tid >> 5;
+    // No lane predicates inside the factorisation (every r == k, c <= r is a 64-bit scalar mask; the compiler keeps all of them alive and
+    // spills): entries above the diagonal are computed as garbage and never read; the diagonal entry of step k is d / sqrt(d).
+    double ar[NBZ], ai[NBZ];
+#pragma unroll
+    for (int c = 0; c < NBZ; ++c) {
+      ar[c] = Lr[rr][c];
+      ai[c] = Li[rr][c];
+    }
+#pragma unroll
     for (int k = 0; k < NBZ; ++k) {
-      double d = Lr[k][k];
+      double d = potrf::readlane_f64(ar[k], k);
       if (!(d > 0.0) || !isfinite(d)) {  // uniform
         if (bad == 0) bad = k + 1;
         d = 1.0;
       }
-      const double sq = sqrt(d), inv = 1.0 / sq;
-      __builtin_amdgcn_wave_barrier();
-      double lr = 0.0, li = 0.0;
-      if (rr >= k) {
-        lr = rr == k ? sq : Lr[rr][k] * inv;
-        li = rr == k ? 0.0 : Li[rr][k] * inv;
-        if (h == 0) {
-          Lr[rr][k] = lr;
-          Li[rr][k] = li;
-        }
-      }
+      const double inv = 1.0 / sqrt(d);
       if (tid == 0) dv[k] = inv;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      for (int c = k + 1 + h; c <= rr; c += 2) {  // a[rr][c] -= l[rr] conj(l[c])
-        const double cr = Lr[c][k], ci = Li[c][k];
-        Lr[rr][c] -= lr * cr + li * ci;
-        Li[rr][c] = c == rr ? 0.0 : Li[rr][c] - (li * cr - lr * ci);
+      const double lr = ar[k] * inv, li = ai[k] * inv;
+      ar[k] = lr;
+      ai[k] = li;
+#pragma unroll
+      for (int c = k + 1; c < NBZ; ++c) {  // a[rr][c] -= l[rr] conj(l[c])   (meaningful for rr >= c)
+        const double cr = potrf::readlane_f64(lr, c), ci = potrf::readlane_f64(li, c);
+        ar[c] -= lr * cr + li * ci;
+        // two ROUNDED products, not a fused pair: on the diagonal (rr == c) they are the same product and must cancel exactly - the diagonal
+        // of the factor is real (HIP's __dmul_rn is a plain multiplication and gets contracted; the empty asm pins the rounding)
+        double p1 = li * cr, p2 = lr * ci;
+        asm volatile("" : "+v"(p1), "+v"(p2));
+        ai[c] -= p1 - p2;
+        if ((c & 7) == 7) __builtin_amdgcn_sched_barrier(0);  // (the broadcasts are scalar registers: keep their live ranges short)
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_sched_barrier(0);
     }
+    if (h == 0) {
+#pragma unroll
+      for (int c = 0; c < NBZ; ++c) {
+        Lr[rr][c] = ar[c];
+        Li[rr][c] = ai[c];  // (the diagonal's imaginary part stays exactly zero: see above)
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     if (rhs_run) {  // y[k0 .. k0 + w): L11 y = (running right-hand side), forward substitution across the lanes
       double2 acc = (h == 0 && rr < w) ? rhs_run[k0 + rr] : make_double2(0.0, 0.0);
       for (int t = 0; t < NBZ; ++t) {
@@ -278,9 +292,11 @@ __global__ void __launch_bounds__(256) k_ztrsv_block(const double2* __restrict__
       blk[rr][cc] = (rr < w && cc < w && rr >= cc) ? Lc[(long)(k0 + rr) + (long)(k0 + cc) * lda] : make_double2(rr == cc ? 1.0 : 0.0, 0.0);
     }
     __syncthreads();
-    if (tid == 0) {
-      for (int cc = w - 1; cc >= 0; --cc) {
-        double2 acc = y[k0 + cc];
+    if (tid < 64) {  // wave 0: lane cc holds its unknown's right-hand side; 32 steps of backward substitution across the lanes
+      const int cc = tid & (NBZ - 1);
+      double2 acc = make_double2(0.0, 0.0);
+      if (tid < w) {
+        acc = y[k0 + cc];
         if (sums) {
           acc.x -= sums[k0 - K0 + cc].x;
           acc.y -= sums[k0 - K0 + cc].y;
@@ -289,17 +305,21 @@ __global__ void __launch_bounds__(256) k_ztrsv_block(const double2* __restrict__
           acc.x -= part[q][cc].x;
           acc.y -= part[q][cc].y;
         }
-        for (int rr = cc + 1; rr < w; ++rr) {
-          const double2 l = blk[rr][cc], b = sol[rr];
+      }
+      for (int t = NBZ - 1; t >= 0; --t) {
+        if (tid == t) {
+          const double dinv = 1.0 / blk[t][t].x;  // the diagonal of a Cholesky factor is real
+          sol[t] = make_double2(acc.x * dinv, acc.y * dinv);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (tid < t) {  // unknown cc < t: take Lc[t][cc] beta[t] off
+          const double2 l = blk[t][cc], b = sol[t];
           acc.x -= l.x * b.x - l.y * b.y;
           acc.y -= l.x * b.y + l.y * b.x;
         }
-        const double dinv = 1.0 / blk[cc][cc].x;  // the diagonal of a Cholesky factor is real
-        acc.x *= dinv;
-        acc.y *= dinv;
-        sol[cc] = acc;
-        y[k0 + cc] = acc;
       }
+      if (tid < w) y[k0 + cc] = sol[cc];
     }
     __threadfence_block();
     __syncthreads();

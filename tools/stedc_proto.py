@@ -5,10 +5,10 @@ the HIP kernels implement, kept because its index conventions and tolerances are
 
 Cuppen's divide and conquer as LAPACK's dstedc / dlaed0-dlaed4 organise it, with two simplifications that suit a GPU:
   * the tree is level-synchronous: leaves of LEAF rows, then merges of neighbouring blocks of LEAF 2^l rows;
-  * the secular equation is solved by BISECTION in the logarithm of the distance to the nearest pole (one wave per root on the GPU, the poles
-    spread over its lanes): ~60 evaluations of an O(k) sum instead of dlaed4's ~4-6 rational interpolation steps - trivially parallel, no
-    special cases, and it stops exactly where the computed secular function changes sign, i.e. at the residual level dlaed4's stopping
-    criterion asks for.  Orthogonality does not rest on the accuracy of the roots: as in dlaed3, the vector z is recomputed from the
+  * the secular equation is solved for the offset from the nearest pole by dlaed4's iteration ("the middle way": a two-pole rational
+    model of the function), every step that leaves the bracket replaced by a bisection step in the logarithm of the offset (one wave per
+    8 roots on the GPU, the poles spread over its lanes).
+    Orthogonality does not rest on the accuracy of the roots: as in dlaed3, the vector z is recomputed from the
     computed roots (Gu / Eisenstat: the roots are then the EXACT eigenvalues of D + rho zhat zhat^T), and the differences d_i - lam_j are
     formed as (d_i - d_origin) - mu_j, never from the rounded lam_j.
 Deflation is dlaed2's: negligible components of z, and pairs of close poles rotated into one (the rotations are applied to the eigenvector
@@ -53,23 +53,54 @@ def secular_roots(dl, w, rho):
             lo = 0.5 * rho * w2[o] / max(others - 1.0, 1.0)
         lo = min(lo, hi)
         lo = max(lo, np.finfo(float).tiny)
-        llo, lhi = np.log(lo), np.log(hi)
+        # "the middle way" (Li 1994; dlaed4's iteration): with psi = sum over the poles left of the root, phi = over those right of it, the
+        # secular function is modelled by c + a / (dL - t) + b / (dR - t) (dL, dR: the two poles that enclose the root) matching value and
+        # slope of psi and phi separately; the model's root inside the interval is the next iterate.  Every iterate that leaves the bracket is
+        # replaced by a bisection step in the logarithm of the distance to the origin.  tau: signed offset from the origin pole.
+        last = j == k - 1
+        dL = 0.0 if right else -(dl[j + 1] - dl[j])
+        dR = np.inf if last else ((dl[j + 1] - dl[j]) if right else 0.0)
+        tlo, thi = (lo, hi) if right else (-hi, -lo)
+        tau = min(2.0 * lo, hi) if right else -min(2.0 * lo, hi)
+        left_mask = np.arange(k) <= j
         for _ in range(80):
-            lm = 0.5 * (llo + lhi)
-            m = np.exp(lm)
-            if right:
-                f = 1.0 + rho * np.sum(w2 / (delta - m))
-                neg_side = f < 0.0  # the function is negative next to the pole on the left
+            den = delta - tau
+            t = w2 / den
+            psi, dpsi = np.sum(t[left_mask]), np.sum((t / den)[left_mask])
+            phi, dphi = np.sum(t[~left_mask]), np.sum((t / den)[~left_mask])
+            f = 1.0 / rho + psi + phi
+            if f < 0.0:
+                tlo = tau
             else:
-                f = 1.0 + rho * np.sum(w2 / (delta + m))
-                neg_side = f > 0.0  # positive next to the pole on the right: mirror
-            if neg_side:
-                llo = lm
+                thi = tau
+            if abs(f) <= EPS * (8.0 * (phi - psi) + 2.0 / rho + abs(tau) * (dpsi + dphi)):
+                break  # dlaed4's criterion: the function value is at the level of its own rounding error
+            DL = dL - tau
+            if last:
+                c = f - DL * dpsi
+                a = dpsi * DL * DL
+                eta = DL + a / c if c != 0.0 else np.inf  # root of c + a / (DL - eta)
             else:
-                lhi = lm
-            if lhi - llo <= 2.0 * EPS * max(1.0, abs(lm)):
+                DR = dR - tau
+                c = f - DL * dpsi - DR * dphi
+                a, b2 = dpsi * DL * DL, dphi * DR * DR
+                B = c * (DL + DR) + a + b2
+                C = DL * DR * f
+                disc = np.sqrt(abs(B * B - 4.0 * c * C))
+                if c == 0.0:
+                    eta = C / B if B != 0.0 else np.inf
+                elif B <= 0.0:
+                    eta = (B - disc) / (2.0 * c)
+                else:
+                    eta = 2.0 * C / (B + disc)
+            tnew = tau + eta
+            if not (tlo < tnew < thi):
+                tnew = np.sign(tau) * np.sqrt(abs(tlo)) * np.sqrt(abs(thi))
+            stop = abs(tnew - tau) <= 8.0 * EPS * abs(tnew) or abs(thi - tlo) <= 8.0 * EPS * abs(tnew)
+            tau = tnew
+            if stop:
                 break
-        m = np.exp(0.5 * (llo + lhi))
+        m = abs(tau)
         org[j] = o
         mu[j] = m if right else -m
     return org, mu

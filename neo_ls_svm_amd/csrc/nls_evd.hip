@@ -380,6 +380,40 @@ static int apply_q2(nls_ctx* ctx, const T* V2, int n, T* C, long ldc, int ncols)
       // more slabs than CUs: two workgroups per CU (half the LDS each) cover each other's barriers and operand latencies
       // (three for real blocks of 32, whose kernel is light enough in registers: 84 VGPRs)
       const unsigned nwg = (unsigned)((ncols + 15) / 16);
+      if constexpr (sizeof(T) == 8 && B == 32) {
+        // real blocks of 32, NLS_Q2_FORM=wave: one wave per block + a mover wave (k_q2_apply_wave).  Built and measured in round 4: bit-identical
+        // results, 117 against 108 ms at n = 10^4 (profiles/r04_q2_forms.md) - the two-waves-per-block form below stays the default.
+        static const bool wave_form = [] { const char* m = std::getenv("NLS_Q2_FORM"); return m && std::string(m) == "wave"; }();
+        if (wave_form) {
+          static const size_t lds_extra = [] { const char* m = std::getenv("NLS_Q2_LDS_EXTRA"); return m ? (size_t)std::atol(m) : (size_t)0; }();  // experiment: fewer workgroups per CU
+          const size_t lds_wave = Q2Wave::lds_bytes() + lds_extra;
+          NLSCHK(sb_lds_optin(ctx, k_q2_apply_wave, lds_wave, "k_q2_apply_wave"));
+          long long* stamps = nullptr;
+          static const bool want_stamps = [] { const char* m = std::getenv("NLS_Q2_STAMP"); return m && m[0] == '1'; }();
+          if (want_stamps) {
+            NLSCHK(ws_get_t(ctx, "q2.stamps", (size_t)384, &stamps));
+            HIPCHK(ctx, hipMemsetAsync(stamps, 0, 384 * sizeof(long long), ctx->stream));
+          }
+          hipLaunchKernelGGL(k_q2_apply_wave, dim3(nwg), dim3(256), lds_wave, ctx->stream, Pk, doff, ngroups, n, C, ldc, ncols, stamps);
+          HIPCHK(ctx, hipGetLastError());
+          if (want_stamps) {
+            long long h[384];
+            HIPCHK(ctx, hipMemcpyAsync(h, stamps, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            for (int w = 0; w < 3; ++w)
+              for (int q = 0; q < 8; ++q) {
+                const long long* t = h + (w * 8 + q) * 4;
+                std::fprintf(stderr, "[q2 wave stamps] wave %d step %d: barrier wait %.2f us, product 1 %.2f, product 2 %.2f | next step %.2f us later\n", w, 20 + q,
+                             (t[1] - t[0]) * 0.01, (t[2] - t[1]) * 0.01, (t[3] - t[2]) * 0.01, q < 7 ? (t[4] - t[0]) * 0.01 : 0.0);
+              }
+            for (int wsel = 0; wsel < 2; ++wsel)
+              for (int pi = 0; pi + 1 < 120 && h[128 + 128 * wsel + pi + 1] != 0; pi += 8)
+                std::fprintf(stderr, "[q2 wave stamps] workgroup %d pass %d: started %.1f us after pass 0, this pass %.1f us (%d steps)\n", wsel ? 300 : 0, pi,
+                             (h[128 + 128 * wsel + pi] - h[128 + 128 * wsel]) * 0.01, (h[128 + 128 * wsel + pi + 1] - h[128 + 128 * wsel + pi]) * 0.01, 3 * pi + 5);
+          }
+          return NLS_OK;
+        }
+      }
       const unsigned per_cu = std::min<unsigned>((nwg + ctx->cus - 1) / ctx->cus, (sizeof(T) == 8 && B == 32) ? 3u : 2u);
       const size_t budget = per_cu >= 3 ? ((size_t)53 << 10) : per_cu == 2 ? ((size_t)80 << 10) : ((size_t)158 << 10);
       while (G > 1 && L::lds_bytes(G) > budget) --G;

@@ -54,6 +54,12 @@ __device__ __forceinline__ void q2_load_block(const T* V2, long ldv, int n, int 
 //   F2[b][ks][lane]  = (V T)[rho][j],    rho = 16 b + lane % 16,         j = 4 ks + lane / 16      (Z -= (V T) W1; tile b = window rows 16b ..)
 // with V[rho][i] = Vc[i][rho - i] (0 <= rho - i < B).  V T is zero for rho >= j + B: the k-steps ks < ks2_first(b) of tile b are structural zeros
 // (stored, never read).  Real operands are stored in pairs of k-steps so that one 16-byte load feeds two MFMAs.
+// Leading dimension of the LDS ring (doubles per column of the slab) = rows + Q2_RING_PAD.  A lane (column c = lane % 16, row group lane / 16) reads
+// and updates ring[c LDR + row]; hipcc pairs these accesses into ds_read2_b64 / ds_write2_b64, which the LDS serves in groups of 16 consecutive
+// lanes over 32 four-byte banks: the 16 columns of a group must fall on 16 different bank pairs, i.e. LDR must be ODD (round 4: the + 4 of round 3
+// was laid out for ds_read_b64's 64 banks and is a 4-way conflict in the paired form - SQ_LDS_BANK_CONFLICT was a quarter of the kernel time).
+constexpr int Q2_RING_PAD = 1;
+
 template <class T, int B>
 struct Q2P {
   static constexpr bool CX = sizeof(T) == 16;
@@ -68,7 +74,7 @@ struct Q2P {
   // Real blocks of 32 hold too little work for four waves (2 + 4 tiles): the waves form two teams that take two blocks of the same step
   // - they lie two block rows apart, hence independent - side by side, each with its own W1.
   static constexpr int TEAMS = (!CX && B == 32) ? 2 : 1;
-  static size_t lds_bytes(int G) { return sizeof(double) * ((size_t)NP * 16 * ((size_t)2 * G * B + 4) + (size_t)TEAMS * NP * B * 16); }
+  static size_t lds_bytes(int G) { return sizeof(double) * ((size_t)NP * 16 * ((size_t)2 * G * B + Q2_RING_PAD) + (size_t)TEAMS * NP * B * 16); }
 };
 
 // T factor of every block: Tb[block][i + B j] (upper triangular, zeros below; Tb == nullptr: not stored) and the packed operands P
@@ -339,7 +345,7 @@ __global__ void __launch_bounds__(256, 2) k_q2_apply_packed(const T* __restrict_
   constexpr int TPW = NT2 / NW;                    // window tiles per wave
   static_assert(NT1 <= NW && (TPW == 1 || TPW == 2), "tile distribution");
   extern __shared__ __attribute__((aligned(16))) unsigned char q2_smem[];
-  const int R = 2 * G, LDR = R * B + 4;
+  const int R = 2 * G, LDR = R * B + Q2_RING_PAD;
   double* ring = reinterpret_cast<double*>(q2_smem);  // [NP][16][LDR]: ring[c LDR + slot B + r]
   const int ringp = 16 * LDR, wp = B * 16;
   const long c0 = (long)blockIdx.x * 16;
@@ -549,6 +555,204 @@ __global__ void __launch_bounds__(256, 2) k_q2_apply_packed(const T* __restrict_
     }
     __syncthreads();
     for (int tb = lo; tb <= hi; ++tb) store_row(tb);
+  }
+}
+
+
+// ================================================================================================================
+// Real blocks of 32, one WAVE per block plus a MOVER wave (round 4; opt-in with NLS_Q2_FORM=wave: bit-identical to k_q2_apply_packed, measured
+// 8 % SLOWER at n = 10^4 - 117 against 108 ms, profiles/r04_q2_forms.md - and kept as the record of the experiment).  In k_q2_apply_packed two waves share a block and meet at two
+// workgroup barriers per block, and every thread takes part in sliding the ring: a block is only 56 matrix instructions, and on this
+// hardware a wave's vector-memory counter is in order - the first wait for an operand fragment (an L2 hit) also waits for the ring's
+// next block row, which comes from HBM.  Here the two kinds of traffic live in different waves:
+//   * three COMPUTE waves: a pass takes G = 3 groups, wave w owns group S_hi - w and at step u applies block (S_hi - w, u - w) all by
+//     itself: W1 is private to the wave (a wave-level fence orders its LDS write and read), the (V T) fragments of the block are requested
+//     before the first product and the V^H fragments of the next block before the second; their only global accesses are these L2 hits;
+//   * one MOVER wave: while the others work on the window of step u (block rows S_hi + u - 2G + 2 .. S_hi + u + 1) it retires the block row
+//     that left the window after step u - 1 (LDS -> global) and puts the row that step u + 1 needs into the freed slot (requested one
+//     step earlier) - the ring has 2G + 1 slots so that this touches no row of the current window.
+// One workgroup barrier per step.  41.5 KB of LDS, <= 168 registers: three workgroups per CU; the roles rotate with the workgroup index so
+// that co-resident workgroups put their mover on different SIMDs.  Same packed operands (Q2P) and the same order of operations per
+// element as k_q2_apply_packed: bit-identical results.
+// ================================================================================================================
+struct Q2Wave {
+  static constexpr int B = 32, G = 3, R = 2 * G + 1, LDR = R * B + Q2_RING_PAD;
+  static constexpr size_t lds_bytes() { return sizeof(double) * ((size_t)16 * LDR + (size_t)G * B * 16); }
+};
+
+__global__ void __launch_bounds__(256, 3) k_q2_apply_wave(const double* __restrict__ P, const int* __restrict__ blk_off, int ngroups, int n, double* C,
+                                                           long ldc, int ncols, long long* stamps /* diagnostic (nullptr: none) */) {
+  constexpr int B = Q2Wave::B, G = Q2Wave::G, R = Q2Wave::R, LDR = Q2Wave::LDR;
+  using L = Q2P<double, B>;
+  constexpr int KS1 = L::KS1, KS2 = L::KS2, NT1 = L::NT1, NT2 = L::NT2;
+  static_assert(NT1 == 2 && NT2 == 4 && KS1 == 12 && KS2 == 8, "tile counts of a real block of 32");
+  extern __shared__ __attribute__((aligned(16))) unsigned char q2_smem[];
+  double* ring = reinterpret_cast<double*>(q2_smem);  // [16][LDR]: ring[c LDR + slot B + r], slot = block row % R
+  const long c0 = (long)blockIdx.x * 16;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  // 0 .. G - 1: compute wave of group S_hi - role; G: mover.  Workgroups that share a CU come from the same XCD (index = multiples of 8 apart),
+  // consecutive or 32 apart in index / 8 depending on how the dispatcher walks the CUs: rotate with both
+  const int role = (wv + (int)(blockIdx.x >> 3) + (int)(blockIdx.x >> 8)) & 3;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  double* W1 = ring + (size_t)16 * LDR + (size_t)(role < G ? role : 0) * B * 16;  // [B][16], this wave's
+
+  // whole-workgroup transfers of one block row (start and end of a pass)
+  constexpr int EPR = B * 16 / 256;
+  auto load_row_all = [&](int tb) {
+#pragma unroll
+    for (int q = 0; q < EPR; ++q) {
+      const int idx = threadIdx.x + 256 * q, rr = idx % B, cc = idx / B;
+      const long gr = (long)tb * B + 1 + rr;
+      ring[cc * LDR + (tb % R) * B + rr] = (gr < n && c0 + cc < ncols) ? C[gr + (c0 + cc) * ldc] : 0.0;
+    }
+  };
+  auto store_row_all = [&](int tb) {
+#pragma unroll
+    for (int q = 0; q < EPR; ++q) {
+      const int idx = threadIdx.x + 256 * q, rr = idx % B, cc = idx / B;
+      const long gr = (long)tb * B + 1 + rr;
+      if (gr < n && c0 + cc < ncols) C[gr + (c0 + cc) * ldc] = ring[cc * LDR + (tb % R) * B + rr];
+    }
+  };
+  // the mover's transfers: 8 elements per lane
+  constexpr int EPM = B * 16 / 64;
+  auto mover_fetch = [&](double (&pre)[EPM], int tb) {
+#pragma unroll
+    for (int q = 0; q < EPM; ++q) {
+      const int idx = lane + 64 * q, rr = idx % B, cc = idx / B;
+      const long gr = (long)tb * B + 1 + rr;
+      pre[q] = (gr < n && c0 + cc < ncols) ? C[gr + (c0 + cc) * ldc] : 0.0;
+    }
+  };
+  // retire block row `old` (same slot as `tb`; old < first: never loaded, nothing to store) and put the fetched row tb in its place
+  auto mover_swap = [&](const double (&pre)[EPM], int tb, int old, int first) {
+    const int slot = tb % R;
+#pragma unroll
+    for (int q = 0; q < EPM; ++q) {
+      const int idx = lane + 64 * q, rr = idx % B, cc = idx / B;
+      double* cell = ring + cc * LDR + slot * B + rr;
+      const long gr = (long)old * B + 1 + rr;
+      if (old >= first && gr < n && c0 + cc < ncols) C[gr + (c0 + cc) * ldc] = *cell;
+      *cell = pre[q];
+    }
+  };
+
+  Q2Frag<double, KS1> f1[NT1];
+  Q2Frag<double, KS2> f2[NT2];
+  for (int S_hi = ngroups - 1; S_hi >= 0; S_hi -= G) {
+    const int gcount = min(G, S_hi + 1);
+    int u_last = 0;
+    for (int i = 0; i < gcount; ++i) u_last = max(u_last, q2_nblocks(n, B, S_hi - i) - 1 + i);
+    const bool mine = role < gcount;
+    const int S = S_hi - role;
+    const int nb = mine ? q2_nblocks(n, B, S) : 0;
+    const double* Pg = P + (size_t)(mine ? blk_off[S] : 0) * L::PER_BLOCK;
+    if (nb > 0) {  // (never true for the mover: its role is not a group)
+#pragma unroll
+      for (int a = 0; a < NT1; ++a) f1[a].load(Pg, a, lane);
+#pragma unroll
+      for (int b = 0; b < NT2; ++b) f2[b].load(Pg + L::F1, b, lane);
+    }
+    // the ring starts with the block rows first .. S_hi + 1 (what step 0 and the joining groups need); the mover adds one row per step
+    const int first = S_hi - gcount + 1;
+    __syncthreads();  // the previous pass has written its rows back
+    if (stamps != nullptr && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 300)) {
+      const int pi = (ngroups - 1 - S_hi) / G;
+      if (pi < 120) stamps[128 + (blockIdx.x == 0 ? 0 : 128) + pi] = wall_clock64();
+    }
+    for (int tb = first; tb <= S_hi + 1; ++tb) load_row_all(tb);
+    if (role == G) {
+      // ---- mover (its own loop: the fetched row's registers are live across steps only here) ----
+      // three rows in flight (a row comes from HBM: ~ 2 us under load, a step lasts ~ 1.5 us; one row per workgroup in flight would also be
+      // too few bytes in flight chip-wide); the step loop is unrolled by three so that the buffers are named statically
+      double pre[3][EPM];
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        if (j <= u_last) mover_fetch(pre[j], S_hi + 2 + j);
+      for (int u = 0; u <= u_last; u += 3) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          if (u + j <= u_last) {
+            chase::lds_barrier();
+            // row S_hi + u + 2 (first needed at step u + 1) into the slot of row S_hi + u + 2 - R, which left the window after step u - 1
+            mover_swap(pre[j], S_hi + u + j + 2, S_hi + u + j + 2 - R, first);
+            if (u + j + 3 <= u_last) mover_fetch(pre[j], S_hi + u + j + 5);
+          }
+        }
+      }
+    } else {
+      for (int u = 0; u <= u_last; ++u) {
+        chase::lds_barrier();  // the previous step's ring updates and the mover's row are complete
+        const int k = u - role;
+        if (k < 0 || k >= nb) continue;  // wave-uniform
+        const int tb = S + k;
+        const double* Pn = Pg + (size_t)(k + 1) * L::PER_BLOCK;  // the next block of this group
+        const bool more = k + 1 < nb;
+        // the lane index is formed again in every block: as a loop invariant it (and everything derived from it) would be one more set of
+        // registers live across the loop, and the allocator then spills one of them - a scratch reload in the loop makes every wait a full drain
+        int ln;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+        // window rows 0 .. 31: ring slot tb % R, rows 32 .. 63: slot (tb + 1) % R
+        double* zb = ring + (ln & 15) * LDR + (ln >> 4);
+        double* z0 = zb + (tb % R) * B;
+        double* z1 = zb + ((tb + 1) % R) * B - B;
+        double* W1l = W1 + ln;
+        // ---------------- W1 = V^H Z: tile a covers window rows 16 a .. 16 a + 47 (k-step q of the window = k-step q - 4 a of tile a) ----
+        v4d acc1[NT1];
+#pragma unroll
+        for (int a = 0; a < NT1; ++a) acc1[a] = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const double zq = q < 8 ? z0[4 * q] : z1[4 * q];
+          if (q < KS1) acc1[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f1[0].re(q), zq, acc1[0], 0, 0, 0);
+          if (q >= 4) acc1[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f1[1].re(q - 4), zq, acc1[1], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // operand fragments travel one block ahead, each set requested into its registers as soon as the product that read them has been
+        // issued (an L2 hit takes longer than one product lasts)
+        if (more) {
+#pragma unroll
+          for (int a = 0; a < NT1; ++a) f1[a].load(Pn, a, ln);
+        }
+#pragma unroll
+        for (int a = 0; a < NT1; ++a)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) W1l[256 * a + 64 * j] = acc1[a][j];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---------------- Z -= (V T) W1, two tiles at a time ----------------
+        double w1[KS2];
+#pragma unroll
+        for (int ks = 0; ks < KS2; ++ks) w1[ks] = W1l[64 * ks];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          v4d acc2[2];
+          acc2[0] = acc2[1] = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int ks = 0; ks < KS2; ++ks)
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) acc2[bb] = __builtin_amdgcn_mfma_f64_16x16x4f64(f2[2 * h + bb].re(ks), w1[ks], acc2[bb], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (more) {
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) f2[2 * h + bb].load(Pn + L::F1, 2 * h + bb, ln);
+          }
+#pragma unroll
+          for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              double* d = (h == 0 ? z0 : z1) + 16 * (2 * h + bb) + 4 * j;
+              *d = *d - acc2[bb][j];
+            }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    __syncthreads();
+    // what the mover has not retired: the rows of the last window and the row it brought in during the last step
+    for (int tb = max(first, S_hi + u_last + 3 - R); tb <= S_hi + u_last + 2; ++tb) store_row_all(tb);
   }
 }
 

@@ -74,11 +74,14 @@ struct nls_ctx {
   // stage times of the most recent eigendecomposition (nls_evd_stage_ms): events 0..5 bracket the five stages
   hipEvent_t evd_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   int evd_kind = 0, evd_n = 0;
-  // XCD patch shape of k_rotate3 (NLS_ROT_PATCH=RxC; 0x0 = plain order).  Unset: plain on one GPU, a padding-free patch with a communicator
+  // XCD patch shape of k_rotate3 (NLS_ROT_PATCH=RxC; 0x0 = plain order).  Unset: a padding-free 8-row patch, with or without a communicator
   // (launch_rotate in nls_lib.hip has the counters)
   int rot_pr = 0, rot_pc = 0;
   bool rot_patch_set = false;
-  bool gram_contig = true;  // k_gram3: contiguous run of the (split, half tile) list per XCD (NLS_GRAM_ORDER=plain: round-robin)
+  // k_gram3 tile order: 1 = contiguous run of the (split, half tile) list per XCD, 0 = round-robin, -1 = unset (NLS_GRAM_ORDER=contiguous / plain):
+  // contiguous with a communicator (17 % less traffic past L2 for the ranks that share the fabric), plain on one GPU (the contiguous order costs
+  // 1.4 % of the kernel in the counter passes and 3 % - 22 ms - per c3 fit: profiles/r04_pmc_summary.md, profiles/r04_bench_c3.json)
+  int gram_order = -1;
   int k1_stagger_ticks = 0;  // NLS_K1_STAGGER_US: period over which the first-round workgroups of K1 are spread (k1_stagger)
   int rot_kstagger = 0;  // NLS_ROT_KSTAGGER=S: K-walk phase (tr + tc) % S slices per workgroup (see mainloop_3m)
   bool no_resident = false;  // NLS_NO_RESIDENT_PLANES=1: recompute the feature planes per phase even when they would fit

@@ -164,7 +164,7 @@ extern "C" int nls_ctx_create(int device, nls_ctx** out) {
   ctx->cus = prop.multiProcessorCount;
   if (const char* ep = std::getenv("NLS_ROT_PATCH")) ctx->rot_patch_set = std::sscanf(ep, "%dx%d", &ctx->rot_pr, &ctx->rot_pc) == 2;
   if (const char* er = std::getenv("NLS_NO_RESIDENT_PLANES")) ctx->no_resident = er[0] == '1';
-  if (const char* eg = std::getenv("NLS_GRAM_ORDER")) ctx->gram_contig = std::string(eg) != "plain";
+  if (const char* eg = std::getenv("NLS_GRAM_ORDER")) ctx->gram_order = std::string(eg) != "plain" ? 1 : 0;
   if (const char* es = std::getenv("NLS_K1_STAGGER_US")) ctx->k1_stagger_ticks = std::max(0, std::min(100000, (int)(std::atof(es) * 100.0)));
   if (const char* et = std::getenv("NLS_K1_SINCOS")) ctx->k1_table = std::string(et) == "table";
   if (const char* ek = std::getenv("NLS_ROT_KSTAGGER")) ctx->rot_kstagger = std::max(0, std::min(16, std::atoi(ek)));
@@ -515,8 +515,9 @@ static int primal_gram_phase(nls_ctx* ctx, PrimalState& st, double* timings) {
       const long rps = round_up((rows_pad + nsplit - 1) / nsplit, BK);
       const long ns = (rows_pad + rps - 1) / rps;
       const long gblocks = half_tiles * ns;
-      hipLaunchKernelGGL(k_gram3, dim3((unsigned)(ctx->gram_contig ? round_up(gblocks, 8) : gblocks)), dim3(m3::NT3), m3::SMEM3, ctx->stream,
-                         planes_c(st, r0), planes_s(st, r0), mp.Kf, rows_pad, st.ntri, rps, slab, gblocks, ctx->gram_contig ? 1 : 0);
+      const bool contig = ctx->gram_order >= 0 ? ctx->gram_order == 1 : multi_rank(ctx);
+      hipLaunchKernelGGL(k_gram3, dim3((unsigned)(contig ? round_up(gblocks, 8) : gblocks)), dim3(m3::NT3), m3::SMEM3, ctx->stream,
+                         planes_c(st, r0), planes_s(st, r0), mp.Kf, rows_pad, st.ntri, rps, slab, gblocks, contig ? 1 : 0);
       HIPCHK(ctx, hipGetLastError());
       hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)((st.tile_elems + 255) / 256)), dim3(256), 0, ctx->stream, slab, (int)ns,
                          (long)st.tile_elems, st.gacc);
@@ -912,8 +913,9 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
       HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
       HIPCHK(ctx, hipMemcpyAsync(Lc, Cn, sizeof(double2) * (size_t)D1 * D1, hipMemcpyDeviceToDevice, ctx->stream));
       BLASCHK(ctx, rocblas_set_stream(ctx->blas, ctx->stream));
-      BLASCHK(ctx, rocsolver_zpotrf(ctx->blas, rocblas_fill_lower, D1, reinterpret_cast<rocblas_double_complex*>(Lc), D1, dinfo));
-      NLSCHK(check_info(ctx, dinfo, "rocsolver_zpotrf(complexity matrix)"));
+      // (the library's own factorisation: rocsolver_zpotrf is not safe when two contexts fit at the same time, profiles/r04_two_contexts.md)
+      NLSCHK(zpotrf_lower(ctx, ctx->stream, ctx->blas, Lc, D1, D1, reinterpret_cast<int*>(dinfo), 0));
+      NLSCHK(check_info(ctx, dinfo, "Cholesky factorisation of the complexity matrix"));
       const rocblas_double_complex one(1.0, 0.0);
       auto* zL = reinterpret_cast<const rocblas_double_complex*>(Lc);
       auto* zA = reinterpret_cast<rocblas_double_complex*>(Qcm);

@@ -594,7 +594,6 @@ __global__ void __launch_bounds__(256, 3) k_q2_apply_wave(const double* __restri
   // 0 .. G - 1: compute wave of group S_hi - role; G: mover.  Workgroups that share a CU come from the same XCD (index = multiples of 8 apart),
   // consecutive or 32 apart in index / 8 depending on how the dispatcher walks the CUs: rotate with both
   const int role = (wv + (int)(blockIdx.x >> 3) + (int)(blockIdx.x >> 8)) & 3;
-  const int l15 = lane & 15, l4 = lane >> 4;
   double* W1 = ring + (size_t)16 * LDR + (size_t)(role < G ? role : 0) * B * 16;  // [B][16], this wave's
 
   // whole-workgroup transfers of one block row (start and end of a pass)

@@ -254,12 +254,13 @@ def run_dual(args, cfg):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     n, d, G = cfg["n"], cfg["d"], cfg["G"]
-    ctx = hp.Context(local_rank)
+    dev = int(os.environ.get("NLS_BENCH_DEVICE", local_rank))  # (tests: every rank on one device, through the stand-in communicator)
+    ctx = hp.Context(dev)
     cctx = None
     if world > 1:
         from neo_ls_svm_amd.distributed import init_from_env
 
-        cctx = hp.Context(local_rank)
+        cctx = hp.Context(dev)
         init_from_env(cctx)
     X, y01 = synth_clf(n, d)
     y = np.where(y01 == 1.0, 1.0, -1.0)
@@ -434,13 +435,14 @@ def main():
 
     n, d, D, G = cfg["n"], cfg["d"], cfg["D"], cfg["G"]
     grid_mode = "sigmas" in cfg
-    ctx = hp.Context(local_rank)
+    dev = int(os.environ.get("NLS_BENCH_DEVICE", local_rank))  # (tests: every rank on one device, through the stand-in communicator)
+    ctx = hp.Context(dev)
     # Row sharding: the fitting context itself joins the communicator.  Sigma sharding (c5): every rank fits all rows on
     # its own, so the communicator lives on a second context that only serves the barrier / the merge of the small tables.
     use_comm = world > 1 or os.environ.get("NLS_BENCH_FORCE_COMM") == "1"
     cctx = None
     if use_comm:
-        cctx = hp.Context(local_rank) if grid_mode else ctx
+        cctx = hp.Context(dev) if grid_mode else ctx
         init_from_env(cctx)
 
     lo, hi = (0, n) if grid_mode else ((n * rank) // world, (n * (rank + 1)) // world)

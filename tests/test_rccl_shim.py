@@ -7,6 +7,7 @@ the library finds it through ``NLS_RCCL_LIB``.  The shim itself is checked on th
 
 from __future__ import annotations
 
+import json
 import os
 import socket
 import subprocess
@@ -104,3 +105,43 @@ def test_native_communicator_failure_inside_the_group():
     """... and inside the grouped all-gather (broadcasts 4.. of a fit: flag, lam, eigenvectors come first): the group is closed,
     the error surfaces, nobody hangs."""
     _launch_native("gpu_rccl_fail", 2, {"NLS_SHIM_FAIL_BROADCAST": "5"}, timeout=300)
+
+
+def _bench_line(out):
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out[-3000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("launcher", ["self", "torchrun"])
+def test_bench_two_ranks_one_gpu(launcher):
+    """``bench.py --gpus 2`` end to end - rendezvous, row shards, the barrier / max-over-ranks timing through the native communicator, rank 0's
+    JSON line - with both ranks on GPU 0 and the stand-in communicator: what the driver's scaling run executes, minus the second device.
+    Launched by the script itself and by ``python -m torch.distributed.run`` (only its environment is used)."""
+    lib = build_shim(host_only=False)
+    root = HERE.parent
+    with tempfile.TemporaryDirectory() as td:
+        env = dict(os.environ, NLS_RCCL_LIB=str(lib), NLS_RENDEZVOUS_DIR=td, NLS_SHIM_SLOT_BYTES=str(1 << 20), NLS_SHIM_TIMEOUT_S="300",
+                   NLS_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4", OPENBLAS_NUM_THREADS="4")  # fmt: skip
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        args = ["bench.py", "--gpus", "2", "--config", "c2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-end-to-end"]
+        if launcher == "self":
+            cmd = [sys.executable] + args
+        else:
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                   "--master-port", str(_free_port())] + args  # fmt: skip
+        p = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+        d = _bench_line(p.stdout)
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] in ("strong", "weak") and d["value"] > 0
+    one = subprocess.run([sys.executable] + args[:2] + ["1"] + args[3:], cwd=root, env={k: v for k, v in env.items() if k != "NLS_RCCL_LIB"},
+                         capture_output=True, text=True, timeout=900)  # fmt: skip
+    assert one.returncode == 0, (one.stdout + one.stderr)[-3000:]
+    d1 = _bench_line(one.stdout)
+    # the same fit either way: the selected gamma and the LOO score agree (two ranks on ONE device are slower, not different)
+    assert d["config"]["workload"] == d1["config"]["workload"]
+    assert d["config"]["gamma_index"] == d1["config"]["gamma_index"]
+    assert d["config"]["loo_score"] == pytest.approx(d1["config"]["loo_score"], rel=1e-9)
+    assert d["config"]["rows_per_gpu"] * 2 == d1["config"]["rows_per_gpu"] and "row-shard x2" in d["config"]["parallelism"]

@@ -301,7 +301,11 @@ extern "C" int nls_dual_fit(nls_ctx* ctx, const nls_dual_fit_args* a) {
   }
   std::vector<double> herrs((size_t)3 * Gp), hobj((size_t)G);
   HIPCHK(ctx, hipMemcpyAsync(herrs.data(), errs, sizeof(double) * 3 * Gp, hipMemcpyDeviceToHost, ctx->stream));
-  if (a->L) pinL.pin(a->L, sizeof(double) * (size_t)n * n);  // the host would wait here anyway: page-lock the L_ output behind the EVD / sweep
+  // NLS_PIN_OUTPUT=1: page-lock the L_ output here (the host would wait anyway) and send the finished block columns with asynchronous copies
+  // (round 3).  Default since round 4: no registration - a helper thread sends them into the pageable buffer while the factorisation runs
+  // (registering and releasing 800 MB cost ~ 30 ms of the call that nothing hid; profiles/r04_dual_L_download.log).
+  static const bool pin_on = [] { const char* m = std::getenv("NLS_PIN_OUTPUT"); return m && m[0] == '1'; }();
+  if (a->L && pin_on) pinL.pin(a->L, sizeof(double) * (size_t)n * n);
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   for (int g = 0; g < G; ++g) hobj[g] = is_clf ? (herrs[Gp + g] + herrs[2 * Gp + g]) + herrs[g] : herrs[g];  // :296-302
   int opt = a->gamma_index_in;
@@ -343,6 +347,16 @@ extern "C" int nls_dual_fit(nls_ctx* ctx, const nls_dual_fit_args* a) {
       if (s) (void)hipStreamSynchronize(s);
     }
   } copy_join;
+  struct HelperJoin {  // the helper threads that download L_ into pageable memory: never outlive the call
+    enum { LANES = 2 };  // (four lanes: no further gain)
+    std::thread t[LANES];
+    int rc[LANES] = {NLS_OK, NLS_OK};
+    void join() {
+      for (auto& th : t)
+        if (th.joinable()) th.join();
+    }
+    ~HelperJoin() { join(); }
+  } dl;
   // alpha(gamma*) = M^-1 y = sn W (gamma* + Lam)^-1 W^T sn y is the selected column of AG, which the sweep has already formed for the whole
   // grid (_neo_ls_svm.py:313-316 solve it with the Cholesky factor: two n x n triangular solves, 10.6 ms at n = 10^4).  The factorisation
   // itself only produces the L_ output and is skipped when the caller does not ask for it.
@@ -357,12 +371,27 @@ extern "C" int nls_dual_fit(nls_ctx* ctx, const nls_dual_fit_args* a) {
     // (leading dimension n_pad: the rank-128 update reads whole 128-row blocks.)  Into page-locked memory the finished block columns of 512
     // travel on the copy stream while the following ones are factored; pageable outputs are downloaded afterwards in one piece.
     pipelined_L = pinL.p != nullptr;
+    NLSCHK(ensure_copy_stream(ctx, (int)((n + 511) / 512)));
+    copy_join.s = ctx->copy_stream;
+    NLSCHK(potrf_lower_real(ctx, M2, (int)n, n_pad, dinfo, 512));
     if (pipelined_L) {
-      NLSCHK(ensure_copy_stream(ctx, (int)((n + 511) / 512)));
-      copy_join.s = ctx->copy_stream;
+      NLSCHK(download_block_columns(ctx, a->L, M2, (int)n, n_pad, sizeof(double), 512, false));
+    } else {
+      // pageable output: every copy blocks its caller until the block column has arrived (and touches the pages of a fresh buffer for the
+      // first time) - in two threads of their own (even and odd block columns, a stream each), beside the factorisation:
+      // 514 -> 496 ms per c4 fit against the page-locked path (profiles/r04_dual_L_download.log)
+      void* hostL = a->L;
+      for (int lane = 0; lane < HelperJoin::LANES; ++lane)
+        dl.t[lane] = std::thread([ctx, hostL, M2, n, n_pad, lane, &dl] {
+          hipStream_t cs = lane == 0 ? ctx->copy_stream : ctx->copy_lane[lane - 1];
+          if (hipSetDevice(ctx->device) != hipSuccess) {
+            dl.rc[lane] = NLS_ERR_HIP;
+            return;
+          }
+          dl.rc[lane] = download_block_columns(ctx, hostL, M2, (int)n, n_pad, sizeof(double), 512, false, lane, HelperJoin::LANES, cs);
+          if (dl.rc[lane] == NLS_OK && hipStreamSynchronize(cs) != hipSuccess) dl.rc[lane] = NLS_ERR_HIP;
+        });
     }
-    NLSCHK(potrf_lower_real(ctx, M2, (int)n, n_pad, dinfo, pipelined_L ? 512 : 0));
-    if (pipelined_L) NLSCHK(download_block_columns(ctx, a->L, M2, (int)n, n_pad, sizeof(double), 512, false));
     // alpha = cho_solve(L_, y) (_neo_ls_svm.py:314: "resolve the linear system for better accuracy"): two triangular solves with one right-hand
     // side against the factor just formed, so that the returned pair satisfies alpha == cho_solve(L_, y) to rounding.  (The selected column of
     // the sweep's table above is the same vector from the eigendecomposition; it stays the answer when no factor is asked for.)
@@ -398,7 +427,9 @@ extern "C" int nls_dual_fit(nls_ctx* ctx, const nls_dual_fit_args* a) {
     NLSCHK(d2h(a->loo_std, sig, sizeof(double) * n));
     NLSCHK(d2h(a->residuals, res, sizeof(double) * n));
     // Column-major lower Cholesky factor == row-major upper factor U (M2 = U^T U): scipy's lower=False layout.
-    if (a->L && !pipelined_L) NLSCHK(download_factor(ctx, a->L, M2, (int)n, n_pad, sizeof(double), ctx->stream, false));
+    dl.join();
+    for (int lane = 0; lane < HelperJoin::LANES; ++lane)
+      if (dl.rc[lane] != NLS_OK) return dl.rc[lane] == NLS_ERR_HIP ? fail(ctx, NLS_ERR_HIP, "download of the Cholesky factor failed") : dl.rc[lane];
     if (pipelined_L) HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));
   }
   NLSCHK(spans_collect(ctx, tm));

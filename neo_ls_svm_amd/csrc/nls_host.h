@@ -14,6 +14,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/neolssvm_hip.h"
@@ -55,6 +56,7 @@ struct nls_ctx {
   hipStream_t stream2 = nullptr;   // side stream (created on first use): the Cholesky factor L_ and its download run beside the residual pass
   rocblas_handle blas2 = nullptr;
   hipStream_t copy_stream = nullptr;  // block columns of a Cholesky factor travel to the host on it while the rest is still being factored
+  hipStream_t copy_lane[3] = {nullptr, nullptr, nullptr};  // further lanes of the pageable download (nls_dual.hip: helper threads)
   std::vector<hipEvent_t> blk_ev;     // one event per finished block column
   hipEvent_t side_ev[4] = {nullptr, nullptr, nullptr, nullptr};  // fork, potrf done, download done (timing of the side stream)
   std::string err;
@@ -355,6 +357,8 @@ static int download_factor(nls_ctx* ctx, void* host, const void* dev, int n, lon
 // AFTER everything else has been enqueued (the thread would wait for the result anyway).
 static int ensure_copy_stream(nls_ctx* ctx, int nblk) {
   if (!ctx->copy_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+  for (auto& ls : ctx->copy_lane)
+    if (!ls) HIPCHK(ctx, hipStreamCreateWithFlags(&ls, hipStreamNonBlocking));
   while ((int)ctx->blk_ev.size() < nblk) {
     hipEvent_t e = nullptr;
     HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -368,19 +372,22 @@ __global__ void k_conj_block(double2* A, long ld, long r0, long c0, long rows, l
   double2* p = A + (r0 + idx % rows) + (c0 + idx / rows) * ld;
   p->y = -p->y;
 }
-static int download_block_columns(nls_ctx* ctx, void* host, void* dev, int n, long ld_dev, size_t elem_bytes, int nbk, bool conj) {
+// (b_first, b_step, stream: a lane of the block columns on a stream of its own - the pageable download of nls_dual.hip runs two of them.)
+static int download_block_columns(nls_ctx* ctx, void* host, void* dev, int n, long ld_dev, size_t elem_bytes, int nbk, bool conj, int b_first = 0,
+                                  int b_step = 1, hipStream_t lane = nullptr) {
   const int nblk = (n + nbk - 1) / nbk;
   const size_t spitch = (size_t)ld_dev * elem_bytes, dpitch = (size_t)n * elem_bytes;
-  for (int b = 0; b < nblk; ++b) {
+  hipStream_t cs = lane ? lane : ctx->copy_stream;
+  for (int b = b_first; b < nblk; b += b_step) {
     const long k0 = (long)b * nbk, w = std::min<long>(nbk, n - k0), rows = n - k0;
-    HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->blk_ev[b], 0));
+    HIPCHK(ctx, hipStreamWaitEvent(cs, ctx->blk_ev[b], 0));
     if (conj) {
-      hipLaunchKernelGGL(k_conj_block, dim3((unsigned)((rows * w + 255) / 256)), dim3(256), 0, ctx->copy_stream, static_cast<double2*>(dev), ld_dev, k0, k0, rows, w);
+      hipLaunchKernelGGL(k_conj_block, dim3((unsigned)((rows * w + 255) / 256)), dim3(256), 0, cs, static_cast<double2*>(dev), ld_dev, k0, k0, rows, w);
       HIPCHK(ctx, hipGetLastError());
     }
     HIPCHK(ctx, hipMemcpy2DAsync(static_cast<char*>(host) + ((size_t)k0 + (size_t)k0 * n) * elem_bytes, dpitch,
                                  static_cast<const char*>(dev) + ((size_t)k0 + (size_t)k0 * ld_dev) * elem_bytes, spitch, (size_t)rows * elem_bytes, (size_t)w,
-                                 hipMemcpyDeviceToHost, ctx->copy_stream));
+                                 hipMemcpyDeviceToHost, cs));
   }
   return NLS_OK;
 }

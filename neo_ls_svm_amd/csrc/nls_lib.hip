@@ -243,6 +243,8 @@ extern "C" void nls_ctx_destroy(nls_ctx* ctx) {
   for (auto e : ctx->blk_ev)
     if (e) (void)hipEventDestroy(e);
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+  for (auto ls : ctx->copy_lane)
+    if (ls) (void)hipStreamDestroy(ls);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }

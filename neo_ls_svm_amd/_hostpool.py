@@ -1,0 +1,79 @@
+"""Host buffers for the LARGE outputs of a fit (the Cholesky factor ``L_``: 268 MB at D = 4096, 800 MB at n = 10^4 in the dual path).
+
+A fresh ``np.zeros`` of that size costs the process ~2 10^5 first-touch page faults when the download arrives and a ``munmap`` of as many
+pages when the previous result is dropped - 35-40 ms per dual fit at n = 10^4, more than the factorisation itself.  Buffers of at least
+``MIN_BYTES`` therefore come from a small pool of anonymous mappings: the array handed out keeps a *lease* object alive as its base; when the
+last array (or view) on it is garbage collected the mapping goes back to the pool - still mapped, pages resident - for the next fit.
+Smaller outputs are plain ``np.zeros``.
+
+Only the triangle the library defines is meaningful in such an array (scipy's ``cho_factor`` contract: the other triangle "contains random
+data"); a recycled buffer holds a previous factor's entries there, a fresh one zeros.  ``release()`` unmaps what the pool holds
+(``Context.release_workspace`` calls it).
+"""
+
+from __future__ import annotations
+
+import ctypes
+import mmap
+import threading
+
+import numpy as np
+
+MIN_BYTES = 64 << 20
+MAX_POOLED_PER_SIZE = 2
+MAX_POOLED_BYTES = 4 << 30
+
+_lock = threading.Lock()
+_free: dict[int, list[mmap.mmap]] = {}
+
+
+def _pooled_bytes() -> int:
+    return sum(size * len(v) for size, v in _free.items())
+
+
+class _Lease:
+    """Owner of one mapping while arrays on it are alive (``ndarray.base``)."""
+
+    __slots__ = ("_mm", "_view", "__array_interface__")
+
+    def __init__(self, mm: mmap.mmap, shape, dtype):
+        self._mm = mm
+        self._view = ctypes.c_char.from_buffer(mm)  # (pins the mapping: it cannot be resized or closed under the arrays)
+        self.__array_interface__ = {"data": (ctypes.addressof(self._view), False), "shape": tuple(shape), "typestr": np.dtype(dtype).str, "version": 3}
+
+    def __del__(self):
+        mm, self._view = self._mm, None
+        if mm is None:
+            return
+        try:
+            with _lock:
+                size = len(mm)
+                lst = _free.setdefault(size, [])
+                if len(lst) < MAX_POOLED_PER_SIZE and _pooled_bytes() + size <= MAX_POOLED_BYTES:
+                    lst.append(mm)
+                    return
+            mm.close()
+        except Exception:  # interpreter shutdown: the module globals may be gone; the mapping dies with the process
+            pass
+
+
+def factor_output(shape, dtype) -> np.ndarray:
+    """A writable C-contiguous array for a factor output: pooled mapping when it is large, ``np.zeros`` otherwise."""
+    nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    if nbytes < MIN_BYTES:
+        return np.zeros(shape, dtype=dtype)
+    with _lock:
+        lst = _free.get(nbytes)
+        mm = lst.pop() if lst else None
+    if mm is None:
+        mm = mmap.mmap(-1, nbytes)  # anonymous, zero-filled on first touch
+    return np.asarray(_Lease(mm, shape, dtype))
+
+
+def release() -> None:
+    """Unmap every pooled buffer (arrays still alive keep theirs)."""
+    with _lock:
+        held = [mm for lst in _free.values() for mm in lst]
+        _free.clear()
+    for mm in held:
+        mm.close()

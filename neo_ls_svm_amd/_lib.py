@@ -351,6 +351,9 @@ class Context:
         only grows between calls (a c3-size fit leaves ~100 GB allocated for the next one); this is the trim."""
         held = C.c_size_t()
         self._check(self.lib.nls_ws_release(self.handle, int(min_bytes), C.byref(held)))
+        from . import _hostpool  # the pooled host buffers of large factor outputs go with it
+
+        _hostpool.release()
         return int(held.value)
 
     # ---- native RCCL communicator (one process per GPU; no torch) -----------------------------------

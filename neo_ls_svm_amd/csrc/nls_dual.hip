@@ -15,7 +15,11 @@ constexpr size_t SMEM_REAL_D = 2 * 2 * TILE_DOUBLES * sizeof(double);
 
 // A = L L^T in place (lower, column-major): nls_potrf.h; NLS_POTRF=rocsolver takes rocsolver_dpotrf instead (diagnostic).  info: device word,
 // 0 or the 1-based index of the first non-positive pivot.
-static int potrf_lower_real(nls_ctx* ctx, double* A, int n, long lda, rocblas_int* dinfo, int event_cols = 0) {
+// rhs_run (n doubles, device; may be NULL): on entry the right-hand side y of alpha = cho_solve(L, y); on return L^-1 y - the forward substitution
+// carried through the factorisation (*carried = true; false on the rocSOLVER path, where the caller solves both halves afterwards).
+static int potrf_lower_real(nls_ctx* ctx, double* A, int n, long lda, rocblas_int* dinfo, int event_cols = 0, double* rhs_run = nullptr,
+                            bool* carried = nullptr) {
+  if (carried) *carried = false;
   using namespace potrf;
   const char* m = std::getenv("NLS_POTRF");
   if (m && std::string(m) == "rocsolver") {
@@ -33,38 +37,65 @@ static int potrf_lower_real(nls_ctx* ctx, double* A, int n, long lda, rocblas_in
     return fail(ctx, NLS_ERR_HIP, "Cholesky kernels: %zu / %zu bytes of LDS refused", LEAF_LDS, SMEM_REAL_D);
   if (lda % 2 != 0 || lda < (long)((n + BM - 1) / BM) * BM)
     return fail(ctx, NLS_ERR_ARG, "potrf_lower_real: the leading dimension (%ld) must be n rounded up to %d", lda, BM);
-  for (int k0 = 0; k0 < n; k0 += NB) {
+  // Outer blocks of two panels (256 columns): panel a updates only the strip of panel b's columns, and the trailing matrix beyond the outer block
+  // is updated once with both panels (K = 256): one pass over the trailing triangle per 256 columns instead of per 128.
+  static_assert(NB == BM, "a panel is one tile column");
+  double* xsol = nullptr;  // the solved unknowns; the running right-hand side stays in rhs_run until its rows are solved
+  if (rhs_run) NLSCHK(ws_get_t(ctx, "potrf.xsol", (size_t)n, &xsol));
+  auto panel = [&](int k0) -> int {  // leaf + rows below
     const int w = std::min(NB, n - k0), mrows = n - k0 - w;
     double* D = A + (long)k0 + (long)k0 * lda;
-    hipLaunchKernelGGL(k_potrf_leaf, dim3(1), dim3(256), LEAF_LDS, ctx->stream, D, lda, w, k0, Sinv, reinterpret_cast<int*>(dinfo));
-    if (mrows > 0) {
-      double* P = D + w;  // A21: rows below the diagonal block
-      hipLaunchKernelGGL(k_potrf_panel, dim3((unsigned)((mrows + 63) / 64)), dim3(256), 0, ctx->stream, P, lda, mrows, w, D, Sinv);
-      const int nt = (mrows + BM - 1) / BM;
-      hipLaunchKernelGGL(k_potrf_syrk, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(Cfg4::NTHREADS), SMEM_REAL_D, ctx->stream, D + w + (long)w * lda, lda, mrows, P,
-                         lda);
-    }
+    hipLaunchKernelGGL(k_potrf_leaf, dim3(1), dim3(256), LEAF_LDS, ctx->stream, D, lda, w, k0, Sinv, reinterpret_cast<int*>(dinfo), (const double*)rhs_run, xsol);
+    if (mrows > 0)
+      hipLaunchKernelGGL(k_potrf_panel, dim3((unsigned)((mrows + 63) / 64)), dim3(256), 0, ctx->stream, D + w, lda, mrows, w, D, Sinv,
+                         rhs_run ? (const double*)(xsol + k0) : (const double*)nullptr, rhs_run ? rhs_run + k0 + w : (double*)nullptr);
     HIPCHK(ctx, hipGetLastError());
-    // event_cols > 0 (a multiple of NB): block column b of that width is final and no longer read once its last panel's update has run
-    if (event_cols > 0 && ((k0 + NB) % event_cols == 0 || k0 + NB >= n)) HIPCHK(ctx, hipEventRecord(ctx->blk_ev[k0 / event_cols], ctx->stream));
+    return NLS_OK;
+  };
+  const int NBO = 2 * NB;
+  for (int K0 = 0; K0 < n; K0 += NBO) {
+    NLSCHK(panel(K0));
+    const int ma = n - K0 - NB;  // rows (and columns) below panel a
+    if (ma > 0) {
+      double* Pa = A + (long)(K0 + NB) + (long)K0 * lda;  // panel a's rows below its diagonal block
+      const int nta = (ma + BM - 1) / BM;
+      // the strip of the next 128 columns: tiles (R, 0)
+      hipLaunchKernelGGL(k_potrf_syrk, dim3((unsigned)nta), dim3(Cfg4::NTHREADS), SMEM_REAL_D, ctx->stream, A + (long)(K0 + NB) + (long)(K0 + NB) * lda, lda, ma, Pa,
+                         lda, NB / BK, 1);
+      NLSCHK(panel(K0 + NB));
+      const int mb = n - K0 - NBO;  // rows below the outer block
+      if (mb > 0) {
+        const int ntb = (mb + BM - 1) / BM;
+        hipLaunchKernelGGL(k_potrf_syrk, dim3((unsigned)(ntb * (ntb + 1) / 2)), dim3(Cfg4::NTHREADS), SMEM_REAL_D, ctx->stream,
+                           A + (long)(K0 + NBO) + (long)(K0 + NBO) * lda, lda, mb, A + (long)(K0 + NBO) + (long)K0 * lda, lda, NBO / BK, ntb);
+      }
+      HIPCHK(ctx, hipGetLastError());
+    }
+    // event_cols > 0 (a multiple of 256): block column b of that width is final and no longer read once its last outer block's update has run
+    if (event_cols > 0 && ((K0 + NBO) % event_cols == 0 || K0 + NBO >= n)) HIPCHK(ctx, hipEventRecord(ctx->blk_ev[K0 / event_cols], ctx->stream));
+  }
+  if (rhs_run) {
+    HIPCHK(ctx, hipMemcpyAsync(rhs_run, xsol, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
+    if (carried) *carried = true;
   }
   return NLS_OK;
 }
 
 // x <- L^-T L^-1 x in place (nls_trsv.h): forwards then backwards in outer blocks of 256 unknowns.  NLS_TRSV=rocblas: two rocblas_dtrsv calls.
-static int cho_solve_real(nls_ctx* ctx, const double* L, int n, long ldl, double* x) {
+static int cho_solve_real(nls_ctx* ctx, const double* L, int n, long ldl, double* x, bool forward_done = false) {
   using namespace trsv;
   const char* mode = std::getenv("NLS_TRSV");
   if (mode && std::string(mode) == "rocblas") {
     BLASCHK(ctx, rocblas_set_stream(ctx->blas, ctx->stream));
-    BLASCHK(ctx, rocblas_dtrsv(ctx->blas, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, (rocblas_int)n, L, (rocblas_int)ldl, x, 1));
+    if (!forward_done)
+      BLASCHK(ctx, rocblas_dtrsv(ctx->blas, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, (rocblas_int)n, L, (rocblas_int)ldl, x, 1));
     BLASCHK(ctx, rocblas_dtrsv(ctx->blas, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, (rocblas_int)n, L, (rocblas_int)ldl, x, 1));
     return NLS_OK;
   }
   double* sums = nullptr;
   NLSCHK(ws_get_t(ctx, "trsv.sums", (size_t)OB, &sums));
   const int nblk = (n + OB - 1) / OB;
-  for (int b = 0; b < nblk; ++b) {
+  for (int b = 0; b < nblk && !forward_done; ++b) {
     const int K0 = b * OB, W = std::min(OB, n - K0), below = n - K0 - W;
     hipLaunchKernelGGL(k_trsv_fwd_block, dim3(1), dim3(256), 0, ctx->stream, L, ldl, K0, W, x);
     if (below > 0) hipLaunchKernelGGL(k_trsv_fwd_update, dim3((unsigned)((below + 255) / 256)), dim3(256), 0, ctx->stream, L, ldl, n, K0, W, x);
@@ -164,6 +195,8 @@ extern "C" int nls_dual_fit(nls_ctx* ctx, const nls_dual_fit_args* a) {
   const int G = a->G, is_clf = a->is_classifier ? 1 : 0;
   const long n_pad = round_up(n, BM), r_pad = round_up(r, BK);
   const int Gp = (int)round_up(G, BN);
+  Prefault prefault;  // the pages of the L_ output are faulted in behind the eigendecomposition (joined before the download starts)
+  if (a->L) prefault.start(a->L, sizeof(double) * (size_t)n * n);
   const double *dX = nullptr, *dy = nullptr, *ds_in = nullptr;
   {
     SpanGuard g(ctx, NLS_T_UPLOAD);
@@ -373,10 +406,14 @@ extern "C" int nls_dual_fit(nls_ctx* ctx, const nls_dual_fit_args* a) {
     pipelined_L = pinL.p != nullptr;
     NLSCHK(ensure_copy_stream(ctx, (int)((n + 511) / 512)));
     copy_join.s = ctx->copy_stream;
-    NLSCHK(potrf_lower_real(ctx, M2, (int)n, n_pad, dinfo, 512));
+    // alpha = cho_solve(L_, y): the forward substitution travels with the factorisation (alpha holds the running right-hand side)
+    HIPCHK(ctx, hipMemcpyAsync(alpha, dy, sizeof(double) * n, hipMemcpyDeviceToDevice, ctx->stream));
+    bool carried = false;
+    NLSCHK(potrf_lower_real(ctx, M2, (int)n, n_pad, dinfo, 512, alpha, &carried));
     if (pipelined_L) {
       NLSCHK(download_block_columns(ctx, a->L, M2, (int)n, n_pad, sizeof(double), 512, false));
     } else {
+      prefault.join();
       // pageable output: every copy blocks its caller until the block column has arrived (and touches the pages of a fresh buffer for the
       // first time) - in two threads of their own (even and odd block columns, a stream each), beside the factorisation:
       // 514 -> 496 ms per c4 fit against the page-locked path (profiles/r04_dual_L_download.log)
@@ -395,8 +432,7 @@ extern "C" int nls_dual_fit(nls_ctx* ctx, const nls_dual_fit_args* a) {
     // alpha = cho_solve(L_, y) (_neo_ls_svm.py:314: "resolve the linear system for better accuracy"): two triangular solves with one right-hand
     // side against the factor just formed, so that the returned pair satisfies alpha == cho_solve(L_, y) to rounding.  (The selected column of
     // the sweep's table above is the same vector from the eigendecomposition; it stays the answer when no factor is asked for.)
-    HIPCHK(ctx, hipMemcpyAsync(alpha, dy, sizeof(double) * n, hipMemcpyDeviceToDevice, ctx->stream));
-    NLSCHK(cho_solve_real(ctx, M2, (int)n, n_pad, alpha));
+    NLSCHK(cho_solve_real(ctx, M2, (int)n, n_pad, alpha, carried));
     NLSCHK(check_info(ctx, dinfo, "Cholesky factorisation (potrf)"));
   } else {
     // no factorisation, hence no pivot test: gamma* diag(sn^-2) + K is positive definite iff gamma* + lam_min(sn K sn) > 0

@@ -313,6 +313,34 @@ struct HostPin {
   }
 };
 
+// Touches every page of a caller's pageable OUTPUT buffer from helper threads, early in a call, while the host would otherwise wait for the GPU:
+// a fresh 800 MB array costs ~ 10^5 first-touch page faults (the kernel zeroes each page), which would otherwise land in the download at the end
+// of the call.  Contents are preserved (each page's first byte is read and written back).  Device and page-locked pointers are left alone.
+struct Prefault {
+  std::thread t[4];
+  void start(void* ptr, size_t bytes) {
+    if (!ptr || bytes < ((size_t)64 << 20)) return;
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, ptr) == hipSuccess && attr.type != hipMemoryTypeUnregistered) return;
+    (void)hipGetLastError();
+    constexpr size_t PAGE = 4096;
+    const size_t per = (bytes / 4 + PAGE - 1) / PAGE * PAGE;
+    for (int i = 0; i < 4; ++i) {
+      const size_t lo = std::min(bytes, (size_t)i * per), hi = std::min(bytes, lo + per);
+      if (lo >= hi) break;
+      volatile char* p = static_cast<volatile char*>(ptr);
+      t[i] = std::thread([p, lo, hi] {
+        for (size_t off = lo; off < hi; off += PAGE) p[off] = p[off];
+      });
+    }
+  }
+  void join() {
+    for (auto& th : t)
+      if (th.joinable()) th.join();
+  }
+  ~Prefault() { join(); }
+};
+
 // Stage marks of the eigendecomposition (nls_evd_stage_ms): mark i closes stage i - 1.  A stage that does not exist in the path taken is
 // marked twice at the same point (0 ms).
 static inline void evd_mark(nls_ctx* ctx, int i) {

@@ -34,7 +34,10 @@ __device__ __forceinline__ double readlane_f64(double v, int src) {
 // A: the w x w diagonal block (lower, leading dimension lda), w <= NB.  Out: L11 in place (strict upper part untouched),
 // Sinv (four 32 x 32 column-major inverses of the diagonal sub-blocks; the block is identity-padded beyond w), info (0 or the global 1-based
 // index of the first bad pivot; only ever raised).
-__global__ void __launch_bounds__(256) k_potrf_leaf(double* A, long lda, int w, int k0, double* Sinv, int* info) {
+// With `rhs_run` (round 4) the forward half of alpha = cho_solve(L, y) is carried along: rhs_run = y - L[:, :k0] x[:k0] on entry; wave 0 solves the
+// block's unknowns x[k0 .. k0 + w) against the finished L11 (two rows per lane, the solved value travels by v_readlane) and stores them in xsol;
+// k_potrf_panel then takes L21 x off the rows below.
+__global__ void __launch_bounds__(256) k_potrf_leaf(double* A, long lda, int w, int k0, double* Sinv, int* info, const double* rhs_run, double* xsol) {
   extern __shared__ __attribute__((aligned(16))) unsigned char potrf_smem[];
   double(*Ls)[LDL] = reinterpret_cast<double(*)[LDL]>(potrf_smem);  // Ls[r][c], lower part valid
   __shared__ double dinv[NB];                                       // 1 / L[k][k]: the solves multiply
@@ -118,6 +121,22 @@ __global__ void __launch_bounds__(256) k_potrf_leaf(double* A, long lda, int w, 
       __syncthreads();
     }
   }
+  if (rhs_run != nullptr && wave == 0) {  // L11 x = rhs: rows lane and lane + 64
+    double a0 = lane < w ? rhs_run[k0 + lane] : 0.0, a1 = lane + 64 < w ? rhs_run[k0 + 64 + lane] : 0.0;
+    for (int t = 0; t < NB; ++t) {  // (identity rows beyond w: their unknowns are 0)
+      const double xt = (t < 64 ? readlane_f64(a0, t) : readlane_f64(a1, t - 64)) * dinv[t];
+      if (lane == (t & 63)) {
+        if (t < 64)
+          a0 = xt;
+        else
+          a1 = xt;
+      }
+      if (lane > t) a0 -= Ls[lane][t] * xt;
+      if (lane + 64 > t) a1 -= Ls[lane + 64][t] * xt;
+    }
+    if (lane < w) xsol[k0 + lane] = a0;
+    if (lane + 64 < w) xsol[k0 + 64 + lane] = a1;
+  }
   // L11 back, and the inverses of its diagonal sub-blocks: thread (s, c) solves L_ss x = e_c (32 x 32, the solution in registers)
   for (int idx = tid; idx < NB * NB; idx += 256) {
     const int r = idx % NB, c = idx / NB;
@@ -141,7 +160,10 @@ __global__ void __launch_bounds__(256) k_potrf_leaf(double* A, long lda, int w, 
 
 // L21 = A21 L11^-T, in place.  A21: m x w (leading dimension lda), L11: the factored diagonal block (w x w, same leading dimension), Sinv: the
 // inverses of its diagonal sub-blocks.  Workgroup = 64 rows, wave = 16 rows.
-__global__ void __launch_bounds__(256) k_potrf_panel(double* A21, long lda, int m, int w, const double* L11, const double* Sinv) {
+// xsol_p / rhs_rows (round 4, both or neither): the block's solved unknowns (k_potrf_leaf) and the running right-hand side of the panel's rows:
+// rhs_rows[r] -= L21[r, :] . xsol_p.
+__global__ void __launch_bounds__(256) k_potrf_panel(double* A21, long lda, int m, int w, const double* L11, const double* Sinv, const double* xsol_p,
+                                                     double* rhs_rows) {
   const int lane = threadIdx.x & 63, x = lane & 15, kk = lane >> 4;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const long r = (long)blockIdx.x * 64 + 16 * wv + x;
@@ -191,6 +213,17 @@ __global__ void __launch_bounds__(256) k_potrf_panel(double* A21, long lda, int 
     const int k = 4 * ks + kk;
     if (r < m && k < w) A21[r + (long)k * lda] = b[ks];
   }
+  if (xsol_p != nullptr) {  // this row's share of the forward substitution: the lanes x, x + 16, x + 32, x + 48 hold the row's k = kk mod 4
+    double sdot = 0.0;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int k = 4 * ks + kk;
+      sdot += b[ks] * (k < w ? xsol_p[k] : 0.0);
+    }
+    sdot += __shfl_xor(sdot, 16, 64);
+    sdot += __shfl_xor(sdot, 32, 64);
+    if (kk == 0 && r < m) rhs_rows[r] -= sdot;
+  }
 }
 
 // A22 -= L21 L21^T on the lower triangle: 128 x 128 tiles R >= C of the m x m matrix A22 on the real tile engine of nls_gemm.h (double-buffered
@@ -198,18 +231,28 @@ __global__ void __launch_bounds__(256) k_potrf_panel(double* A21, long lda, int 
 // k-major operand for BOTH sides.  The tile is formed transposed (A operand: the tile's columns, B operand: its rows), so the 16 lanes of an
 // accumulator register are 16 consecutive rows of one stored column.  The loaders have no bounds tests: the panel must be readable up to a
 // multiple of 128 rows (the caller's leading dimension is padded; rows beyond m only feed results that are not stored).
-__global__ void __launch_bounds__(Cfg4::NTHREADS, 2) k_potrf_syrk(double* A, long lda, int m, const double* Lp, long ldl) {
+// Tile list: rows R = 0 .. nt - 1, for each the columns C = 0 .. min(R, ncol_tiles - 1) (ncol_tiles = nt: the whole lower triangle; 1: the strip of
+// the next panel's columns only).  K = 16 ktiles columns of Lp (round 4: two panels of 128 share ONE pass over the trailing matrix, K = 256 -
+// the update is bound by the traffic of the trailing triangle, which halves).
+__global__ void __launch_bounds__(Cfg4::NTHREADS, 2) k_potrf_syrk(double* A, long lda, int m, const double* Lp, long ldl, int ktiles, int ncol_tiles) {
   using C4 = Cfg4;
   extern __shared__ double smem[];
-  int t = blockIdx.x, R = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
-  while ((R + 1) * (R + 2) / 2 <= t) ++R;
-  while (R * (R + 1) / 2 > t) --R;
-  const int C = t - R * (R + 1) / 2;
+  int t = blockIdx.x, R, C;
+  const int tri = ncol_tiles * (ncol_tiles + 1) / 2;
+  if (t < tri) {
+    R = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+    while ((R + 1) * (R + 2) / 2 <= t) ++R;
+    while (R * (R + 1) / 2 > t) --R;
+    C = t - R * (R + 1) / 2;
+  } else {
+    R = ncol_tiles + (t - tri) / ncol_tiles;
+    C = (t - tri) % ncol_tiles;
+  }
   v4d acc[C4::MT][C4::NTL];
   zero_acc(acc);
   KMajorLoader<C4::NTHREADS, BM> la{Lp, ldl, (long)C * BM};
   KMajorLoader<C4::NTHREADS, BN> lb{Lp, ldl, (long)R * BN};
-  mainloop_real<C4, true>(acc, la, lb, 0, NB / BK, smem);
+  mainloop_real<C4, true>(acc, la, lb, 0, ktiles, smem);
 #pragma unroll
   for (int mt = 0; mt < C4::MT; ++mt)
 #pragma unroll

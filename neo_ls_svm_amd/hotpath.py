@@ -15,6 +15,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
+from ._hostpool import factor_output
 from ._prestep import blas_threads
 from ._lib import Context, DeviceArray, DualFitArgs, Factor, PrimalFitArgs, default_context
 
@@ -337,7 +338,7 @@ def primal_fit(
         "objective": np.empty(G),
     }
     if want_L:
-        out["L"] = np.zeros((D1, D1), dtype=np.complex128)  # only the upper triangle is defined (cho_factor layout; large factors arrive as the triangle alone)
+        out["L"] = factor_output((D1, D1), np.complex128)  # only the upper triangle is defined (cho_factor layout; large factors arrive as the triangle alone)
     if want_rows:
         for k in ("loo_residuals", "loo_leverage", "loo_std", "residuals"):
             out[k] = np.empty(n)
@@ -528,7 +529,7 @@ def dual_fit(
         "residuals": np.empty(n),
     }
     if want_L:
-        out["L"] = np.zeros((n, n))  # only the upper triangle is defined (cho_factor layout; large factors arrive as the triangle alone)
+        out["L"] = factor_output((n, n), np.float64)  # only the upper triangle is defined (cho_factor layout; large factors arrive as the triangle alone)
     score, opt = C.c_double(), C.c_int32()
     tm = np.zeros(_lib.NUM_TIMINGS)
     a = DualFitArgs()

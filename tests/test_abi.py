@@ -323,3 +323,38 @@ def test_sigma_grid_merge_over_ranks(monkeypatch):
     g = hotpath.primal_fit_sigma_grid(None, None, None, None, None, B, False, sig, gammas=np.arange(1.0, G + 1))
     assert (g["sigma_index"], g["gamma_index"]) == (4, 2) and g["best"]["beta"][0] == 4.0
     assert g["timings"]["gram"] == 0.5 * S
+
+
+def test_pooled_factor_outputs_are_recycled_only_when_nobody_holds_them():
+    """Large factor outputs (``L_``) come from a pool of anonymous mappings (``_hostpool``): an array and its views keep their mapping; once all are
+    gone the NEXT output of that size reuses it (no munmap / mmap / first-touch faults per fit); small outputs are plain arrays; ``release`` unmaps."""
+    import gc
+
+    from neo_ls_svm_amd import _hostpool as pool
+
+    pool.release()
+    n = 2900  # 2900^2 doubles = 67 MB >= MIN_BYTES
+    a = pool.factor_output((n, n), np.float64)
+    assert a.shape == (n, n) and a.flags["C_CONTIGUOUS"] and a.flags["WRITEABLE"] and not a.any()
+    a[:] = 3.0
+    addr = a.__array_interface__["data"][0]
+    view = a[5:7]
+    b = pool.factor_output((n, n), np.float64)  # a is alive: a second mapping
+    assert b.__array_interface__["data"][0] != addr
+    del a
+    gc.collect()
+    assert pool._pooled_bytes() == 0 and view[0, 0] == 3.0  # the view keeps the mapping
+    del view
+    gc.collect()
+    assert pool._pooled_bytes() == n * n * 8
+    c = pool.factor_output((n, n), np.float64)
+    assert c.__array_interface__["data"][0] == addr  # recycled (its contents are the previous factor's: only the defined triangle is output)
+    import pickle
+
+    assert pickle.loads(pickle.dumps(c[:2])).shape == (2, n)
+    small = pool.factor_output((10, 10), np.complex128)
+    assert small.base is None and not small.any()
+    del b, c
+    gc.collect()
+    pool.release()
+    assert pool._pooled_bytes() == 0

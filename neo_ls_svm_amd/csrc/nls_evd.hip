@@ -385,8 +385,7 @@ static int apply_q2(nls_ctx* ctx, const T* V2, int n, T* C, long ldc, int ncols)
         // results, 117 against 108 ms at n = 10^4 (profiles/r04_q2_forms.md) - the two-waves-per-block form below stays the default.
         static const bool wave_form = [] { const char* m = std::getenv("NLS_Q2_FORM"); return m && std::string(m) == "wave"; }();
         if (wave_form) {
-          static const size_t lds_extra = [] { const char* m = std::getenv("NLS_Q2_LDS_EXTRA"); return m ? (size_t)std::atol(m) : (size_t)0; }();  // experiment: fewer workgroups per CU
-          const size_t lds_wave = Q2Wave::lds_bytes() + lds_extra;
+          const size_t lds_wave = Q2Wave::lds_bytes();
           NLSCHK(sb_lds_optin(ctx, k_q2_apply_wave, lds_wave, "k_q2_apply_wave"));
           long long* stamps = nullptr;
           static const bool want_stamps = [] { const char* m = std::getenv("NLS_Q2_STAMP"); return m && m[0] == '1'; }();
@@ -400,12 +399,6 @@ static int apply_q2(nls_ctx* ctx, const T* V2, int n, T* C, long ldc, int ncols)
             long long h[384];
             HIPCHK(ctx, hipMemcpyAsync(h, stamps, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-            for (int w = 0; w < 3; ++w)
-              for (int q = 0; q < 8; ++q) {
-                const long long* t = h + (w * 8 + q) * 4;
-                std::fprintf(stderr, "[q2 wave stamps] wave %d step %d: barrier wait %.2f us, product 1 %.2f, product 2 %.2f | next step %.2f us later\n", w, 20 + q,
-                             (t[1] - t[0]) * 0.01, (t[2] - t[1]) * 0.01, (t[3] - t[2]) * 0.01, q < 7 ? (t[4] - t[0]) * 0.01 : 0.0);
-              }
             for (int wsel = 0; wsel < 2; ++wsel)
               for (int pi = 0; pi + 1 < 120 && h[128 + 128 * wsel + pi + 1] != 0; pi += 8)
                 std::fprintf(stderr, "[q2 wave stamps] workgroup %d pass %d: started %.1f us after pass 0, this pass %.1f us (%d steps)\n", wsel ? 300 : 0, pi,

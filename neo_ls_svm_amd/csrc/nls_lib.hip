@@ -774,7 +774,7 @@ static int zpotrf_lower(nls_ctx* ctx, hipStream_t stream, rocblas_handle blas, d
       const int m_pad = (int)round_up(mrows, BM);
       const int pgrid = std::max(1, (m_pad + ZP_ROWS - 1) / ZP_ROWS);
       const long ko = (long)(k0 - K0) * ldp;  // this panel's 32 k-rows inside the halves of the outer stacks
-      hipLaunchKernelGGL(k_zpotrf_panel, dim3((unsigned)pgrid), dim3(ZP_ROWS), ZP_LDS, stream, D, lda, w, k0, mrows, m_pad, S1, S2, S3, ldp, O1 + ko, O2 + ko,
+      hipLaunchKernelGGL(k_zpotrf_panel, dim3((unsigned)pgrid), dim3(ZP_THREADS), ZP_LDS, stream, D, lda, w, k0, mrows, m_pad, S1, S2, S3, ldp, O1 + ko, O2 + ko,
                          O3 + ko, (long)NBO, K0 + W - (k0 + w), L11w, rhs_run, ysol, dinfo);
       const int icols = K0 + W - (k0 + w);  // columns of the outer block right of the panel: the panel's own (tall) update
       if (icols > 0) {

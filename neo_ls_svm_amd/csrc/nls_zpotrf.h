@@ -39,9 +39,10 @@ constexpr int NBO = 256;  // outer block column: the trailing matrix beyond it i
 // Out besides L21 (in place): the planes of L21 as the update kernel reads them, [k][row] with the row index fastest, zero for k >= w and for rows
 // m .. m_pad - 1, stacked in pairs along k (each half padded to NBZ rows): S1 = [Re; Im], S2 = [Re; -Im], S3 = [Im; Re]; and the same entries in
 // the outer block column's stacks O1 .. O3 (halves of ohalf rows; rows below the outer block only, index r - orow0; zeroed by the caller).
-constexpr int ZP_ROWS = 256;
+constexpr int ZP_ROWS = 256;                // rows of the panel per workgroup
+constexpr int ZP_THREADS = ZP_ROWS + 64;    // + the wave that factors the diagonal block
 constexpr size_t ZP_LDS = (size_t)2 * NBZ * (NBZ + 1) * sizeof(double) + (size_t)NBZ * ZP_ROWS * sizeof(double2) + NBZ * sizeof(double);
-__global__ void __launch_bounds__(ZP_ROWS) k_zpotrf_panel(double2* __restrict__ A, long lda, int w, int k0, int m, int m_pad, double* __restrict__ S1,
+__global__ void __launch_bounds__(ZP_THREADS) k_zpotrf_panel(double2* __restrict__ A, long lda, int w, int k0, int m, int m_pad, double* __restrict__ S1,
                                                           double* __restrict__ S2, double* __restrict__ S3, long ldp, double* __restrict__ O1,
                                                           double* __restrict__ O2, double* __restrict__ O3, long ohalf, int orow0,
                                                           double2* __restrict__ L11out, double2* __restrict__ rhs_run, double2* __restrict__ ysol, int* info) {
@@ -51,14 +52,22 @@ __global__ void __launch_bounds__(ZP_ROWS) k_zpotrf_panel(double2* __restrict__ 
   double2(*xs)[ZP_ROWS] = reinterpret_cast<double2(*)[ZP_ROWS]>(zp_smem + (size_t)2 * NBZ * (NBZ + 1) * sizeof(double));
   double* dv = reinterpret_cast<double*>(zp_smem + (size_t)2 * NBZ * (NBZ + 1) * sizeof(double) + (size_t)NBZ * ZP_ROWS * sizeof(double2));
   __shared__ double2 ysh[NBZ];
-  const int tid = threadIdx.x;
+  __shared__ int cols_done;  // columns of the diagonal block's factor that are final in Lr / Li / dv (written by wave 0, polled by the row waves)
+  // Round 4: wave 0 only factors the diagonal block and PUBLISHES each finished column; the four row waves (thread = row) trail it by one
+  // column - step c of a row needs L[c][0 .. c], final after the block's step c - so the two chains of 32 dependent steps overlap instead of
+  // following each other (80 -> ~ 50 us per panel).
+  const int ftid = threadIdx.x;          // 0 .. 63: the factoring wave
+  const int tid = (int)threadIdx.x - 64;  // >= 0: row thread
+  const bool rowthr = tid >= 0;
   const long r = (long)blockIdx.x * ZP_ROWS + tid;
-  const bool live = r < m;
+  const bool live = rowthr && r < m;
   double2* A21 = A + w;
+  if (ftid == 0) cols_done = 0;
   // ---- this thread's row of the panel: loads in flight while the block is factored ----
-  for (int c = 0; c < NBZ; ++c) xs[c][tid] = (live && c < w) ? A21[r + (long)c * lda] : make_double2(0.0, 0.0);
+  if (rowthr)
+    for (int c = 0; c < NBZ; ++c) xs[c][tid] = (live && c < w) ? A21[r + (long)c * lda] : make_double2(0.0, 0.0);
   // ---- the diagonal block (rows / columns k0 .. k0 + w of A), identity-padded to 32 x 32 ----
-  for (int idx = tid; idx < NBZ * NBZ; idx += ZP_ROWS) {
+  for (int idx = ftid; idx < NBZ * NBZ; idx += ZP_THREADS) {
     const int rr = idx % NBZ, c = idx / NBZ;
     double2 v = make_double2(rr == c ? 1.0 : 0.0, 0.0);
     if (rr < w && c < w && rr >= c) v = A[rr + (long)c * lda];
@@ -67,8 +76,8 @@ __global__ void __launch_bounds__(ZP_ROWS) k_zpotrf_panel(double2* __restrict__ 
   }
   __syncthreads();
   int bad = 0;
-  if (tid < 64) {  // wave 0: lane = row rr (lanes 32 .. 63 mirror 0 .. 31), the row in registers, the pivot row travels by v_readlane
-    const int rr = tid & (NBZ - 1), h = tid >> 5;
+  if (!rowthr) {  // wave 0: lane = row rr (lanes 32 .. 63 mirror 0 .. 31), the row in registers, the pivot row travels by v_readlane
+    const int rr = ftid & (NBZ - 1), h = ftid >> 5;
     // No lane predicates inside the factorisation (every r == k, c <= r is a 64-bit scalar mask; the compiler keeps all of them alive and
     // spills): entries above the diagonal are computed as garbage and never read; the diagonal entry of step k is d / sqrt(d).
     double ar[NBZ], ai[NBZ];
@@ -85,10 +94,17 @@ __global__ void __launch_bounds__(ZP_ROWS) k_zpotrf_panel(double2* __restrict__ 
         d = 1.0;
       }
       const double inv = 1.0 / sqrt(d);
-      if (tid == 0) dv[k] = inv;
       const double lr = ar[k] * inv, li = ai[k] * inv;
       ar[k] = lr;
       ai[k] = li;
+      // column k is final: publish it (rows above the diagonal hold garbage that nobody reads), then the count
+      // (no lane predicates here either: the mirror lanes 32 .. 63 store the same values to the same places)
+      dv[k] = inv;
+      Lr[rr][k] = lr;
+      Li[rr][k] = li;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __hip_atomic_store(&cols_done, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
       for (int c = k + 1; c < NBZ; ++c) {  // a[rr][c] -= l[rr] conj(l[c])   (meaningful for rr >= c)
         const double cr = potrf::readlane_f64(lr, c), ci = potrf::readlane_f64(li, c);
@@ -102,19 +118,11 @@ __global__ void __launch_bounds__(ZP_ROWS) k_zpotrf_panel(double2* __restrict__ 
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (h == 0) {
-#pragma unroll
-      for (int c = 0; c < NBZ; ++c) {
-        Lr[rr][c] = ar[c];
-        Li[rr][c] = ai[c];  // (the diagonal's imaginary part stays exactly zero: see above)
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    // (every column went to Lr / Li as it was finished; the diagonal's imaginary part stays exactly zero: see above)
     if (rhs_run) {  // y[k0 .. k0 + w): L11 y = (running right-hand side), forward substitution across the lanes
       double2 acc = (h == 0 && rr < w) ? rhs_run[k0 + rr] : make_double2(0.0, 0.0);
       for (int t = 0; t < NBZ; ++t) {
-        if (tid == t) ysh[t] = make_double2(acc.x * dv[t], acc.y * dv[t]);
+        if (ftid == t) ysh[t] = make_double2(acc.x * dv[t], acc.y * dv[t]);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (h == 0 && rr > t) {
@@ -127,34 +135,38 @@ __global__ void __launch_bounds__(ZP_ROWS) k_zpotrf_panel(double2* __restrict__ 
       if (blockIdx.x == 0 && h == 0 && rr < w) ysol[k0 + rr] = ysh[rr];
     }
   }
-  __syncthreads();
+  if (rowthr) {
+    // ---- this workgroup's rows of the panel below the block: column c as soon as the block's column c is final ----
+    for (int c = 0; c < NBZ; ++c) {
+      while (__hip_atomic_load(&cols_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= c) __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      double2 x = xs[c][tid];
+      double sr = x.x, si = x.y;
+#pragma unroll 4
+      for (int t = 0; t < c; ++t) {  // x[c] -= x[t] conj(L[c][t])
+        const double lr = Lr[c][t], li = Li[c][t];
+        x = xs[t][tid];
+        sr = fma(-x.x, lr, sr);
+        sr = fma(-x.y, li, sr);
+        si = fma(-x.y, lr, si);
+        si = fma(x.x, li, si);
+      }
+      xs[c][tid] = make_double2(sr * dv[c], si * dv[c]);  // (read back by this thread only: no barrier)
+    }
+  }
+  __syncthreads();  // the factor, ysh and every row are complete
   if (blockIdx.x == 0) {
     // L11 goes back into A directly only when no other workgroup exists that may still be reading the un-factored block; otherwise into
     // L11out, from where the update kernel (the next launch) puts it in place.
     double2* dst = gridDim.x == 1 ? A : L11out;
     const long ldd = gridDim.x == 1 ? lda : NBZ;
-    for (int idx = tid; idx < NBZ * NBZ; idx += ZP_ROWS) {
+    for (int idx = ftid; idx < NBZ * NBZ; idx += ZP_THREADS) {
       const int rr = idx % NBZ, c = idx / NBZ;
       if (rr < w && c <= rr) dst[rr + (long)c * ldd] = make_double2(Lr[rr][c], Li[rr][c]);
     }
-    if (bad != 0 && bad <= w && tid == 0) atomicCAS(info, 0, k0 + bad);  // (pivots of the identity padding beyond w cannot fail)
+    if (bad != 0 && bad <= w && ftid == 0) atomicCAS(info, 0, k0 + bad);  // (pivots of the identity padding beyond w cannot fail)
   }
-  // ---- this workgroup's rows of the panel below the block ----
-  if (r >= m_pad) return;
-  for (int c = 0; c < NBZ; ++c) {
-    double2 x = xs[c][tid];
-    double sr = x.x, si = x.y;
-#pragma unroll 4
-    for (int t = 0; t < c; ++t) {  // x[c] -= x[t] conj(L[c][t])
-      const double lr = Lr[c][t], li = Li[c][t];
-      x = xs[t][tid];
-      sr = fma(-x.x, lr, sr);
-      sr = fma(-x.y, li, sr);
-      si = fma(-x.y, lr, si);
-      si = fma(x.x, li, si);
-    }
-    xs[c][tid] = make_double2(sr * dv[c], si * dv[c]);  // (read back by this thread only: no barrier)
-  }
+  if (!rowthr || r >= m_pad) return;
   if (rhs_run && live) {  // this row's share of the forward substitution: b[r] -= L21[r, :] y
     double2 acc = rhs_run[k0 + w + r];
     for (int c = 0; c < w; ++c) {

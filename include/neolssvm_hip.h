@@ -106,6 +106,13 @@ int nls_device_free(nls_ctx* ctx, void* dptr);
 int nls_memcpy_h2d(nls_ctx* ctx, void* dst, const void* src, size_t bytes);
 int nls_memcpy_d2h(nls_ctx* ctx, void* dst, const void* src, size_t bytes);
 int nls_synchronize(nls_ctx* ctx);
+/* Page-lock / release a HOST buffer that the caller will pass as a large output more than once (the L_ of the fits: 268 MB at D = 4096, 800 MB
+ * at n = 10^4): into page-locked memory the finished block columns of the factor travel with asynchronous copies beside the factorisation at the
+ * full PCIe rate; into pageable memory they are staged (~ 6-10 GB/s).  Registering costs ~ 10 ms per 268 MB - once per buffer, not per call
+ * (the Python mirror registers the buffers of its output pool, neo_ls_svm_amd/_hostpool.py).  Unregister BEFORE the memory is unmapped; ctx may be
+ * NULL there (the registering context may already be destroyed). */
+int nls_host_register(nls_ctx* ctx, void* ptr, size_t bytes);
+int nls_host_unregister(nls_ctx* ctx, void* ptr);
 /* Device description: name (<=255 chars), CU count, HBM bytes. */
 int nls_device_info(nls_ctx* ctx, char* name, int name_len, int* compute_units, size_t* hbm_bytes);
 

@@ -151,6 +151,8 @@ SIGNATURES = {
     "nls_tridiag_only": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nls_eigh_only": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "nls_twostage_stage": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "nls_host_register": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "nls_host_unregister": (C.c_int, [C.c_void_p, C.c_void_p]),
     "nls_cholesky_only": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "nls_zcholesky_only": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "nls_twostage_fallbacks": (C.c_long, [C.c_void_p]),

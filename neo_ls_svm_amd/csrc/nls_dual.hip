@@ -403,7 +403,7 @@ extern "C" int nls_dual_fit(nls_ctx* ctx, const nls_dual_fit_args* a) {
     // rocSOLVER leaves had given 49.7 against 52.7 with the triangular solves still inside)
     // (leading dimension n_pad: the rank-128 update reads whole 128-row blocks.)  Into page-locked memory the finished block columns of 512
     // travel on the copy stream while the following ones are factored; pageable outputs are downloaded afterwards in one piece.
-    pipelined_L = pinL.p != nullptr;
+    pipelined_L = pinL.p != nullptr || is_pinned_host(a->L);  // page-locked by this call (NLS_PIN_OUTPUT=1) or by the caller (nls_host_register)
     NLSCHK(ensure_copy_stream(ctx, (int)((n + 511) / 512)));
     copy_join.s = ctx->copy_stream;
     // alpha = cho_solve(L_, y): the forward substitution travels with the factorisation (alpha holds the running right-hand side)

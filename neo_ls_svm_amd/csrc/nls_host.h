@@ -313,6 +313,18 @@ struct HostPin {
   }
 };
 
+// True for a host pointer that is already page-locked (hipHostMalloc / hipHostRegister - e.g. through nls_host_register): copies into it are
+// asynchronous and run at the full PCIe rate.
+static inline bool is_pinned_host(const void* ptr) {
+  if (!ptr) return false;
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, ptr) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return attr.type == hipMemoryTypeHost;
+}
+
 // Touches every page of a caller's pageable OUTPUT buffer from helper threads, early in a call, while the host would otherwise wait for the GPU:
 // a fresh 800 MB array costs ~ 10^5 first-touch page faults (the kernel zeroes each page), which would otherwise land in the download at the end
 // of the call.  Contents are preserved (each page's first byte is read and written back).  Device and page-locked pointers are left alone.

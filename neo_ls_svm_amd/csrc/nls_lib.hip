@@ -268,6 +268,21 @@ extern "C" int nls_set_workspace_limit(nls_ctx* ctx, size_t bytes) {
   return NLS_OK;
 }
 
+extern "C" int nls_host_register(nls_ctx* ctx, void* ptr, size_t bytes) {
+  if (!ctx) return NLS_ERR_ARG;
+  if (!ptr || bytes == 0) return fail(ctx, NLS_ERR_ARG, "nls_host_register: null pointer or zero size");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+  return NLS_OK;
+}
+extern "C" int nls_host_unregister(nls_ctx* ctx, void* ptr) {  // (ctx may be NULL: the context that registered the buffer may be gone)
+  if (!ptr) return fail(ctx, NLS_ERR_ARG, "nls_host_unregister: null pointer");
+  if (ctx) HIPCHK(ctx, hipSetDevice(ctx->device));
+  const hipError_t e = hipHostUnregister(ptr);
+  if (e != hipSuccess) return fail(ctx, NLS_ERR_HIP, "hipHostUnregister: %s", hipGetErrorString(e));
+  return NLS_OK;
+}
+
 extern "C" int nls_ws_release(nls_ctx* ctx, size_t min_bytes, size_t* still_held) {
   if (!ctx) return NLS_ERR_ARG;
   HIPCHK(ctx, hipSetDevice(ctx->device));

@@ -338,7 +338,7 @@ def primal_fit(
         "objective": np.empty(G),
     }
     if want_L:
-        out["L"] = factor_output((D1, D1), np.complex128)  # only the upper triangle is defined (cho_factor layout; large factors arrive as the triangle alone)
+        out["L"] = factor_output((D1, D1), np.complex128, ctx)  # only the upper triangle is defined (cho_factor layout; large factors arrive as the triangle alone)
     if want_rows:
         for k in ("loo_residuals", "loo_leverage", "loo_std", "residuals"):
             out[k] = np.empty(n)
@@ -529,7 +529,7 @@ def dual_fit(
         "residuals": np.empty(n),
     }
     if want_L:
-        out["L"] = factor_output((n, n), np.float64)  # only the upper triangle is defined (cho_factor layout; large factors arrive as the triangle alone)
+        out["L"] = factor_output((n, n), np.float64, ctx)  # only the upper triangle is defined (cho_factor layout; large factors arrive as the triangle alone)
     score, opt = C.c_double(), C.c_int32()
     tm = np.zeros(_lib.NUM_TIMINGS)
     a = DualFitArgs()

@@ -415,3 +415,45 @@ def test_beta_is_the_cholesky_resolve(name, gi, golden_loader, hp):
     assert np.linalg.norm(r2["beta"] - r["beta"]) <= 1e-7 * np.linalg.norm(r["beta"])
     for k in ("loo_residuals", "loo_leverage", "loo_std", "residuals", "loo_errors_gammas"):
         assert np.array_equal(r2[k], r[k]), k
+
+
+@pytest.mark.gpu
+def test_large_factor_outputs_come_from_the_pool_and_can_be_page_locked(hp):
+    """``L_`` of at least 64 MB is handed out from the pool of host mappings, page-locked once through the context after ``pin_large_outputs(True)``; the factor that arrives in it
+    (asynchronous copies beside the factorisation) is the one a plain pageable buffer receives; buffers are recycled once nothing holds them."""
+    import gc
+
+    import scipy.linalg as sla
+    from neo_ls_svm_amd import _hostpool as pool
+
+    pool.release()
+    pool.pin_large_outputs(True)  # (off by default: it pays for repeated fits only)
+    rng = np.random.default_rng(5)
+    n, d, D = 6000, 12, 2100  # (D + 1)^2 complex = 71 MB
+    X = rng.standard_normal((n, d))
+    y = np.sin(X @ rng.standard_normal(d)) + 0.1 * rng.standard_normal(n)
+    s = np.ones(n)
+    shift, scale, B = X.mean(0), X.std(0), hp.orf_frequencies(d, D) * 0.5
+    ctx = hp.default_context()
+    r1 = hp.primal_fit(X, y, s, shift, scale, B, False, ctx=ctx)
+    assert type(r1["L"].base).__name__ == "_Lease" and len(pool._registered) == 1
+    addr = r1["L"].__array_interface__["data"][0]
+    iu = np.triu_indices(D + 1)
+    L1 = r1["L"][iu].copy()
+    A, b = hp.gram(X, y, s, shift, scale, B, ctx=ctx)
+    beta_ref = sla.cho_solve((r1["L"], False), b)  # the downloaded factor reproduces beta
+    assert relerr(r1["beta"], beta_ref) < 1e-9
+    del r1
+    gc.collect()
+    r2 = hp.primal_fit(X, y, s, shift, scale, B, False, ctx=ctx)
+    assert r2["L"].__array_interface__["data"][0] == addr and len(pool._registered) == 1  # recycled, still page-locked
+    assert np.array_equal(r2["L"][iu], L1)
+    del r2
+    gc.collect()
+    pool.pin_large_outputs(False)
+    r3 = hp.primal_fit(X, y, s, shift, scale, B, False, ctx=ctx)  # the recycled mapping stays page-locked; results as before
+    assert np.array_equal(r3["L"][iu], L1)
+    del r3
+    gc.collect()
+    pool.release()
+    assert pool._pooled_bytes() == 0 and not pool._registered

@@ -292,7 +292,10 @@ typedef struct nls_dual_fit_args {
   int32_t is_classifier;
   int32_t gamma_index_in;
   double* alpha;         /* n */
-  double* L;             /* n x n  cho_factor(gamma* diag(sn^-2) + K), upper, row-major; only that triangle is defined */
+  double* L;             /* n x n  cho_factor(gamma* diag(sn^-2) + K), upper, row-major; only that triangle is defined.  A pageable host
+                            buffer is filled by short-lived helper threads of the call (its pages touched behind the eigendecomposition, the
+                            finished block columns copied beside the factorisation), a page-locked one (nls_host_register) by asynchronous
+                            copies; NULL: no factorisation (alpha is then the eigendecomposition's) */
   double* lam;           /* n */
   double* loo_errors;    /* G */
   double* objective;     /* G */

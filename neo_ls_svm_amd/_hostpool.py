@@ -21,6 +21,7 @@ from __future__ import annotations
 
 import ctypes
 import mmap
+import os
 import threading
 
 import numpy as np
@@ -93,7 +94,7 @@ def factor_output(shape, dtype, ctx=None) -> np.ndarray:
     """A writable C-contiguous array for a factor output: pooled mapping when it is large (page-locked through ``ctx`` after ``pin_large_outputs(True)``),
     ``np.zeros`` otherwise."""
     nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
-    if nbytes < MIN_BYTES:
+    if nbytes < MIN_BYTES or os.environ.get("NLS_HOST_POOL", "1") == "0":  # (NLS_HOST_POOL=0: always a fresh array)
         return np.zeros(shape, dtype=dtype)
     with _lock:
         lst = _free.get(nbytes)

@@ -336,6 +336,9 @@ class Context:
 
     def close(self):
         if getattr(self, "handle", None):
+            dev, self._hold_cache = getattr(self, "_hold_cache", None), None
+            if dev is not None:
+                dev.free()
             self.lib.nls_ctx_destroy(self.handle)
             self.handle = None
 
@@ -356,6 +359,9 @@ class Context:
         from . import _hostpool  # the pooled host buffers of large factor outputs go with it
 
         _hostpool.release()
+        dev, self._hold_cache = getattr(self, "_hold_cache", None), None
+        if dev is not None:
+            dev.free()
         return int(held.value)
 
     # ---- native RCCL communicator (one process per GPU; no torch) -----------------------------------
@@ -439,11 +445,24 @@ class Context:
             def __enter__(self_inner):
                 arr = np.asarray(a)
                 if arr.dtype == np.float64 and arr.ndim == 2 and arr.flags.c_contiguous and arr.size:
-                    ctx._held = (arr.__array_interface__["data"][0], arr.shape, arr.strides, ctx.to_device(arr))
+                    # the device buffer of the previous fit's X is kept and reused when the size matches: a hipMalloc + hipFree of the
+                    # matrix per fit cost 15-55 ms (51 MB ... 1 GB), more than the upload itself; Context.release_workspace drops it
+                    dev = getattr(ctx, "_hold_cache", None)
+                    ctx._hold_cache = None
+                    if dev is not None and dev.ptr and dev.nbytes == arr.nbytes:
+                        dev.shape = tuple(arr.shape)
+                        dev.copy_from_host(arr)
+                    else:
+                        if dev is not None:
+                            dev.free()
+                        dev = ctx.to_device(arr)
+                    ctx._held = (arr.__array_interface__["data"][0], arr.shape, arr.strides, dev)
                 return self_inner
 
             def __exit__(self_inner, *exc):
-                ctx._held = None
+                h, ctx._held = getattr(ctx, "_held", None), None
+                if h is not None:
+                    ctx._hold_cache = h[3]
                 return False
 
         return _Hold()

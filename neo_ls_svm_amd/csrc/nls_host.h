@@ -223,7 +223,10 @@ static int spans_collect(nls_ctx* ctx, double* timings) {
 struct SpanGuard {  // RAII so early returns still close the span
   nls_ctx* c;
   bool open;
-  SpanGuard(nls_ctx* ctx, int stage) : c(ctx), open(span_begin(ctx, stage) == NLS_OK) {}
+  SpanGuard(nls_ctx* ctx, int stage) : c(ctx), open(span_begin(ctx, stage) == NLS_OK) {
+    static const bool marks = [] { const char* m = std::getenv("NLS_HOST_MARKS"); return m && m[0] == '1'; }();  // diagnostic: when the HOST reaches each stage
+    if (marks) std::fprintf(stderr, "[nls host] stage %d enqueued at %.3f ms\n", stage, 1e3 * std::fmod(std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(), 1000.0));
+  }
   ~SpanGuard() {
     if (open) span_end(c);
   }

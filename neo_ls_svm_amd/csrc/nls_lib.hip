@@ -868,7 +868,10 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
   PrimalState st;
   const long n = a->n;
   const int G = a->G, is_clf = a->is_classifier ? 1 : 0;
+  static const bool host_marks = [] { const char* m = std::getenv("NLS_HOST_MARKS"); return m && m[0] == '1'; }();
+  if (host_marks) std::fprintf(stderr, "[nls host] nls_primal_fit entered at %.3f ms\n", 1e3 * std::fmod(wall(), 1000.0));
   NLSCHK(upload_map(ctx, a->shift, a->scale, a->B, a->d, a->D, &st.mp));
+  if (host_marks) std::fprintf(stderr, "[nls host] map uploaded at %.3f ms\n", 1e3 * std::fmod(wall(), 1000.0));
   const MapParams& mp = st.mp;
   const int D1 = mp.D1, Kf = mp.Kf, Np = mp.Np;
   const int Gp = (int)round_up(G, BN);
@@ -1230,6 +1233,7 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
     *a->loo_score = is_clf ? hsum[0] : 1.0 - hsum[0] / hsum[1];
   }
   tm[NLS_T_TOTAL] = wall() - t_start;
+  if (host_marks) std::fprintf(stderr, "[nls host] nls_primal_fit leaves at %.3f ms\n", 1e3 * std::fmod(wall(), 1000.0));
   if (a->timings) std::memcpy(a->timings, tm, sizeof(tm));
   return NLS_OK;
 }

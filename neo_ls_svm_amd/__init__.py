@@ -6,6 +6,7 @@ hand-written HIP kernels for gfx950 plus rocSOLVER for the dense EVD / Cholesky.
 
 from ._lib import Context, DeviceArray, Factor, NlsError, default_context, load_library, set_default_context  # noqa: F401
 from ._hostpool import pin_large_outputs  # noqa: F401
+from ._hostpool import reserve as reserve_factor_outputs  # noqa: F401
 from .hotpath import (  # noqa: F401
     dual_fit,
     dual_predict,
@@ -43,6 +44,7 @@ __all__ = [
     "AffineFeatureMap",
     "set_default_context",
     "pin_large_outputs",
+    "reserve_factor_outputs",
     "Context",
     "DeviceArray",
     "Factor",

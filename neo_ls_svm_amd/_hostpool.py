@@ -10,11 +10,13 @@ Only the triangle the library defines is meaningful in such an array (scipy's ``
 data"); a recycled buffer holds a previous factor's entries there, a fresh one zeros.  ``release()`` unmaps what the pool holds
 (``Context.release_workspace`` calls it).
 
-``pin_large_outputs(True)`` (off by default) additionally page-locks each mapping ONCE (``nls_host_register``): the library then sends the
-finished block columns of the factor with asynchronous copies at the full PCIe rate instead of staging them (~6-10 GB/s).  Measured on an
-MI355X box: registering costs 40 ms per 268 MB / 110-140 ms per 800 MB, once per buffer; it takes the primal fit's remaining ~8 ms of download
-off every later fit (c3e 421 -> 412 ms) and nothing off the dual fit (whose pageable download is already hidden) - worth it for loops of
-fits, a loss for a single one, hence opt-in.  A failed registration (locked-memory limit) simply leaves the buffer pageable.
+A mapping can additionally be page-locked ONCE (``nls_host_register``): the library then sends the finished block columns of the factor with
+asynchronous copies at the full PCIe rate instead of staging them (~6-10 GB/s).  Measured on an MI355X box: registering costs 40 ms per 268 MB /
+110-140 ms per 800 MB, once per buffer; it takes the primal fit's remaining ~8-12 ms of download off every later fit (c3e 421 -> 412 ms) and
+nothing off the dual fit (whose pageable download is already hidden) - it pays for loops of fits and is a loss for a single one.  Hence the
+default policy ``"reuse"``: a mapping is page-locked when it is handed out for the SECOND time (a recycled buffer is evidence of a loop); a
+process that fits once or twice never pays.  ``pin_large_outputs(True)``: at creation; ``pin_large_outputs(False)``: never.  A failed
+registration (locked-memory limit) simply leaves the buffer pageable.
 """
 
 from __future__ import annotations
@@ -29,7 +31,8 @@ import numpy as np
 MIN_BYTES = 64 << 20
 MAX_POOLED_PER_SIZE = 2
 MAX_POOLED_BYTES = 4 << 30
-PIN_OUTPUTS = False
+PIN_OUTPUTS = "reuse"  # False | "reuse" | True, see the module docstring
+LAST_REGISTER_RC = None  # return code of the most recent nls_host_register (diagnostic)
 
 _lock = threading.Lock()
 _free: dict[int, list[mmap.mmap]] = {}
@@ -84,10 +87,11 @@ class _Lease:
             pass
 
 
-def pin_large_outputs(flag: bool = True) -> None:
-    """Page-lock the pooled buffers of large factor outputs from now on (see the module docstring: pays for repeated fits)."""
+def pin_large_outputs(flag=True) -> None:
+    """Policy for page-locking the pooled buffers of large factor outputs: ``True`` (at creation), ``"reuse"`` (the default: when a buffer is
+    handed out for the second time) or ``False`` (never); see the module docstring."""
     global PIN_OUTPUTS
-    PIN_OUTPUTS = bool(flag)
+    PIN_OUTPUTS = "reuse" if flag == "reuse" else bool(flag)
 
 
 def factor_output(shape, dtype, ctx=None) -> np.ndarray:
@@ -99,19 +103,50 @@ def factor_output(shape, dtype, ctx=None) -> np.ndarray:
     with _lock:
         lst = _free.get(nbytes)
         mm = lst.pop() if lst else None
+    recycled = mm is not None
     if mm is None:
         mm = mmap.mmap(-1, nbytes)  # anonymous, zero-filled on first touch
         try:  # transparent huge pages where the system allows them on request (what numpy asks for its own large arrays): 512 x fewer faults / TLB entries
             mm.madvise(mmap.MADV_HUGEPAGE)
         except (AttributeError, OSError, ValueError):
             pass
-    if PIN_OUTPUTS and ctx is not None and id(mm) not in _registered and getattr(ctx, "handle", None):
+    if (PIN_OUTPUTS is True or (PIN_OUTPUTS == "reuse" and recycled)) and ctx is not None and id(mm) not in _registered and getattr(ctx, "handle", None):
+        global LAST_REGISTER_RC
         try:
-            if ctx.lib.nls_host_register(ctx.handle, ctypes.c_void_p(_address(mm)), ctypes.c_size_t(nbytes)) == 0:
+            LAST_REGISTER_RC = ctx.lib.nls_host_register(ctx.handle, ctypes.c_void_p(_address(mm)), ctypes.c_size_t(nbytes))
+            if LAST_REGISTER_RC == 0:
                 _registered[id(mm)] = ctx.lib
-        except Exception:
-            pass
+        except Exception as exc:  # pragma: no cover
+            LAST_REGISTER_RC = repr(exc)
     return np.asarray(_Lease(mm, shape, dtype))
+
+
+def reserve(shape, dtype, ctx=None, count: int = 2) -> int:
+    """Put ``count`` mappings for outputs of this shape into the pool ahead of time - page-locked when a context is given - so that a loop of
+    fits starts in its steady state (what a C caller does when it allocates and registers its output buffer once).  Returns how many were added."""
+    nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    if nbytes < MIN_BYTES or os.environ.get("NLS_HOST_POOL", "1") == "0":
+        return 0
+    added = 0
+    for _ in range(count):
+        with _lock:
+            if len(_free.get(nbytes, [])) >= MAX_POOLED_PER_SIZE or _pooled_bytes() + nbytes > MAX_POOLED_BYTES:
+                break
+        mm = mmap.mmap(-1, nbytes)
+        try:
+            mm.madvise(mmap.MADV_HUGEPAGE)
+        except (AttributeError, OSError, ValueError):
+            pass
+        if ctx is not None and getattr(ctx, "handle", None):
+            try:
+                if ctx.lib.nls_host_register(ctx.handle, ctypes.c_void_p(_address(mm)), ctypes.c_size_t(nbytes)) == 0:
+                    _registered[id(mm)] = ctx.lib
+            except Exception:
+                pass
+        with _lock:
+            _free.setdefault(nbytes, []).append(mm)
+        added += 1
+    return added
 
 
 def release() -> None:

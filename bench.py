@@ -485,7 +485,7 @@ def main():
         # row-sharded fit: every rank ends with the same beta / lam / curve; the factor L_ (an output only) is produced and downloaded by rank 0
         return hp.primal_fit(X_, y_, s_, shift, scale, B, False, gammas=gammas, ctx=ctx, want_L=(rank == 0))
 
-    if not grid_mode and rank == 0:
+    if grid_mode or rank == 0:
         # the L_ outputs of the loop: two page-locked host buffers reserved once, like the inputs (a C caller allocates - and may register - its
         # output buffer once; the Python mirror would otherwise create them during the first steps and page-lock them when they are first recycled)
         hp.reserve_factor_outputs((D + 1, D + 1), np.complex128, ctx, 2)

@@ -635,6 +635,7 @@ def main():
             out["parity"] = None
         if world == 1 and not args.no_end_to_end:
             ctx.release_workspace()
+            r.pop("L", None)  # (hand the loop's output buffer back to the pool: the estimator's two fits then find their buffers there)
             out["end_to_end"] = None if grid_mode else end_to_end_fit(cfg, ctx)
             if out["end_to_end"]:
                 out["value_end_to_end"] = out["end_to_end"]["fits_per_s"]

@@ -10,13 +10,15 @@ Only the triangle the library defines is meaningful in such an array (scipy's ``
 data"); a recycled buffer holds a previous factor's entries there, a fresh one zeros.  ``release()`` unmaps what the pool holds
 (``Context.release_workspace`` calls it).
 
-A mapping can additionally be page-locked ONCE (``nls_host_register``): the library then sends the finished block columns of the factor with
-asynchronous copies at the full PCIe rate instead of staging them (~6-10 GB/s).  Measured on an MI355X box: registering costs 40 ms per 268 MB /
-110-140 ms per 800 MB, once per buffer; it takes the primal fit's remaining ~8-12 ms of download off every later fit (c3e 421 -> 412 ms) and
-nothing off the dual fit (whose pageable download is already hidden) - it pays for loops of fits and is a loss for a single one.  Hence the
-default policy ``"reuse"``: a mapping is page-locked when it is handed out for the SECOND time (a recycled buffer is evidence of a loop); a
-process that fits once or twice never pays.  ``pin_large_outputs(True)``: at creation; ``pin_large_outputs(False)``: never.  A failed
-registration (locked-memory limit) simply leaves the buffer pageable.
+The arrays start 64 bytes into their mapping on purpose: into a PAGE-ALIGNED pageable destination the HIP runtime locks the user pages in place
+for every copy (measured: 12 ms per 268 MB when the pages are resident, 38 ms when they are fresh), into an unaligned one it stages the copy
+(0.4 ms visible once the pages are resident) - numpy's own arrays are never page-aligned either.
+
+A mapping can additionally be page-locked ONCE (``nls_host_register``; 16-40 ms per 268 MB, 110-140 ms per 800 MB): the library then sends the
+finished block columns with asynchronous copies.  With the unaligned start this buys nothing measurable any more (0.36 against 0.43 ms of visible
+download at D = 4096), so the default policy is ``False``; ``pin_large_outputs("reuse")`` page-locks a mapping when it is handed out for the
+second time, ``pin_large_outputs(True)`` at creation, and ``reserve(shape, dtype, ctx)`` puts page-locked mappings into the pool ahead of a loop
+(``bench.py``).  A failed registration (locked-memory limit) simply leaves the buffer pageable.
 """
 
 from __future__ import annotations
@@ -31,7 +33,11 @@ import numpy as np
 MIN_BYTES = 64 << 20
 MAX_POOLED_PER_SIZE = 2
 MAX_POOLED_BYTES = 4 << 30
-PIN_OUTPUTS = "reuse"  # False | "reuse" | True, see the module docstring
+# The array starts OFFSET bytes into its mapping: a page-aligned pageable destination makes the HIP runtime lock the user pages in place for every copy
+# (12 ms per 268 MB when the pages are resident, 38 ms when they are fresh - measured), an unaligned one takes its staged path (2-3 ms), as numpy's own
+# arrays do.
+OFFSET = 64
+PIN_OUTPUTS = False  # False | "reuse" | True, see the module docstring
 LAST_REGISTER_RC = None  # return code of the most recent nls_host_register (diagnostic)
 
 _lock = threading.Lock()
@@ -42,7 +48,7 @@ _registered: dict[int, object] = {}  # id(mapping) -> the ctypes library that pa
 def _address(mm: mmap.mmap) -> int:
     view = ctypes.c_char.from_buffer(mm)
     try:
-        return ctypes.addressof(view)
+        return ctypes.addressof(view) + OFFSET
     finally:
         del view
 
@@ -69,7 +75,7 @@ class _Lease:
     def __init__(self, mm: mmap.mmap, shape, dtype):
         self._mm = mm
         self._view = ctypes.c_char.from_buffer(mm)  # (pins the mapping: it cannot be resized or closed under the arrays)
-        self.__array_interface__ = {"data": (ctypes.addressof(self._view), False), "shape": tuple(shape), "typestr": np.dtype(dtype).str, "version": 3}
+        self.__array_interface__ = {"data": (ctypes.addressof(self._view) + OFFSET, False), "shape": tuple(shape), "typestr": np.dtype(dtype).str, "version": 3}
 
     def __del__(self):
         mm, self._view = self._mm, None
@@ -77,7 +83,7 @@ class _Lease:
             return
         try:
             with _lock:
-                size = len(mm)
+                size = len(mm) - 4096
                 lst = _free.setdefault(size, [])
                 if len(lst) < MAX_POOLED_PER_SIZE and _pooled_bytes() + size <= MAX_POOLED_BYTES:
                     lst.append(mm)
@@ -88,8 +94,8 @@ class _Lease:
 
 
 def pin_large_outputs(flag=True) -> None:
-    """Policy for page-locking the pooled buffers of large factor outputs: ``True`` (at creation), ``"reuse"`` (the default: when a buffer is
-    handed out for the second time) or ``False`` (never); see the module docstring."""
+    """Policy for page-locking the pooled buffers of large factor outputs: ``True`` (at creation), ``"reuse"`` (when a buffer is handed out for
+    the second time) or ``False`` (never: the default); see the module docstring."""
     global PIN_OUTPUTS
     PIN_OUTPUTS = "reuse" if flag == "reuse" else bool(flag)
 
@@ -105,7 +111,7 @@ def factor_output(shape, dtype, ctx=None) -> np.ndarray:
         mm = lst.pop() if lst else None
     recycled = mm is not None
     if mm is None:
-        mm = mmap.mmap(-1, nbytes)  # anonymous, zero-filled on first touch
+        mm = mmap.mmap(-1, nbytes + 4096)  # anonymous, zero-filled on first touch (+ a page: the array starts OFFSET bytes in)
         try:  # transparent huge pages where the system allows them on request (what numpy asks for its own large arrays): 512 x fewer faults / TLB entries
             mm.madvise(mmap.MADV_HUGEPAGE)
         except (AttributeError, OSError, ValueError):
@@ -132,7 +138,7 @@ def reserve(shape, dtype, ctx=None, count: int = 2) -> int:
         with _lock:
             if len(_free.get(nbytes, [])) >= MAX_POOLED_PER_SIZE or _pooled_bytes() + nbytes > MAX_POOLED_BYTES:
                 break
-        mm = mmap.mmap(-1, nbytes)
+        mm = mmap.mmap(-1, nbytes + 4096)
         try:
             mm.madvise(mmap.MADV_HUGEPAGE)
         except (AttributeError, OSError, ValueError):

@@ -868,6 +868,8 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
   PrimalState st;
   const long n = a->n;
   const int G = a->G, is_clf = a->is_classifier ? 1 : 0;
+  Prefault prefault;  // a fresh pageable L_ buffer: its pages are touched by helper threads behind the Gram / eigendecomposition (joined before the download)
+  if (a->L) prefault.start(a->L, sizeof(double2) * (size_t)(a->D + 1) * (size_t)(a->D + 1));
   static const bool host_marks = [] { const char* m = std::getenv("NLS_HOST_MARKS"); return m && m[0] == '1'; }();
   if (host_marks) std::fprintf(stderr, "[nls host] nls_primal_fit entered at %.3f ms\n", 1e3 * std::fmod(wall(), 1000.0));
   NLSCHK(upload_map(ctx, a->shift, a->scale, a->B, a->d, a->D, &st.mp));
@@ -1182,6 +1184,7 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
     NLSCHK(d2h(a->residuals, res, sizeof(double) * n));
   }
   if (side_copy) {  // everything else is enqueued: the block columns of L_ now follow the factorisation (pageable memory: each copy blocks this thread)
+    prefault.join();
     NLSCHK(download_block_columns(ctx, a->L, Acm, D1, (long)D1, sizeof(double2), 512, true));
     HIPCHK(ctx, hipEventRecord(ctx->side_ev[2], ctx->copy_stream));
   }

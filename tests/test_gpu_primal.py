@@ -427,7 +427,7 @@ def test_large_factor_outputs_come_from_the_pool_and_can_be_page_locked(hp):
     from neo_ls_svm_amd import _hostpool as pool
 
     pool.release()
-    pool.pin_large_outputs(True)  # (default "reuse": page-locked when handed out for the second time)
+    pool.pin_large_outputs(True)  # (default False: with the unaligned start of the pooled arrays the staged copies are as fast)
     rng = np.random.default_rng(5)
     n, d, D = 6000, 12, 2100  # (D + 1)^2 complex = 71 MB
     X = rng.standard_normal((n, d))
@@ -457,7 +457,7 @@ def test_large_factor_outputs_come_from_the_pool_and_can_be_page_locked(hp):
     gc.collect()
     pool.release()
     assert pool._pooled_bytes() == 0 and not pool._registered
-    pool.pin_large_outputs("reuse")  # the default policy: pageable the first time, page-locked from the second hand-out on
+    pool.pin_large_outputs("reuse")  # pageable the first time, page-locked from the second hand-out on
     r4 = hp.primal_fit(X, y, s, shift, scale, B, False, ctx=ctx)
     assert not pool._registered and np.array_equal(r4["L"][iu], L1)
     del r4
@@ -467,4 +467,5 @@ def test_large_factor_outputs_come_from_the_pool_and_can_be_page_locked(hp):
     del r5
     gc.collect()
     pool.release()
+    pool.pin_large_outputs(False)  # (the default)
     assert pool._pooled_bytes() == 0 and not pool._registered

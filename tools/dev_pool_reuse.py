@@ -7,6 +7,9 @@ import neo_ls_svm_amd as hp
 from neo_ls_svm_amd import _hostpool as pool
 import bench
 n, d, D = 125000, 128, 4096
+policy = {"never": False, "reuse": "reuse", "always": True}[sys.argv[1] if len(sys.argv) > 1 else "reuse"]
+pool.pin_large_outputs(policy)
+print("policy", policy)
 ctx = hp.Context(0)
 shift, scale, B = bench.affine_params(n, d, D, ctx=ctx)
 X, y = bench.synth(n, d, 0, n); s = np.ones(n)

@@ -39,6 +39,8 @@ CONFIGS = {
     "c3q": dict(n=262_144, d=128, D=4096, G=1024, name="synthetic regression n=262144 d=128 D=4096 ORF, primal, G=1024"),
     # BASELINE.json configs[3]: dual path, binary classification, explicit n x n kernel + eigendecomposition gamma-sweep (G = 128)
     "c4": dict(n=10_000, d=256, G=128, dual=True, name="synthetic binary classification n=1e4 d=256, dual path (n x n RBF kernel, EVD gamma-sweep G=128)"),
+    # config 5 in miniature (tests: sigma sharding through the native communicator at world 8 on one GPU)
+    "c5s": dict(n=20_000, d=32, D=512, G=32, sigmas=16, name="gamma x sigma LOO grid 32 x 16, n=2e4 d=32 D=512 ORF, primal"),
     # small plumbing configuration for quick checks
     "c0": dict(n=20_000, d=32, D=512, G=1024, name="synthetic regression n=2e4 d=32 D=512 ORF, primal, G=1024"),
 }
@@ -471,17 +473,16 @@ def main():
         if cctx is not None:
             cctx.comm_barrier()
 
-    def allreduce_sum(a):
-        flat = np.ascontiguousarray(a, dtype=np.float64).ravel()
-        return cctx.comm_allreduce(flat, "sum").reshape(np.shape(a))
-
     def step(X_=dX, y_=dy, s_=ds):
         if grid_mode:
             sig = np.logspace(np.log10(0.25), np.log10(4.0), cfg["sigmas"])
+            # ONE library call per grid (nls_primal_fit_grid): visiting order, early-out, tie rules and - through the communicator-only
+            # context - the merge of the small tables all happen behind the C ABI
             g = hp.primal_fit_sigma_grid(X_, y_, s_, shift, scale, B, False, sig, gammas=gammas, ctx=ctx, rank=rank, world=world,
-                                         allreduce_sum=allreduce_sum if world > 1 else None)  # fmt: skip
+                                         merge_ctx=cctx if world > 1 else None)  # fmt: skip
             best = g["best"] or {}
-            return {"opt": g["gamma_index"], "sigma_index": g["sigma_index"], "loo_score": best.get("loo_score"), "timings": g["timings"]}
+            return {"opt": g["gamma_index"], "sigma_index": g["sigma_index"], "loo_score": best.get("loo_score"), "timings": g["timings"],
+                    "finished_count": g["finished_count"]}  # fmt: skip
         # row-sharded fit: every rank ends with the same beta / lam / curve; the factor L_ (an output only) is produced and downloaded by rank 0
         return hp.primal_fit(X_, y_, s_, shift, scale, B, False, gammas=gammas, ctx=ctx, want_L=(rank == 0))
 
@@ -578,6 +579,7 @@ def main():
                 "parallelism": (f"sigma-shard x{world}, rows replicated" if grid_mode else f"row-shard x{world}, RCCL all-reduce of A||b") if world > 1 else "single GPU",
                 "affine": f"package pre-step (AffineSeparator + ORF RandomState 42) fitted on the first {min(n, PRESTEP_PREFIX)} rows (SURVEY 8d)",
                 "gamma_index": r["opt"],
+                "sigma_index": r.get("sigma_index"),
                 "loo_score": r["loo_score"],
                 "outputs": "every fitted attribute downloaded inside the timed region; L_ into one of two host buffers reserved (page-locked) before the warm-up, as a C caller's reused output buffer would be",
                 "generator": "SURVEY 8(d) (X ~ N(0,1), w ~ N(0,1)/sqrt(d), y = sin(Xw) + 0.1 eps) with w from default_rng(0) and the rows of "

@@ -61,7 +61,7 @@ extern "C" {
 #define NLS_ERR_LINALG 3
 #define NLS_ERR_COMM 4
 
-#define NLS_ABI_VERSION 2
+#define NLS_ABI_VERSION 3
 #define NLS_NUM_TIMINGS 24
 
 typedef struct nls_ctx nls_ctx;
@@ -247,6 +247,79 @@ typedef struct nls_primal_fit_args {
 #define NLS_T_ROW_CHUNK 20       /* rows per chunk used                                       */
 
 int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* args);
+
+/* ---- gamma x sigma leave-one-out grid (BASELINE config 5; SURVEY.md 8(b): the `sigmas[Sg]` / `sigma_idx` / `loo_errors[Sg G]` arguments of
+ * the nls_primal_fit row, 8(d): its definition) ----------------------------------------------------------------------------------------
+ * The reference fixes the kernel bandwidth in closed form (_affine_separator.py:200-209); the grid extends the search with multipliers
+ * sigma_k that divide the folded projection (T / sigma_k, i.e. B / sigma_k).  For every sigma one fit runs P2-P7 on args->gammas - ONE
+ * eigendecomposition per sigma is the factorisation all gammas reuse (_neo_ls_svm.py:120,146-150) - and the (sigma, gamma) pair with the
+ * smallest selection objective wins.  What the call does, in this order:
+ *   1. this rank's sigmas (k = rank, rank + world, ...) are visited nearest to 1 first (|ln sigma_k| ascending, ties by index): sigma = 1
+ *      is the separator's own bandwidth, so the incumbent is good from the start;
+ *   2. the first sigma is finished unconditionally (P8 / P9: Cholesky re-solve, row outputs, L); a later one only when its selected
+ *      objective is STRICTLY below the incumbent's (NLS_FIT_FINISH_IF_BELOW) - its outputs then replace the incumbent's in args' buffers;
+ *   3. with world > 1 and a merge context the Sg x G tables (each sigma owned by one rank, zeros elsewhere) are summed over the ranks;
+ *      without one the rows of the other ranks' sigmas are NaN;
+ *   4. sigma_index = first minimum over the owned sigmas of min_g objective[k][g] (numpy.argmin: ties go to the SMALLEST index); unmerged,
+ *      a tie that includes the finished incumbent goes to the incumbent (it carries the full result); gamma_index = argmin_g of that row.
+ * args: as for nls_primal_fit, with args->B the UNSCALED projection; args->gamma_index_in must be -1 and args->flags 0.  The row / factor /
+ * beta outputs of args hold the winner's full result iff *best_valid == 1 (always on one rank; after a merge on the rank that owns the
+ * winning sigma); args->loo_errors / objective / gamma_index / lam receive the winning sigma's curve, selected index and spectrum when it
+ * was fitted by this rank.  merge: a context that has joined a communicator (nls_comm_init_rank) and is NOT the fitting context - a fitting
+ * context inside a communicator makes every fit a row-sharded collective - or NULL. */
+typedef struct nls_sigma_grid {
+  const double* sigmas;    /* Sg   multipliers, > 0                                                     */
+  int32_t Sg;
+  int32_t rank, world;     /* sigma sharding: this call fits k = rank, rank + world, ... (0, 1: all)     */
+  nls_ctx* merge;          /* communicator-only context for the merge of the small tables, or NULL       */
+  double* loo_errors;      /* Sg x G   s @ |e_loo| per (sigma, gamma)                  (may be NULL)     */
+  double* objective;       /* Sg x G   the selection objective                         (may be NULL)     */
+  double* seconds;         /* Sg       wall time of each sigma's fit                   (may be NULL)     */
+  int32_t* sigma_index;    /* 1        winning sigma                                                     */
+  int32_t* gamma_index;    /* 1        winning gamma index of that sigma                                 */
+  int32_t* best_valid;     /* 1        1: args' beta / L / row outputs are the winner's full result      */
+  int32_t* finished_count; /* 1        how many of this rank's sigmas ran P8 / P9      (may be NULL)     */
+  double* timings;         /* NLS_NUM_TIMINGS  stage seconds summed over this rank's sigmas (may be NULL) */
+} nls_sigma_grid;
+int nls_primal_fit_grid(nls_ctx* ctx, const nls_primal_fit_args* args, const nls_sigma_grid* grid);
+/* Test hooks of the grid's bookkeeping (host arithmetic only, no GPU needed).  nls_grid_visiting_order: step 1 - order[] receives this
+ * rank's sigma indices in visiting order, the return value is their count.  nls_grid_select: step 4 on an Sg x G objective table with
+ * owned[k] != 0 marking the rows that count; incumbent >= 0: the unmerged tie rule (a tie that includes it goes to it), -1: merged. */
+int nls_grid_visiting_order(const double* sigmas, int Sg, int rank, int world, int32_t* order);
+int nls_grid_select(const double* objective, const unsigned char* owned, int Sg, int G, int incumbent, int32_t* sigma_index, int32_t* gamma_index);
+
+/* ---- several GPUs behind ONE handle and ONE host call (`nls_ctx_create(const int* devs, int ndev, ...)`, "multi-GPU is
+ * internal to the ctx ... the Python surface is identical at 1 and 8 GPUs"; 8(e)) -------------------------------------------------------
+ * A group owns one context per listed device and, for ndev > 1, an RCCL communicator that joins them (several ranks of ONE process, one
+ * per device: librccl is loaded on first use).  Every group call fans out to one short-lived host thread per device, each driving its own
+ * context, stream and collectives - exactly the per-rank code path of the process-per-GPU launch (nls_comm_init_rank + nls_primal_fit per
+ * rank), so the two deployments cannot diverge.
+ *   nls_group_primal_fit     args as nls_primal_fit with n = ALL rows and HOST pointers X, y, s (device pointers only when every member
+ *                            context sits on the device that holds them); rank r takes the contiguous row block [n r / ndev, n (r + 1) / ndev)
+ *                            (_neo_ls_svm.py:110: s is normalised by the GLOBAL sum; one all-reduce of the packed Hermitian block A || b
+ *                            before the eigendecomposition); row outputs land in the caller's n-vectors at the block's offset, the
+ *                            replicated outputs (beta, L, lam, curves, score, timings) are rank 0's.  n >= ndev.
+ *   nls_group_primal_fit_grid  the gamma x sigma grid with the SIGMAS dealt over the devices (every device holds all rows, no collective in
+ *                            the data path; the tables are merged on the host); grid->rank / world / merge must be 0 / 1 / NULL.
+ *   nls_group_primal_predict query rows sharded the same way; factor: a group factor (U^-1 resident on every member) or NULL with L.
+ * The dual path does not shard (its n x n eigendecomposition): use nls_group_ctx(group, 0) with nls_dual_fit ("replicas only").
+ * devices may name one device several times ONLY with a communication library that allows it (the test stand-in of tests/csrc/rccl_shim.cpp;
+ * RCCL itself refuses two ranks on one device). */
+typedef struct nls_group nls_group;
+typedef struct nls_group_factor nls_group_factor;
+int nls_group_create(const int* devices, int ndev, nls_group** group);
+void nls_group_destroy(nls_group* group);
+/* Message of the last failure of a group call (group == NULL: of nls_group_create); names the rank that failed first. */
+const char* nls_group_last_error(const nls_group* group);
+int nls_group_size(const nls_group* group);
+/* Member context of rank r (owned by the group): pre-step statistics on rank 0, workspace limits, the dual path. */
+nls_ctx* nls_group_ctx(nls_group* group, int rank);
+int nls_group_primal_fit(nls_group* group, const nls_primal_fit_args* args);
+int nls_group_primal_fit_grid(nls_group* group, const nls_primal_fit_args* args, const nls_sigma_grid* grid);
+int nls_group_factor_create(nls_group* group, const double* L, int D, nls_group_factor** factor);
+int nls_group_factor_destroy(nls_group* group, nls_group_factor* factor);
+int nls_group_primal_predict(nls_group* group, const double* X, int64_t m, int d, const double* shift, const double* scale, const double* B,
+                             int D, const double* beta, const double* L, const nls_group_factor* factor, double* yhat, double* sigma);
 
 /* Test hook of the compressed gamma sweep (host arithmetic only, no GPU needed).  For a strictly increasing positive grid of
  * more than 256 points spanning at most e^17.2 (the reference's: 2e7) nls_primal_fit evaluates the rational functions of _neo_ls_svm.py:146-149 at NLS_SWEEP_NODES

@@ -1,10 +1,11 @@
 """MI355X-native implementation of the neo-ls-svm fit/predict hot path.
 
 Host code is Python + NumPy marshalling over a ctypes C ABI (``include/neolssvm_hip.h``) into
-hand-written HIP kernels for gfx950 plus rocSOLVER for the dense EVD / Cholesky.  No CPU fallback.
+hand-written HIP kernels for gfx950 (feature map, Gram, eigendecompositions, sweeps, Cholesky factorisations); rocBLAS serves the blocked
+back-transformations and rocSOLVER one triangular inverse behind ``predict_std``.  No CPU fallback.
 """
 
-from ._lib import Context, DeviceArray, Factor, NlsError, default_context, load_library, set_default_context  # noqa: F401
+from ._lib import Context, DeviceArray, Factor, Group, GroupFactor, NlsError, default_context, default_group, load_library, set_default_context  # noqa: F401
 from ._hostpool import pin_large_outputs  # noqa: F401
 from ._hostpool import reserve as reserve_factor_outputs  # noqa: F401
 from .hotpath import (  # noqa: F401
@@ -17,6 +18,7 @@ from .hotpath import (  # noqa: F401
     gram,
     orf_frequencies,
     primal_fit,
+    primal_fit_sharded,
     primal_fit_sigma_grid,
     primal_predict,
     rotate,
@@ -46,6 +48,9 @@ __all__ = [
     "pin_large_outputs",
     "reserve_factor_outputs",
     "Context",
+    "Group",
+    "GroupFactor",
+    "default_group",
     "DeviceArray",
     "Factor",
     "NlsError",
@@ -54,6 +59,7 @@ __all__ = [
     "featuremap",
     "gram",
     "primal_fit",
+    "primal_fit_sharded",
     "primal_fit_sigma_grid",
     "primal_predict",
     "dual_fit",

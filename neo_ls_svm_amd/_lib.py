@@ -17,7 +17,7 @@ _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("NEOLSSVM_HIP_LIB", _HERE / "libneolssvm_hip.so"))
 
 NLS_OK, NLS_ERR_ARG, NLS_ERR_HIP, NLS_ERR_LINALG, NLS_ERR_COMM = 0, 1, 2, 3, 4
-ABI_VERSION = 2
+ABI_VERSION = 3
 FIT_SWEEP_ONLY, FIT_FINISH_IF_BELOW = 1, 2
 COMM_ID_BYTES = 128
 NUM_TIMINGS = 24
@@ -82,6 +82,26 @@ class PrimalFitArgs(C.Structure):
         ("loo_score", C.c_void_p),
         ("gamma_index", C.c_void_p),
         ("finished", C.c_void_p),
+        ("timings", C.c_void_p),
+    ]
+
+
+class SigmaGrid(C.Structure):
+    """Mirror of ``nls_sigma_grid``."""
+
+    _fields_ = [
+        ("sigmas", C.c_void_p),
+        ("Sg", C.c_int32),
+        ("rank", C.c_int32),
+        ("world", C.c_int32),
+        ("merge", C.c_void_p),
+        ("loo_errors", C.c_void_p),
+        ("objective", C.c_void_p),
+        ("seconds", C.c_void_p),
+        ("sigma_index", C.c_void_p),
+        ("gamma_index", C.c_void_p),
+        ("best_valid", C.c_void_p),
+        ("finished_count", C.c_void_p),
         ("timings", C.c_void_p),
     ]
 
@@ -160,6 +180,23 @@ SIGNATURES = {
     "nls_evd_stage_ms": (C.c_int, [C.c_void_p, C.c_void_p]),
     "nls_stedc_only": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "nls_primal_fit": (C.c_int, [C.c_void_p, C.POINTER(PrimalFitArgs)]),
+    "nls_primal_fit_grid": (C.c_int, [C.c_void_p, C.POINTER(PrimalFitArgs), C.POINTER(SigmaGrid)]),
+    "nls_grid_select": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "nls_grid_visiting_order": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "nls_group_create": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),
+    "nls_group_destroy": (None, [C.c_void_p]),
+    "nls_group_last_error": (C.c_char_p, [C.c_void_p]),
+    "nls_group_size": (C.c_int, [C.c_void_p]),
+    "nls_group_ctx": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "nls_group_primal_fit": (C.c_int, [C.c_void_p, C.POINTER(PrimalFitArgs)]),
+    "nls_group_primal_fit_grid": (C.c_int, [C.c_void_p, C.POINTER(PrimalFitArgs), C.POINTER(SigmaGrid)]),
+    "nls_group_factor_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "nls_group_factor_destroy": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "nls_group_primal_predict": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        + [C.c_void_p, C.c_void_p, C.c_void_p],
+    ),
     "nls_sweep_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
     "nls_primal_predict": (
         C.c_int,
@@ -317,13 +354,17 @@ class Factor:
 class Context:
     """One context per process and GPU: stream, rocBLAS/rocSOLVER handles, grow-only workspace."""
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, _borrowed=None):
         self.lib = load_library()
-        h = C.c_void_p()
-        rc = self.lib.nls_ctx_create(int(device), C.byref(h))
-        if rc != NLS_OK:
-            msg = self.lib.nls_last_error(None)
-            raise NlsError(f"nls_ctx_create failed: {msg.decode() if msg else rc}")
+        self._owned = _borrowed is None
+        if _borrowed is None:
+            h = C.c_void_p()
+            rc = self.lib.nls_ctx_create(int(device), C.byref(h))
+            if rc != NLS_OK:
+                msg = self.lib.nls_last_error(None)
+                raise NlsError(f"nls_ctx_create failed: {msg.decode() if msg else rc}")
+        else:  # a member context of a Group (nls_group_ctx): the group owns and destroys it
+            h = C.c_void_p(_borrowed)
         self.handle = h
         self.device = int(device)
         self.comm_world = 1  # world size of the native communicator this context has joined (1: none, or one rank)
@@ -339,7 +380,8 @@ class Context:
             dev, self._hold_cache = getattr(self, "_hold_cache", None), None
             if dev is not None:
                 dev.free()
-            self.lib.nls_ctx_destroy(self.handle)
+            if self._owned:
+                self.lib.nls_ctx_destroy(self.handle)
             self.handle = None
 
     def __del__(self):
@@ -497,7 +539,104 @@ class Context:
         self._check(self.lib.nls_set_allreduce(self.handle, self._hook, None, int(rank), int(world)))
 
 
+class GroupFactor:
+    """``Factor`` for a group: U^-1 of one fitted ``L_`` resident on every member device (``nls_group_factor_create``)."""
+
+    def __init__(self, group: "Group", L: np.ndarray):
+        L = np.ascontiguousarray(L, dtype=np.complex128)
+        if L.ndim != 2 or L.shape[0] != L.shape[1] or L.shape[0] < 2:
+            raise ValueError("L must be a (D+1) x (D+1) complex matrix")
+        self.ctx, self.D = group, L.shape[0] - 1
+        h = C.c_void_p()
+        group._check(group.lib.nls_group_factor_create(group.handle, L.ctypes.data, self.D, C.byref(h)))
+        self.handle = h
+
+    def close(self):
+        if getattr(self, "handle", None) and getattr(self.ctx, "handle", None):
+            self.ctx.lib.nls_group_factor_destroy(self.ctx.handle, self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Group:
+    """Several GPUs behind one handle (``nls_group_create``; SURVEY.md 8(b): "multi-GPU is internal to the ctx ... the Python surface is
+    identical at 1 and 8 GPUs").  One member context per listed device, joined by an RCCL communicator inside the library; ``hotpath.primal_fit``
+    / ``primal_predict`` / ``primal_fit_sigma_grid`` take a Group wherever they take a Context, and ``NeoLSSVM(devices=[...])`` builds one.
+    A group call blocks the calling thread (ctypes releases the GIL) while the library drives one host thread per device."""
+
+    def __init__(self, devices):
+        self.lib = load_library()
+        self.devices = tuple(int(d) for d in devices)
+        if not self.devices:
+            raise ValueError("devices must name at least one GPU")
+        arr = (C.c_int * len(self.devices))(*self.devices)
+        h = C.c_void_p()
+        with _StdoutToStderr():  # (librccl's version banner, as in Context.comm_init)
+            rc = self.lib.nls_group_create(arr, len(self.devices), C.byref(h))
+        if rc != NLS_OK:
+            msg = self.lib.nls_group_last_error(None)
+            raise_for(rc, f"nls_group_create failed: {msg.decode() if msg else rc}")
+        self.handle = h
+        self.device = self.devices[0]
+        self.contexts = [Context(d, _borrowed=self.lib.nls_group_ctx(h, r)) for r, d in enumerate(self.devices)]
+        for c in self.contexts:
+            c.comm_world = len(self.devices)
+
+    @property
+    def size(self) -> int:
+        return len(self.devices)
+
+    def _check(self, rc: int):
+        if rc != NLS_OK:
+            msg = self.lib.nls_group_last_error(self.handle)
+            raise_for(rc, msg.decode() if msg else f"error {rc}")
+
+    # the estimator's single-device plumbing (pre-step statistics, the dual path: "replicas only") runs on rank 0's context
+    def hold(self, a):
+        return self.contexts[0].hold(a)
+
+    def held(self, a):
+        return a  # a group fit takes host rows: every rank uploads its own block
+
+    def evd_stage_ms(self):
+        return self.contexts[0].evd_stage_ms()
+
+    def synchronize(self):
+        for c in self.contexts:
+            c.synchronize()
+
+    def release_workspace(self, min_bytes: int = 0) -> int:
+        return sum(c.release_workspace(min_bytes) for c in self.contexts)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            for c in self.contexts:
+                c.close()  # (borrowed handles: drops the cached device copies only)
+            self.lib.nls_group_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 _default_ctx: dict[int, Context] = {}
+_default_group: dict[tuple, Group] = {}
+
+
+def default_group(devices) -> Group:
+    """The process-wide group of this device tuple (created on first use, like ``default_context``)."""
+    key = tuple(int(d) for d in devices)
+    if key not in _default_group:
+        _default_group[key] = Group(key)
+    return _default_group[key]
 
 
 def set_default_context(ctx: Context) -> None:

@@ -3,14 +3,16 @@
 // carries another copy of the ROCm communication library, e.g. an imported torch, is left alone).
 #include <dlfcn.h>
 
+#include <mutex>
+
 #include "nls_host.h"
 
 const RcclApi* rccl_api(std::string* why) {
   static RcclApi api;
-  static bool tried = false, ok = false;
+  static bool ok = false;
   static std::string err;
-  if (!tried) {
-    tried = true;
+  static std::once_flag once;  // (the ranks of a group - several host threads of one process - may arrive here together)
+  std::call_once(once, [] {
     void* h = nullptr;
     // NLS_RCCL_LIB: an explicit path (a non-standard install; the test stand-in of tests/csrc/rccl_shim.cpp) - tried alone when set
     const char* explicit_lib = std::getenv("NLS_RCCL_LIB");
@@ -43,7 +45,7 @@ const RcclApi* rccl_api(std::string* why) {
       api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(sym("ncclGroupEnd"));
       api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
     }
-  }
+  });
   if (!ok && why) *why = err;
   return ok ? &api : nullptr;
 }

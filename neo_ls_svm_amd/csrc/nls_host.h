@@ -67,6 +67,7 @@ struct nls_ctx {
   nls_allreduce_fn allreduce = nullptr;
   void* allreduce_user = nullptr;
   int rank = 0, world = 1;
+  bool solo = false;  // set by the group's sigma-sharded grid: the context fits alone although it has joined the group's communicator
   ncclComm_t comm = nullptr;  // native RCCL communicator (nls_comm_init_rank); takes precedence over the hook
   double* comm_scratch = nullptr;  // a few doubles on the device for nls_comm_allreduce
   size_t ws_bytes = 0;        // bytes currently held by the workspace arena
@@ -246,7 +247,7 @@ struct SpanGuard {  // RAII so early returns still close the span
 
 // A native communicator always takes the collective path, also with one rank (the RCCL calls then run on the device
 // buffers for real: how the single-GPU box validates them); a hook only matters with more than one rank.
-static inline bool multi_rank(const nls_ctx* ctx) { return ctx->comm != nullptr || (ctx->world > 1 && ctx->allreduce); }
+static inline bool multi_rank(const nls_ctx* ctx) { return !ctx->solo && (ctx->comm != nullptr || (ctx->world > 1 && ctx->allreduce)); }
 
 static int do_allreduce(nls_ctx* ctx, double* dbuf, size_t count) {
   if (!multi_rank(ctx)) return NLS_OK;

@@ -5,3 +5,4 @@
 #include "nls_lib.hip"
 #include "nls_dual.hip"
 #include "nls_prestep.hip"
+#include "nls_group.hip"

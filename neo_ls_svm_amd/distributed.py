@@ -47,6 +47,19 @@ def _rendezvous_files(key: str | None) -> tuple[Path, Path | None]:
     return base / f"nls_rccl_id_{os.getppid()}_{port}_{run}_{attempt}", base / f"nls_rccl_id_port{port}_{run}_{attempt}"
 
 
+def _launch_nonce() -> bytes:
+    """What the ranks of ONE launch share and a previous launch does not: NLS_RENDEZVOUS_NONCE when the launcher sets it, else the
+    launcher's process id (all ranks of a launch are children of one launcher process), the rendezvous port, the elastic run id and
+    restart count.  Rank 0 writes it into the payload; a reader joins only a payload that carries ITS OWN nonce - so an id file that a
+    dead launch left under the same explicit key (its post-barrier unlink never ran) is not joined by the next launch's ranks while
+    they wait for their rank 0 to replace it."""
+    explicit = os.environ.get("NLS_RENDEZVOUS_NONCE")
+    if explicit:
+        return explicit.encode()
+    port, run = os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none")
+    return f"{os.getppid()}_{port}_{run}_{os.environ.get('TORCHELASTIC_RESTART_COUNT', '0')}".encode()
+
+
 def _fresh_seconds() -> float:
     """How long a published id stays joinable (NLS_RENDEZVOUS_FRESH_SECONDS, read at call time; default 900 s)."""
     return float(os.environ.get("NLS_RENDEZVOUS_FRESH_SECONDS", "900"))
@@ -68,17 +81,19 @@ def _publish(path: Path, payload: bytes) -> None:
 
 
 def _read_fresh(path: Path, explicit_key: bool) -> bytes | None:
-    """The 128-byte id of a payload `id || repr(time)`.  A file under an explicit key is the caller's own rendezvous: it is accepted
-    as it is.  An automatic (launcher-derived) name could be a leftover of a launch that died between publishing and the post-barrier
-    unlink, so it is accepted only while fresh - judged by the file's OWN modification time against the clock of the machine that
-    reads it, both taken from the same filesystem view (no assumption that the ranks' clocks agree with the publisher's)."""
+    """The 128-byte id of a payload `id || repr(time) || "|" || nonce`.  Either kind of file could be a leftover of a launch that died
+    between publishing and the post-barrier unlink.  A file under an explicit key is the caller's own rendezvous, joined whatever its
+    age (a rank may arrive long after rank 0 published) - but only when it carries this launch's nonce (`_launch_nonce`).  An automatic
+    (launcher-derived) name is accepted only while fresh - judged by the file's OWN modification time against the clock of the machine
+    that reads it, both taken from the same filesystem view (no assumption that the ranks' clocks agree with the publisher's)."""
     try:
         raw = path.read_bytes()
         if len(raw) <= 128:
             return None
-        float(raw[128:].decode())  # well-formed payload
+        stamp, _, nonce = raw[128:].partition(b"|")
+        float(stamp.decode())  # well-formed payload
         if explicit_key:
-            return raw[:128]
+            return raw[:128] if nonce == _launch_nonce() else None
         probe = path.with_name(f"{path.name}.probe{os.getpid()}")
         try:  # "now" as the filesystem that holds the file sees it (a shared directory may be served by another clock)
             fd = os.open(probe, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, "O_NOFOLLOW", 0), 0o600)
@@ -95,13 +110,14 @@ def _read_fresh(path: Path, explicit_key: bool) -> bytes | None:
 
 
 def exchange_unique_id(ctx, rank: int, world: int, key: str | None = None, timeout: float = 300.0) -> bytes:
-    """Rank 0 creates the communicator id and publishes it (atomic rename); the other ranks wait for a FRESH file."""
+    """Rank 0 creates the communicator id and publishes it (atomic rename, replacing whatever a previous launch left under the name); the
+    other ranks wait for a file of THIS launch (explicit key: its nonce; automatic name: fresh)."""
     primary, secondary = _rendezvous_files(key)
     if rank == 0:
         uid = ctx.comm_unique_id()
         for path in (primary, secondary):
             if path is not None:
-                _publish(path, uid + repr(time.time()).encode())
+                _publish(path, uid + repr(time.time()).encode() + b"|" + _launch_nonce())
         return uid
     t0 = time.monotonic()
     while True:

@@ -29,7 +29,7 @@ from sklearn.utils.validation import check_array, check_consistent_length, check
 
 from . import _prestep, hotpath
 from .conformal import conformal_delta_quantiles
-from ._lib import default_context
+from ._lib import Group, default_context, default_group
 
 __all__ = ["NeoLSSVM", "AffineFeatureMap", "AffineNormalizer", "AffineSeparator", "RandomFourierFeatures", "OrthogonalRandomFourierFeatures"]
 
@@ -113,11 +113,11 @@ class AffineSeparator(AffineFeatureMap):
         self.random_state = random_state
         self.device = device
 
-    def fit(self, X, y, sample_weight=None, ctx=None):
+    def fit(self, X, y, sample_weight=None, ctx=None, _validated=False):
         """``ctx``: the context (hence GPU) that runs the bin statistics; default: the context of ``self.device``.
-        ``NeoLSSVM.fit`` hands its own context down so that X is uploaded once, to the estimator's device (and has validated X, y itself:
-        a second finiteness pass over a 1 GB matrix is 40 ms)."""
-        if ctx is None or not (isinstance(X, np.ndarray) and X.dtype == np.float64 and X.ndim == 2):
+        ``NeoLSSVM.fit`` hands its own context down so that X is uploaded once, to the estimator's device, and - having validated X, y
+        itself - sets the private ``_validated`` (a second finiteness pass over a 1 GB matrix is 40 ms); every other caller is validated here."""
+        if not (_validated and isinstance(X, np.ndarray) and X.dtype == np.float64 and X.ndim == 2 and X.flags.c_contiguous):
             X, y = check_X_y(X, y, dtype=np.float64)
         ctx = ctx or default_context(int(self.device))
 
@@ -138,11 +138,14 @@ class AffineSeparator(AffineFeatureMap):
         return self
 
 
-def _fit_affine(fm, X, y, sample_weight, ctx):
+def _fit_affine(fm, X, y, sample_weight, ctx, _validated=False):
     """Fit a (possibly caller-supplied) affine map; this package's classes take the context so that X is uploaded once.
     The fitted object must expose (shift, scale, A) - as parameters or fitted attributes, the reference's convention
     (``_affine_feature_map.py:49-51``) - or it is not an affine map this library can fold into its feature map."""
-    fitted = fm.fit(X, y, sample_weight, ctx=ctx) if isinstance(fm, AffineFeatureMap) else fm.fit(X, y, sample_weight)
+    if isinstance(fm, AffineSeparator):
+        fitted = fm.fit(X, y, sample_weight, ctx=ctx, _validated=_validated)
+    else:
+        fitted = fm.fit(X, y, sample_weight, ctx=ctx) if isinstance(fm, AffineFeatureMap) else fm.fit(X, y, sample_weight)
     fitted = fm if fitted is None else fitted
     if _affine_params(fitted) is None:
         raise TypeError(f"{type(fm).__name__} is not an affine map: after fit it exposes no shift / scale / A (parameters or fitted attributes)")
@@ -168,9 +171,9 @@ class RandomFourierFeatures(BaseEstimator):
         self.exact_complexity = exact_complexity
         self.orthogonal = orthogonal
 
-    def fit(self, X, y=None, sample_weight=None, ctx=None):
+    def fit(self, X, y=None, sample_weight=None, ctx=None, _validated=False):
         afm = _as_own_affine_map(self.affine_feature_map)
-        self.affine_feature_map_ = _fit_affine(AffineSeparator() if afm is None else clone(afm), X, y, sample_weight, ctx)
+        self.affine_feature_map_ = _fit_affine(AffineSeparator() if afm is None else clone(afm), X, y, sample_weight, ctx, _validated)
         shift, scale, A = _affine_params(self.affine_feature_map_)
         A = None if A is None else np.asarray(A, dtype=np.float64)
         d_in = A.shape[1] if A is not None else np.asarray(X).shape[1]
@@ -266,6 +269,7 @@ class NeoLSSVM(BaseEstimator):
         estimator_type="auto",
         random_state=42,
         device=0,
+        devices=None,
         release_workspace=False,
     ):
         self.primal_feature_map = primal_feature_map
@@ -274,6 +278,7 @@ class NeoLSSVM(BaseEstimator):
         self.random_state = random_state
         self.estimator_type = estimator_type
         self.device = device
+        self.devices = devices
         self.release_workspace = release_workspace
 
     # ---- sklearn plumbing -------------------------------------------------------------------
@@ -294,7 +299,18 @@ class NeoLSSVM(BaseEstimator):
         return tags
 
     def _ctx(self):
-        return default_context(int(self.device))
+        """Where this estimator computes: the context of ``device``, or - ``devices=[...]`` with more than one GPU - the process-wide
+        ``Group`` of those devices: the primal fit, ``decision_function`` and ``predict_std`` then shard their rows over the GPUs inside ONE
+        library call each (the surface is identical at 1 and 8 GPUs); the pre-step statistics and the dual path (its n x n
+        eigendecomposition does not shard: "replicas only") run on the first device."""
+        devs = getattr(self, "devices", None)
+        if devs is not None and len(devs) > 1:
+            return default_group(devs)
+        return default_context(int(devs[0] if devs else self.device))
+
+    @staticmethod
+    def _ctx0(ctx):
+        return ctx.contexts[0] if isinstance(ctx, Group) else ctx
 
     # The inverse Cholesky factor predict_std needs lives on the device between calls as an explicit handle owned by
     # this estimator: created on the first predict_std after a fit, dropped on refit, never pickled.
@@ -307,7 +323,7 @@ class NeoLSSVM(BaseEstimator):
         f = self.__dict__.get("_factor")
         if f is None or f.ctx is not ctx or not f.handle:
             self._drop_factor()
-            f = self.__dict__["_factor"] = hotpath.Factor(ctx, self.L_[0])
+            f = self.__dict__["_factor"] = (hotpath.GroupFactor if isinstance(ctx, Group) else hotpath.Factor)(ctx, self.L_[0])
         return f
 
     def __getstate__(self):
@@ -351,8 +367,8 @@ class NeoLSSVM(BaseEstimator):
         t0 = time.perf_counter()
         if self.primal_:
             fm = OrthogonalRandomFourierFeatures() if isinstance(self.primal_feature_map, str) else _as_own_feature_map(self.primal_feature_map)
-            with ctx.hold(X):  # one upload of X serves the pre-step's bin statistics and the solver
-                self.primal_feature_map_ = clone(fm).fit(X, y_, sw, ctx=ctx)
+            with ctx.hold(X):  # one upload of X serves the pre-step's bin statistics and the solver (a group: every rank uploads its own row block)
+                self.primal_feature_map_ = clone(fm).fit(X, y_, sw, ctx=self._ctx0(ctx), _validated=True)
                 shift, scale, B = self.primal_feature_map_.map_params
                 Cm = self.primal_feature_map_.complexity_matrix if self.primal_feature_map_.exact_complexity else None
                 wall["prestep"] = time.perf_counter() - t0
@@ -366,11 +382,11 @@ class NeoLSSVM(BaseEstimator):
             sep = AffineSeparator() if isinstance(self.dual_feature_map, str) else _as_own_affine_map(self.dual_feature_map)
             if sep is None:
                 raise TypeError("dual_feature_map must be 'auto' or an affine map")
-            self.dual_feature_map_ = _fit_affine(clone(sep), X, y_, sw, ctx)
+            self.dual_feature_map_ = _fit_affine(clone(sep), X, y_, sw, self._ctx0(ctx), _validated=True)
             self.X_ = np.ascontiguousarray(self._dual_transform(X))
             wall["prestep"] = time.perf_counter() - t0
             t0 = time.perf_counter()
-            r = hotpath.dual_fit(self.X_, y_, sw, is_clf, ctx=ctx)
+            r = hotpath.dual_fit(self.X_, y_, sw, is_clf, ctx=self._ctx0(ctx))
             self.α̂_, self.γ_ = r["alpha"], r["gamma"]
         wall["solver"] = time.perf_counter() - t0
         t0 = time.perf_counter()
@@ -459,7 +475,7 @@ class NeoLSSVM(BaseEstimator):
             yhat, _ = hotpath.primal_predict(Xa, shift, scale, B, beta=self.β̂_, ctx=self._ctx())
         else:
             Xq = np.ascontiguousarray(self._dual_transform(Xa))
-            yhat, _ = hotpath.dual_predict(Xq, self.X_, alpha=self.α̂_, ctx=self._ctx())
+            yhat, _ = hotpath.dual_predict(Xq, self.X_, alpha=self.α̂_, ctx=self._ctx0(self._ctx()))
         return _series_like(yhat, X)
 
     def predict_std(self, X):
@@ -471,7 +487,7 @@ class NeoLSSVM(BaseEstimator):
             _, sigma = hotpath.primal_predict(Xa, shift, scale, B, ctx=ctx, factor=self._factor_for(ctx))
         else:
             Xq = np.ascontiguousarray(self._dual_transform(Xa))
-            _, sigma = hotpath.dual_predict(Xq, self.X_, L=self.L_[0], ctx=self._ctx())
+            _, sigma = hotpath.dual_predict(Xq, self.X_, L=self.L_[0], ctx=self._ctx0(self._ctx()))
         return _series_like(sigma, X)
 
     def _yhat_sigma(self, Xa):
@@ -481,7 +497,7 @@ class NeoLSSVM(BaseEstimator):
             ctx = self._ctx()
             return hotpath.primal_predict(Xa, shift, scale, B, beta=self.β̂_, ctx=ctx, factor=self._factor_for(ctx))
         Xq = np.ascontiguousarray(self._dual_transform(Xa))
-        return hotpath.dual_predict(Xq, self.X_, alpha=self.α̂_, L=self.L_[0], ctx=self._ctx())
+        return hotpath.dual_predict(Xq, self.X_, alpha=self.α̂_, L=self.L_[0], ctx=self._ctx0(self._ctx()))
 
     def predict_quantiles(self, X, *, quantiles=(0.025, 0.5, 0.975), priority="accuracy"):
         """Conformally calibrated quantiles (``:554-624``): [m x q] for a regressor, [m x q x 2] class probabilities

@@ -17,7 +17,7 @@ import numpy as np
 from . import _lib
 from ._hostpool import factor_output
 from ._prestep import blas_threads
-from ._lib import Context, DeviceArray, DualFitArgs, Factor, PrimalFitArgs, default_context
+from ._lib import Context, DeviceArray, DualFitArgs, Factor, Group, GroupFactor, PrimalFitArgs, SigmaGrid, default_context, default_group
 
 __all__ = [
     "gamma_grid",
@@ -31,6 +31,7 @@ __all__ = [
     "eigh",
     "stedc",
     "primal_fit",
+    "primal_fit_sharded",
     "primal_fit_sigma_grid",
     "primal_predict",
     "dual_fit",
@@ -291,36 +292,9 @@ def bin_stats(X, labels, sample_weight=None, ctx: Context | None = None):
     return centers, spreads
 
 
-def primal_fit(
-    X,
-    y,
-    s,
-    shift,
-    scale,
-    B,
-    is_classifier: bool,
-    gammas=None,
-    gamma_index: int | None = None,
-    ctx: Context | None = None,
-    want_L: bool = True,
-    want_rows: bool = True,
-    sweep_only: bool = False,
-    finish_below: float | None = None,
-    complexity_matrix=None,
-) -> dict:
-    """Primal LS-SVM fit with the full gamma sweep (P1-P9).
-
-    X (n x d), y (n), s (n) may be NumPy arrays or ``DeviceArray`` s already resident in HBM.  Returns
-    a dict with the reference's attribute names (ASCII): beta, gamma, gammas, opt, loo_errors_gammas,
-    loo_residuals, loo_yhat (host input y only), loo_leverage, loo_error, loo_score, L (scipy ``cho_factor``
-    format, lower=False), residuals, loo_std, lam, timings.
-
-    ``sweep_only`` stops after the gamma selection (P1-P7); ``finish_below=t`` runs the Cholesky re-solve and the row
-    outputs only when the selected objective is below t (``out["finished"]`` says which) - how a gamma x sigma grid
-    avoids finishing sigmas that cannot win.  ``complexity_matrix``: None = identity (the reference's only reachable
-    case), else a (D+1) x (D+1) symmetric positive definite matrix -> generalised-EVD branch (``_neo_ls_svm.py:122-124``).
-    """
-    ctx = ctx or default_context()
+def _primal_args(X, y, s, shift, scale, B, is_classifier, gammas, gamma_index, ctx, want_L, want_rows, sweep_only, finish_below,
+                 complexity_matrix):
+    """Marshal one ``nls_primal_fit_args``: returns (args, out dict of the output arrays, keep-alive tuple)."""
     X = _f64(ctx.held(X), "X")
     if len(X.shape) != 2:
         raise ValueError("X must be 2-D")
@@ -338,7 +312,8 @@ def primal_fit(
         "objective": np.empty(G),
     }
     if want_L:
-        out["L"] = factor_output((D1, D1), np.complex128, ctx)  # only the upper triangle is defined (cho_factor layout; large factors arrive as the triangle alone)
+        pool_ctx = ctx.contexts[0] if isinstance(ctx, Group) else ctx  # (rank 0 downloads the factor)
+        out["L"] = factor_output((D1, D1), np.complex128, pool_ctx)  # only the upper triangle is defined (cho_factor layout; large factors arrive as the triangle alone)
     if want_rows:
         for k in ("loo_residuals", "loo_leverage", "loo_std", "residuals"):
             out[k] = np.empty(n)
@@ -370,22 +345,74 @@ def primal_fit(
     a.loo_score = C.addressof(score)
     a.gamma_index = C.addressof(opt)
     a.timings = tm.ctypes.data
-    ctx._check(ctx.lib.nls_primal_fit(ctx.handle, C.byref(a)))
+    return a, out, {"X": X, "y": y, "s": s, "shift": shift, "scale": scale, "B": B, "gammas": gammas, "Cm": Cm, "score": score, "opt": opt,
+                    "finished": finished, "tm": tm}  # fmt: skip
+
+
+def _primal_result(out, keep, want_rows):
+    gammas, opt, finished = keep["gammas"], keep["opt"], keep["finished"]
     out["gammas"] = gammas
     out["opt"] = int(opt.value)
     out["gamma"] = float(gammas[opt.value])
     out["loo_error"] = float(out["loo_errors_gammas"][opt.value])
     out["finished"] = bool(finished.value)
-    out["timings"] = timings_dict(tm)
+    out["timings"] = timings_dict(keep["tm"])
     if not out["finished"]:  # the curve only: drop the buffers P8 / P9 would have filled
         for k in ("beta", "L", "loo_residuals", "loo_leverage", "loo_std", "residuals"):
             out.pop(k, None)
         return out
-    out["loo_score"] = float(score.value)
+    out["loo_score"] = float(keep["score"].value)
     out["L_lower"] = False
-    if want_rows and not isinstance(y, DeviceArray):
-        out["loo_yhat"] = y + out["loo_residuals"]
+    if want_rows and not isinstance(keep["y"], DeviceArray):
+        out["loo_yhat"] = keep["y"] + out["loo_residuals"]
     return out
+
+
+def primal_fit(
+    X,
+    y,
+    s,
+    shift,
+    scale,
+    B,
+    is_classifier: bool,
+    gammas=None,
+    gamma_index: int | None = None,
+    ctx: Context | Group | None = None,
+    want_L: bool = True,
+    want_rows: bool = True,
+    sweep_only: bool = False,
+    finish_below: float | None = None,
+    complexity_matrix=None,
+) -> dict:
+    """Primal LS-SVM fit with the full gamma sweep (P1-P9).
+
+    X (n x d), y (n), s (n) may be NumPy arrays or ``DeviceArray`` s already resident in HBM.  Returns
+    a dict with the reference's attribute names (ASCII): beta, gamma, gammas, opt, loo_errors_gammas,
+    loo_residuals, loo_yhat (host input y only), loo_leverage, loo_error, loo_score, L (scipy ``cho_factor``
+    format, lower=False), residuals, loo_std, lam, timings.
+
+    ``ctx``: a ``Context`` (one GPU; inside a communicator: this rank's row block of a process-per-GPU launch) or a ``Group``
+    (several GPUs in this one call, ``nls_group_primal_fit``: rows sharded over the group's devices inside the library, outputs
+    as on one GPU).
+
+    ``sweep_only`` stops after the gamma selection (P1-P7); ``finish_below=t`` runs the Cholesky re-solve and the row
+    outputs only when the selected objective is below t (``out["finished"]`` says which) - how a gamma x sigma grid
+    avoids finishing sigmas that cannot win.  ``complexity_matrix``: None = identity (the reference's only reachable
+    case), else a (D+1) x (D+1) symmetric positive definite matrix -> generalised-EVD branch (``_neo_ls_svm.py:122-124``).
+    """
+    ctx = ctx or default_context()
+    a, out, keep = _primal_args(X, y, s, shift, scale, B, is_classifier, gammas, gamma_index, ctx, want_L, want_rows, sweep_only, finish_below,
+                                complexity_matrix)  # fmt: skip
+    fn = ctx.lib.nls_group_primal_fit if isinstance(ctx, Group) else ctx.lib.nls_primal_fit
+    ctx._check(fn(ctx.handle, C.byref(a)))
+    return _primal_result(out, keep, want_rows)
+
+
+def primal_fit_sharded(X, y, s, shift, scale, B, is_classifier: bool, devices, **kw) -> dict:
+    """``primal_fit`` with the rows sharded over ``devices`` (GPU ordinals) in ONE call of ONE process: the process-wide ``Group`` of that
+    device tuple (one context and one host thread per device inside the library, RCCL between them) - SURVEY.md 8(b), 8(e)."""
+    return primal_fit(X, y, s, shift, scale, B, is_classifier, ctx=default_group(devices), **kw)
 
 
 def primal_fit_sigma_grid(
@@ -398,81 +425,66 @@ def primal_fit_sigma_grid(
     is_classifier: bool,
     sigmas,
     gammas=None,
-    ctx: Context | None = None,
+    ctx: Context | Group | None = None,
     rank: int = 0,
     world: int = 1,
-    allreduce_sum=None,
+    merge_ctx: Context | None = None,
+    want_L: bool = True,
 ) -> dict:
-    """gamma x sigma leave-one-out grid (BASELINE config 5).
+    """gamma x sigma leave-one-out grid (BASELINE config 5) - ONE C call (``nls_primal_fit_grid``; with a ``Group``:
+    ``nls_group_primal_fit_grid``, the sigmas dealt over the group's devices).
 
-    The reference fixes the kernel bandwidth in closed form (``_affine_separator.py:200-209``); this driver extends the
-    search with multipliers sigma_k that divide B (T / sigma_k).  For every sigma one ``primal_fit`` runs P2-P7 on the
-    gamma grid - ONE eigendecomposition per sigma is the factorisation all gammas reuse - and the (sigma, gamma) pair
-    with the smallest selection objective wins.  Only a sigma that beats the incumbent runs P8 / P9 (Cholesky re-solve,
-    residuals, download of L); the winner's full result is returned under ``"best"`` (on the rank that owns it).
+    The reference fixes the kernel bandwidth in closed form (``_affine_separator.py:200-209``); the grid extends the search with
+    multipliers sigma_k that divide B (T / sigma_k).  For every sigma one fit runs P2-P7 on the gamma grid - ONE eigendecomposition
+    per sigma is the factorisation all gammas reuse - and the (sigma, gamma) pair with the smallest selection objective wins.  The
+    library visits this rank's sigmas nearest to 1 first, finishes (P8 / P9) only a sigma that beats the incumbent, and resolves
+    ties as documented at ``nls_sigma_grid`` in the header; the winner's full result is returned under ``"best"`` (on the rank
+    that owns it).
 
     Default gammas: the 32-point grid ``gamma_grid(1024)[::33]`` (exactly a sub-grid of the reference's 1024 points).
-    Multi-GPU: sigmas are dealt round-robin over ``world`` ranks, every rank holding all rows (no collective in the
-    data path); ``allreduce_sum(array) -> array`` merges the small tables - every sigma is owned by one rank, the others
-    contribute zeros.  The communicator behind ``allreduce_sum`` must live on a SEPARATE context (as ``bench.py`` does): a
-    fitting context that has joined a communicator turns every ``primal_fit`` into a row-sharded collective fit, and ranks
-    that hold different sigmas would then all-reduce unrelated Gram matrices or deadlock - so this is refused below.
+    Process-per-GPU launches: sigmas are dealt round-robin over ``world`` ranks, every rank holding all rows (no collective in the
+    data path); ``merge_ctx`` - a SECOND context of this rank that has joined the communicator - merges the small tables.  (A fitting
+    context that has joined a communicator turns every fit into a row-sharded collective, so the library refuses that.)
     """
-    if world > 1 and ctx is not None and getattr(ctx, "comm_world", 1) > 1:
-        raise ValueError("primal_fit_sigma_grid shards sigmas, not rows: the fitting context must not be in a communicator "
-                         "(put the communicator used by allreduce_sum on a second Context)")  # fmt: skip
-    sigmas = np.asarray(sigmas, dtype=np.float64)
+    ctx = ctx or default_context()
+    sigmas = np.ascontiguousarray(sigmas, dtype=np.float64)
     gammas = gamma_grid(1024)[::33] if gammas is None else np.ascontiguousarray(gammas, dtype=np.float64)
-    B = np.ascontiguousarray(B, dtype=np.float64)
+    a, out, keep = _primal_args(X, y, s, shift, scale, B, is_classifier, gammas, None, ctx, want_L, True, False, None, None)
     S, G = sigmas.size, gammas.size
     table, objective, seconds = np.zeros((S, G)), np.zeros((S, G)), np.zeros(S)
-    timings: dict = {}
+    k_opt, g_opt, best_valid, nfin = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+    tm = np.zeros(_lib.NUM_TIMINGS)
+    gr = SigmaGrid()
+    gr.sigmas, gr.Sg, gr.rank, gr.world = sigmas.ctypes.data, S, int(rank), int(world)
+    gr.merge = merge_ctx.handle if merge_ctx is not None else None
+    gr.loo_errors, gr.objective, gr.seconds = table.ctypes.data, objective.ctypes.data, seconds.ctypes.data
+    gr.sigma_index, gr.gamma_index = C.addressof(k_opt), C.addressof(g_opt)
+    gr.best_valid, gr.finished_count, gr.timings = C.addressof(best_valid), C.addressof(nfin), tm.ctypes.data
+    fn = ctx.lib.nls_group_primal_fit_grid if isinstance(ctx, Group) else ctx.lib.nls_primal_fit_grid
+    ctx._check(fn(ctx.handle, C.byref(a), C.byref(gr)))
     best = None
-    # This rank's sigmas, nearest to 1 first: sigma = 1 is the bandwidth the separator chose in closed form
-    # (``_affine_separator.py:200-209``), so the incumbent is good from the start and few later sigmas need finishing.
-    for k in sorted(range(rank, S, world), key=lambda i: (abs(np.log(sigmas[i])), i)):
-        r = primal_fit(X, y, s, shift, scale, B / sigmas[k], is_classifier, gammas=gammas, ctx=ctx,
-                       finish_below=None if best is None else best[0])  # fmt: skip
-        table[k], objective[k], seconds[k] = r["loo_errors_gammas"], r["objective"], r["timings"]["total"]
-        for name, v in r["timings"].items():
-            timings[name] = timings.get(name, 0.0) + v
-        score = r["objective"][r["opt"]]
-        # (finish_below is strict: a sigma that only TIES the incumbent is not finished; the selection below resolves exact
-        # ties towards the finished incumbent, so "best" is never lost to a tie)
-        if r["finished"] and (best is None or score < best[0]):
-            best = (score, k, r)
-    if allreduce_sum is not None and world > 1:
-        merged = allreduce_sum(np.concatenate([table.ravel(), objective.ravel(), seconds]))
-        table, objective, seconds = merged[: S * G].reshape(S, G), merged[S * G : 2 * S * G].reshape(S, G), merged[2 * S * G :]
-        owned = np.ones(S, dtype=bool)
-    else:
-        owned = np.zeros(S, dtype=bool)
-        owned[rank::world] = True
-        table[~owned], objective[~owned] = np.nan, np.nan
-    col_min = np.where(owned, np.nanmin(np.where(owned[:, None], objective, np.inf), axis=1), np.inf)
-    k_opt = int(np.argmin(col_min))  # first minimum: ties go to the smaller sigma index ...
-    merged_table = allreduce_sum is not None and world > 1
-    if not merged_table and best is not None and col_min[best[1]] == col_min[k_opt]:
-        # ... unless (single rank only) the finished incumbent is among the tied: it carries the full result.  After a merge every rank
-        # sees the same table but a different incumbent, so the rule must not depend on it: all ranks return the smallest tied index.
-        k_opt = best[1]
-    g_opt = int(np.argmin(objective[k_opt]))
+    if best_valid.value:
+        keep["finished"].value = 1
+        keep["opt"].value = g_opt.value
+        best = _primal_result(out, keep, True)
+        best["timings"] = timings_dict(tm)
     return {
         "sigmas": sigmas,
         "gammas": gammas,
         "loo_errors": table,
         "objective": objective,
-        "sigma_index": k_opt,
-        "gamma_index": g_opt,
-        "sigma": float(sigmas[k_opt]),
-        "gamma": float(gammas[g_opt]),
+        "sigma_index": int(k_opt.value),
+        "gamma_index": int(g_opt.value),
+        "sigma": float(sigmas[k_opt.value]),
+        "gamma": float(gammas[g_opt.value]),
         "seconds_per_sigma": seconds,
-        "timings": timings,
-        "best": best[2] if (best is not None and best[1] == k_opt) else None,
+        "timings": timings_dict(tm),
+        "finished_count": int(nfin.value),
+        "best": best,
     }
 
 
-def primal_predict(X, shift, scale, B, beta=None, L=None, ctx: Context | None = None, factor: Factor | None = None):
+def primal_predict(X, shift, scale, B, beta=None, L=None, ctx: Context | Group | None = None, factor: Factor | GroupFactor | None = None):
     """(yhat, sigma): ``decision_function`` ``_neo_ls_svm.py:661-665`` and ``predict_std`` ``:464-469,477``.
 
     Pass ``beta`` for yhat and/or, for sigma, ``L`` (upper factor as returned by ``primal_fit``; uploaded and inverted on
@@ -491,7 +503,7 @@ def primal_predict(X, shift, scale, B, beta=None, L=None, ctx: Context | None = 
         yhat = np.empty(m)
     if factor is not None:
         if factor.ctx is not ctx or factor.D != D or not factor.handle:
-            raise ValueError("factor belongs to another context / feature count, or is closed")
+            raise ValueError("factor belongs to another context / group / feature count, or is closed")
         L = None
         sigma = np.empty(m)
     elif L is not None:
@@ -499,8 +511,9 @@ def primal_predict(X, shift, scale, B, beta=None, L=None, ctx: Context | None = 
         if L.shape != (D + 1, D + 1):
             raise ValueError(f"L must have shape ({D + 1}, {D + 1})")
         sigma = np.empty(m)
+    fn = ctx.lib.nls_group_primal_predict if isinstance(ctx, Group) else ctx.lib.nls_primal_predict  # (a Group shards the query rows)
     ctx._check(
-        ctx.lib.nls_primal_predict(
+        fn(
             ctx.handle, _lib._ptr(X), m, d, shift.ctypes.data, scale.ctypes.data, B.ctypes.data, D,
             _lib._ptr(beta), _lib._ptr(L), factor.handle if factor is not None else None, _lib._ptr(yhat), _lib._ptr(sigma),
         )

@@ -1,4 +1,4 @@
-// TEST INFRASTRUCTURE: a stand-in `librccl.so.1` for N processes that share ONE GPU.
+// TEST INFRASTRUCTURE: a stand-in `librccl.so.1` for N ranks - processes, or host threads of one process (a group) - that share ONE GPU.
 //
 // RCCL refuses two ranks on one device, and the pool's boxes have one GPU each, so the library's NATIVE collective
 // path (ctx->comm != NULL: ncclAllReduce / ncclBroadcast / grouped broadcasts, csrc/nls_host.h, csrc/nls_evd.hip)
@@ -60,12 +60,12 @@ struct Comm {
   Header* hdr = nullptr;
   size_t slot_bytes = 0;
   std::vector<char> host;  // staging for this rank's contribution / the result
+  int broadcast_calls = 0;  // per communicator rank (ranks may be threads of one process: a group, include/neolssvm_hip.h)
   char* slot(int r) const { return base + HEADER_BYTES + (size_t)r * slot_bytes; }
 };
 
 thread_local int g_group_depth = 0;
 thread_local std::vector<std::function<ncclResult_t()>> g_deferred;
-int g_broadcast_calls = 0;
 
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 double timeout_s() {
@@ -230,9 +230,9 @@ ncclResult_t ncclBroadcast(const void* sendbuff, void* recvbuff, size_t count, n
                            hipStream_t stream) {
   Comm* c = reinterpret_cast<Comm*>(comm);
   if (!c || !recvbuff || dtype_bytes(datatype) == 0 || root < 0 || root >= c->world) return ncclInvalidArgument;
-  ++g_broadcast_calls;
+  ++c->broadcast_calls;
   if (const char* e = std::getenv("NLS_SHIM_FAIL_BROADCAST"))
-    if (std::atoi(e) == g_broadcast_calls) return ncclInternalError;
+    if (std::atoi(e) == c->broadcast_calls) return ncclInternalError;
   return submit([=] { return run_broadcast(sendbuff, recvbuff, count, root, c, stream); });
 }
 

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared_symbols():
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
-    assert lib.nls_abi_version() == 2
+    assert lib.nls_abi_version() == 3
 
 
 def test_struct_layout_matches_header():
@@ -60,10 +60,11 @@ def test_struct_layout_matches_the_compiler(tmp_path):
 
     pf = [f[0] for f in _lib.PrimalFitArgs._fields_]
     df = [f[0] for f in _lib.DualFitArgs._fields_]
+    gf = [f[0] for f in _lib.SigmaGrid._fields_]
     src = tmp_path / "layout.c"
     src.write_text(
         '#include <stdio.h>\n#include <stddef.h>\n#include "neolssvm_hip.h"\nint main(void) {\n'
-        + prog("nls_primal_fit_args", pf) + prog("nls_dual_fit_args", df) + "  return 0;\n}\n"
+        + prog("nls_primal_fit_args", pf) + prog("nls_dual_fit_args", df) + prog("nls_sigma_grid", gf) + "  return 0;\n}\n"
     )
     exe = tmp_path / "layout"
     subprocess.run(["gcc", "-I", str(ROOT / "include"), str(src), "-o", str(exe)], check=True)
@@ -74,6 +75,9 @@ def test_struct_layout_matches_the_compiler(tmp_path):
         assert int(out[f"nls_primal_fit_args.{f}"]) == getattr(_lib.PrimalFitArgs, f).offset, f
     for f in df:
         assert int(out[f"nls_dual_fit_args.{f}"]) == getattr(_lib.DualFitArgs, f).offset, f
+    assert int(out["sizeof_nls_sigma_grid"]) == ctypes.sizeof(_lib.SigmaGrid)
+    for f in gf:
+        assert int(out[f"nls_sigma_grid.{f}"]) == getattr(_lib.SigmaGrid, f).offset, f
 
 
 def test_estimator_hands_its_device_to_the_prestep(monkeypatch):
@@ -180,11 +184,22 @@ def test_rendezvous_file_exchange(tmp_path, monkeypatch):
     prim, sec = distributed._rendezvous_files(None)
     assert prim.read_bytes()[:128] == bytes(range(128)) and sec.read_bytes()[:128] == bytes(range(128))
     assert (prim.stat().st_mode & 0o777) == 0o600
-    # an explicit key is the caller's own rendezvous: joined whatever its age (a rank may arrive long after rank 0 published) ...
-    old = bytes(range(1, 129)) + repr(0.0).encode()
+    # an explicit key is the caller's own rendezvous: joined whatever its age (a rank may arrive long after rank 0 published) - when it
+    # carries THIS launch's nonce ...
+    old = bytes(range(1, 129)) + repr(0.0).encode() + b"|" + distributed._launch_nonce()
     (tmp_path / "nls_rccl_id_job.1").write_bytes(old)
     os.utime(tmp_path / "nls_rccl_id_job.1", (1.0, 1.0))
     assert distributed.exchange_unique_id(Ctx(), 1, 2, key="job.1", timeout=0.2) == bytes(range(1, 129))
+    # ... and NOT when a previous launch that died before its post-barrier unlink left it there (another nonce, or none at all): the
+    # ranks of the next launch with the same key keep waiting for their own rank 0 instead of joining a dead communicator id
+    for stale in (bytes(range(1, 129)) + repr(0.0).encode() + b"|4242_1_none_0", bytes(range(1, 129)) + repr(0.0).encode()):
+        (tmp_path / "nls_rccl_id_job.1").write_bytes(stale)
+        with pytest.raises(TimeoutError):
+            distributed.exchange_unique_id(Ctx(), 1, 2, key="job.1", timeout=0.2)
+    monkeypatch.setenv("NLS_RENDEZVOUS_NONCE", "4242_1_none_0")  # (a launcher may set the nonce itself)
+    (tmp_path / "nls_rccl_id_job.1").write_bytes(bytes(range(1, 129)) + repr(0.0).encode() + b"|4242_1_none_0")
+    assert distributed.exchange_unique_id(Ctx(), 1, 2, key="job.1", timeout=0.2) == bytes(range(1, 129))
+    monkeypatch.delenv("NLS_RENDEZVOUS_NONCE")
     # ... and a key with a dot keeps its whole name while it is being published (the temporary file is <name>.tmp<pid>)
     assert distributed.exchange_unique_id(Ctx(), 0, 2, key="job.1") == bytes(range(128))
     assert (tmp_path / "nls_rccl_id_job.1").read_bytes()[:128] == bytes(range(128)) and not list(tmp_path.glob("*.tmp*"))
@@ -246,11 +261,69 @@ def test_3m_engine_agpr_invariant():
     assert r.returncode == 0, r.stdout + r.stderr
 
 
-def test_sigma_grid_merge_over_ranks(monkeypatch):
-    """primal_fit_sigma_grid: sigmas dealt round-robin over ranks, tables merged with a sum all-reduce (every sigma has one
-    owner), only a sigma that beats the rank's incumbent is finished.  The solver is replaced by a deterministic stand-in
-    (no GPU): this checks the driver's bookkeeping, the GPU test test_sigma_grid_driver checks the numbers."""
-    from neo_ls_svm_amd import hotpath
+def test_sigma_grid_bookkeeping_hooks():
+    """The gamma x sigma grid runs inside the library (``nls_primal_fit_grid``); its bookkeeping - which sigmas a rank visits in which
+    order, and the selection over the (merged or unmerged) objective table with numpy's argmin / nanmin semantics and the two tie rules -
+    is host arithmetic behind two hooks, checked here against the Python restatement of the round-4 driver (``tests/_grid_reference_driver``).
+    The finish-if-below loop itself needs fits: ``tests/test_gpu_primal.py::test_sigma_grid_driver`` runs both drivers on the GPU."""
+    import sys
+
+    sys.path.insert(0, str(ROOT / "tests"))
+    import _grid_reference_driver as ref
+    from neo_ls_svm_amd import _lib
+
+    lib = _lib.load_library()
+    rng = np.random.default_rng(0)
+    for S in (1, 3, 7, 16):
+        sig = np.exp(rng.uniform(-1.4, 1.4, S))
+        if S >= 3:
+            sig[1] = 1.0 / sig[0]  # |ln sigma| ties: broken by index
+        for world in (1, 2, 3, 8):
+            for rank in range(world):
+                order = np.full(S, -1, dtype=np.int32)
+                cnt = lib.nls_grid_visiting_order(sig.ctypes.data, S, rank, world, order.ctypes.data)
+                assert list(order[:cnt]) == ref.visiting_order(sig, rank, world)
+    assert lib.nls_grid_visiting_order(sig.ctypes.data, 16, 3, 3, order.ctypes.data) == -1  # rank outside the world
+
+    def select(obj, owned, incumbent):
+        k, g = ctypes.c_int32(), ctypes.c_int32()
+        own = np.ascontiguousarray(owned, dtype=np.uint8)
+        rc = lib.nls_grid_select(obj.ctypes.data, own.ctypes.data, obj.shape[0], obj.shape[1], -1 if incumbent is None else incumbent,
+                                 ctypes.byref(k), ctypes.byref(g))  # fmt: skip
+        assert rc == 0
+        return k.value, g.value
+
+    S, G = 7, 5
+    for trial in range(200):
+        obj = np.ascontiguousarray(rng.integers(0, 4, (S, G)).astype(np.float64))  # many exact ties
+        world = int(rng.integers(1, 4))
+        rank = int(rng.integers(0, world))
+        owned = np.zeros(S, dtype=bool)
+        owned[rank::world] = True
+        merged = bool(rng.integers(0, 2))
+        if merged:
+            owned[:] = True
+        else:
+            obj[~owned] = np.nan
+        if trial % 7 == 0:
+            obj[int(np.flatnonzero(owned)[0]), 2] = np.nan  # a NaN inside an owned row: nanmin skips it, argmin of the row returns it
+        cand = np.flatnonzero(owned)
+        incumbent = None if merged else int(rng.choice(cand))
+        assert select(obj, owned, incumbent) == ref.select(obj, owned, incumbent), (trial, obj, owned, incumbent)
+    # the merged rule does not depend on any rank's incumbent: the smallest tied index
+    obj = np.ones((S, G))
+    obj[4, 2] = obj[1, 3] = obj[2, 0] = 0.5
+    assert select(obj, np.ones(S, dtype=bool), None) == (1, 3)
+    assert select(obj, np.ones(S, dtype=bool), 4) == (4, 2)  # unmerged: the finished incumbent keeps a tie
+
+
+def test_sigma_grid_reference_driver_bookkeeping():
+    """The checker itself (``tests/_grid_reference_driver.grid``) over a deterministic stand-in solver: sigmas dealt round-robin over
+    ranks, tables merged with a sum (every sigma has one owner), only a sigma that beats the rank's incumbent is finished."""
+    import sys
+
+    sys.path.insert(0, str(ROOT / "tests"))
+    import _grid_reference_driver as ref
 
     S, G = 7, 5
     sig = np.linspace(0.5, 2.0, S)
@@ -259,7 +332,7 @@ def test_sigma_grid_merge_over_ranks(monkeypatch):
     curves[4, 2] = 0.5  # the joint minimum
     calls = []
 
-    def fake_fit(X, y, s, shift, scale, B, is_clf, gammas=None, ctx=None, finish_below=None, **kw):
+    def fake_fit(B, finish_below):
         k = int(np.argmin(np.abs(sig - 1.0 / B[0, 0])))
         obj = curves[k]
         opt = int(np.argmin(obj))
@@ -270,59 +343,33 @@ def test_sigma_grid_merge_over_ranks(monkeypatch):
             r["beta"] = np.full(3, float(k))
         return r
 
-    monkeypatch.setattr(hotpath, "primal_fit", fake_fit)
     B = np.ones((1, 1))
     world = 3
+    gam = np.arange(1.0, G + 1)
     contribs = []
     for rank in range(world):  # pass 1: what every rank hands to the all-reduce
-        hotpath.primal_fit_sigma_grid(None, None, None, None, None, B, False, sig, gammas=np.arange(1.0, G + 1), rank=rank, world=world,
-                                      allreduce_sum=lambda a: contribs.append(a.copy()) or a)  # fmt: skip
+        ref.grid(fake_fit, B, sig, gam, rank, world, allreduce_sum=lambda a: contribs.append(a.copy()) or a)
     total = sum(contribs)
     calls.clear()
     parts = []
     for rank in range(world):  # pass 2: every rank receives the sum
-        g = hotpath.primal_fit_sigma_grid(None, None, None, None, None, B, False, sig, gammas=np.arange(1.0, G + 1), rank=rank, world=world,
-                                          allreduce_sum=lambda a: total.copy())  # fmt: skip
-        parts.append((g, None))
+        g = ref.grid(fake_fit, B, sig, gam, rank, world, allreduce_sum=lambda a: total.copy())
+        parts.append(g)
         assert (g["sigma_index"], g["gamma_index"]) == (4, 2)
         assert np.allclose(g["objective"], curves) and np.allclose(g["loo_errors"], curves + 10.0)
-    table = total[: S * G].reshape(S, G)
-    objective = total[S * G : 2 * S * G].reshape(S, G)
-    assert np.allclose(objective, curves) and np.allclose(table, curves + 10.0)
     assert np.allclose(total[2 * S * G :], 1.0)  # seconds per sigma: every sigma timed exactly once
     owner = 4 % world
-    assert parts[owner][0]["best"] is not None and parts[owner][0]["best"]["beta"][0] == 4.0
-    assert all(parts[r][0]["best"] is None for r in range(world) if r != owner)
-    # a sigma is finished only when it beats the incumbent of its rank
-    for rank in range(world):
+    assert parts[owner]["best"] is not None and parts[owner]["best"]["beta"][0] == 4.0
+    assert all(parts[r]["best"] is None for r in range(world) if r != owner)
+    for rank in range(world):  # a sigma is finished only when it beats the incumbent of its rank
         mine = [c for c in calls if c[0] % world == rank]
         best = np.inf
         for k, bound, finished in mine:
             assert (bound is None) == (best == np.inf)
             assert finished == (curves[k].min() < best)
             best = min(best, curves[k].min()) if finished else best
-    # an exact tie between sigmas owned by different ranks: after the merge every rank must name the SAME winner (the smallest
-    # tied index), whatever its own incumbent is
-    saved = curves.copy()
-    curves[1, 3] = 0.5  # ties with (4, 2); sigma 1 belongs to rank 1, sigma 4 to rank 1 too -> also tie sigma 2 (rank 2)
-    curves[2, 0] = 0.5
-    contribs.clear()
-    for rank in range(world):
-        hotpath.primal_fit_sigma_grid(None, None, None, None, None, B, False, sig, gammas=np.arange(1.0, G + 1), rank=rank, world=world,
-                                      allreduce_sum=lambda a: contribs.append(a.copy()) or a)  # fmt: skip
-    total = sum(contribs)
-    winners = set()
-    for rank in range(world):
-        g = hotpath.primal_fit_sigma_grid(None, None, None, None, None, B, False, sig, gammas=np.arange(1.0, G + 1), rank=rank, world=world,
-                                          allreduce_sum=lambda a: total.copy())  # fmt: skip
-        winners.add((g["sigma_index"], g["gamma_index"]))
-    assert winners == {(1, 3)}
-    curves[:] = saved
-    # single rank, no all-reduce: the full table and the winner
-    calls.clear()
-    g = hotpath.primal_fit_sigma_grid(None, None, None, None, None, B, False, sig, gammas=np.arange(1.0, G + 1))
-    assert (g["sigma_index"], g["gamma_index"]) == (4, 2) and g["best"]["beta"][0] == 4.0
-    assert g["timings"]["gram"] == 0.5 * S
+    g = ref.grid(fake_fit, B, sig, gam)
+    assert (g["sigma_index"], g["gamma_index"]) == (4, 2) and g["best"]["beta"][0] == 4.0 and g["finished_count"] >= 1
 
 
 def test_pooled_factor_outputs_are_recycled_only_when_nobody_holds_them():

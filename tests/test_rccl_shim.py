@@ -78,19 +78,20 @@ def _launch_native(mode, world, extra_env=None, timeout=900):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_native_communicator_world_n_one_gpu(world):
-    """Row-sharded fits (regression and classification) through the library's own RCCL call sites, world 2 and 3: equal to the
+    """Row-sharded fits (regression and classification) through the library's own RCCL call sites, world 2, 3 and 8: equal to the
     single-rank fit; ``L_`` only on rank 0; beta identical on every rank; one-stage eigendecomposition (rank-0 ``stedc`` + real
     broadcast + column-split back-transformation + grouped all-gather of unequal blocks)."""
     _launch_native("gpu_rccl", world)
 
 
 @pytest.mark.gpu
-def test_native_communicator_two_stage_evd():
+@pytest.mark.parametrize("world", [3, 8])
+def test_native_communicator_two_stage_evd(world):
     """The same with the two-stage reduction forced: both back-transformations split by columns, the ranks vote on the
     chase's invariants check (one more all-reduce)."""
-    _launch_native("gpu_rccl", 3, {"NLS_EVD": "twostage"})
+    _launch_native("gpu_rccl", world, {"NLS_EVD": "twostage"})
 
 
 @pytest.mark.gpu
@@ -105,6 +106,12 @@ def test_native_communicator_failure_inside_the_group():
     """... and inside the grouped all-gather (broadcasts 4.. of a fit: flag, lam, eigenvectors come first): the group is closed,
     the error surfaces, nobody hangs."""
     _launch_native("gpu_rccl_fail", 2, {"NLS_SHIM_FAIL_BROADCAST": "5"}, timeout=300)
+
+
+@pytest.mark.gpu
+def test_native_communicator_failure_world8():
+    """World 8, the failure inside the grouped all-gather of eight unequal blocks (the 7th broadcast of every rank)."""
+    _launch_native("gpu_rccl_fail", 8, {"NLS_SHIM_FAIL_BROADCAST": "7"}, timeout=600)
 
 
 def _bench_line(out):
@@ -145,3 +152,54 @@ def test_bench_two_ranks_one_gpu(launcher):
     assert d["config"]["gamma_index"] == d1["config"]["gamma_index"]
     assert d["config"]["loo_score"] == pytest.approx(d1["config"]["loo_score"], rel=1e-9)
     assert d["config"]["rows_per_gpu"] * 2 == d1["config"]["rows_per_gpu"] and "row-shard x2" in d["config"]["parallelism"]
+
+
+def _bench_env(td):
+    lib = build_shim(host_only=False)
+    env = dict(os.environ, NLS_RCCL_LIB=str(lib), NLS_RENDEZVOUS_DIR=td, NLS_SHIM_SLOT_BYTES=str(1 << 20), NLS_SHIM_TIMEOUT_S="300",
+               NLS_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2", OPENBLAS_NUM_THREADS="2")  # fmt: skip
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return env
+
+
+@pytest.mark.gpu
+def test_bench_eight_ranks_one_gpu():
+    """``bench.py --gpus 8 --config c2`` - the driver's scaling run at its largest world, minus seven devices: eight processes, rendezvous
+    through the id file, 12 500 rows per rank, 1025 = 8 * 128 + 1 eigenvector columns over the ranks, the max-over-ranks clock, one N = 8
+    line with ``parallelism`` filled; the same fit as one rank computes."""
+    root = HERE.parent
+    args = ["bench.py", "--gpus", "8", "--config", "c2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-end-to-end"]
+    with tempfile.TemporaryDirectory() as td:
+        env = _bench_env(td)
+        p = subprocess.run([sys.executable] + args, cwd=root, env=env, capture_output=True, text=True, timeout=1500)
+        assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+        d = _bench_line(p.stdout)
+        one = subprocess.run([sys.executable] + args[:2] + ["1"] + args[3:], cwd=root, env={k: v for k, v in env.items() if k != "NLS_RCCL_LIB"},
+                             capture_output=True, text=True, timeout=900)  # fmt: skip
+        assert one.returncode == 0, (one.stdout + one.stderr)[-3000:]
+        d1 = _bench_line(one.stdout)
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong" and d["value"] > 0 and d["metric"] == d1["metric"]
+    assert d["config"]["rows_per_gpu"] == 12_500 and "row-shard x8" in d["config"]["parallelism"]
+    assert d["config"]["gamma_index"] == d1["config"]["gamma_index"]
+    assert d["config"]["loo_score"] == pytest.approx(d1["config"]["loo_score"], rel=1e-9)
+
+
+@pytest.mark.gpu
+def test_bench_sigma_grid_eight_ranks_one_gpu():
+    """Config 5's deployment at world 8 in miniature (``--config c5s``: 16 sigma x 32 gamma, n = 2e4): every rank fits its two sigmas on
+    all rows through ``nls_primal_fit_grid``, the tables are merged through the NATIVE communicator of a second context
+    (``grid->merge``), every rank names the same winner as the single-rank grid."""
+    root = HERE.parent
+    args = ["bench.py", "--gpus", "8", "--config", "c5s", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-end-to-end"]
+    with tempfile.TemporaryDirectory() as td:
+        env = _bench_env(td)
+        p = subprocess.run([sys.executable] + args, cwd=root, env=env, capture_output=True, text=True, timeout=1500)
+        assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+        d = _bench_line(p.stdout)
+        one = subprocess.run([sys.executable] + args[:2] + ["1"] + args[3:], cwd=root, env={k: v for k, v in env.items() if k != "NLS_RCCL_LIB"},
+                             capture_output=True, text=True, timeout=900)  # fmt: skip
+        assert one.returncode == 0, (one.stdout + one.stderr)[-3000:]
+        d1 = _bench_line(one.stdout)
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and "sigma-shard x8" in d["config"]["parallelism"]
+    assert (d["config"]["sigma_index"], d["config"]["gamma_index"]) == (d1["config"]["sigma_index"], d1["config"]["gamma_index"])

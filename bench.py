@@ -39,6 +39,10 @@ CONFIGS = {
     "c3q": dict(n=262_144, d=128, D=4096, G=1024, name="synthetic regression n=262144 d=128 D=4096 ORF, primal, G=1024"),
     # BASELINE.json configs[3]: dual path, binary classification, explicit n x n kernel + eigendecomposition gamma-sweep (G = 128)
     "c4": dict(n=10_000, d=256, G=128, dual=True, name="synthetic binary classification n=1e4 d=256, dual path (n x n RBF kernel, EVD gamma-sweep G=128)"),
+    # c3's shape at n / D = 16 rows per feature: with this generator the LOO-optimal gamma is INTERIOR to the grid (index ~ 675 of 1024; at c2 / c3
+    # - 98 / 244 rows per feature at 10 % noise - it is the smallest grid point), so gamma selection and the Cholesky re-solve run at an interior
+    # gamma*.  A secondary line (profiles/), not the headline.
+    "c3i": dict(n=65_536, d=128, D=4096, G=1024, name="synthetic regression n=65536 d=128 D=4096 ORF (16 rows per feature: interior LOO optimum), primal, G=1024"),
     # config 5 in miniature (tests: sigma sharding through the native communicator at world 8 on one GPU)
     "c5s": dict(n=20_000, d=32, D=512, G=32, sigmas=16, name="gamma x sigma LOO grid 32 x 16, n=2e4 d=32 D=512 ORF, primal"),
     # small plumbing configuration for quick checks
@@ -91,6 +95,21 @@ def _blas_info():
         return os.cpu_count(), "unknown"
 
 
+def _blas_threads_note(threads):
+    """Why the CPU baseline runs on `threads` BLAS threads and not on every CPU of the box."""
+    cpus = os.cpu_count() or 1
+    if threads >= cpus:
+        return f"all {cpus} CPUs"
+    try:
+        from threadpoolctl import threadpool_info
+
+        ver = ",".join(sorted({f"{i.get('internal_api')} {i.get('version')} ({i.get('threading_layer')}, {i.get('architecture')})" for i in threadpool_info() if i.get("user_api") == "blas"}))
+    except Exception:
+        ver = "unknown"
+    return (f"{threads} of {cpus} CPUs: the thread count NumPy's bundled BLAS ({ver}) starts with on this box - its build-time cap (the OpenBLAS wheel "
+            f"is compiled with NUM_THREADS = 64; threadpoolctl cannot raise it) - not a measured knee")
+
+
 def _parity(gpu, ref, rows):
     """BASELINE.json's second metric half: GPU fit against the float64 oracle fit on the SAME rows -
     max |e - e_ref| / max |e_ref| on ``loo_residuals_`` at the reference's argmin, ||beta - beta_ref|| / ||beta_ref||,
@@ -137,7 +156,7 @@ def cpu_baseline(cfg, shift, scale, B, gammas, gpu_fit, gpu_full=None):
     threads, blas = _blas_info()
     n, d, D = cfg["n"], cfg["d"], cfg["D"]
     D1 = D + 1
-    out = {"unit": "fits/s", "cores": int(threads), "host_cpus": os.cpu_count(), "blas": blas, "kind": "port"}
+    out = {"unit": "fits/s", "cores": int(threads), "host_cpus": os.cpu_count(), "blas": blas, "kind": "port", "cores_note": _blas_threads_note(int(threads))}
     with threadpool_limits(limits=int(threads), user_api="blas"):
         full_fits_ram = n * D1 <= 2e8  # phi, S phi, h, phi beta(.) of the faithful schedule: 4 x 16 B per entry (c2: 6.6 GB)
         if full_fits_ram:
@@ -185,7 +204,8 @@ def cpu_baseline(cfg, shift, scale, B, gammas, gpu_fit, gpu_full=None):
             seconds_sample_fit=t_fit,
             stage_seconds={k: round(v, 3) for k, v in tm.items()},
             note="the reference itself cannot run this size (phi alone is 65.5 GB); Mode R at the largest size it can run "
-            "(c2) is in profiles/ (bench.py --config c2)",
+            "(c2) is in profiles/ (bench.py --config c2); the x n / n_s extrapolation of the row stages is checked once against a FULL-size "
+            "Mode-S run of c3 on the same kind of host: profiles/r05_cpu_modeS_c3_full.json (tools/cpu_modeS_full.py)",
         )
     g = gpu_fit(X, y, s, None)
     argmin_equal = g["opt"] == o["opt"]
@@ -520,18 +540,24 @@ def main():
         rot_alg_tflops = stage["rotate_flops"] / max(stage["rotate"], 1e-12) / 1e12
         # Traffic past L2 comes from separate rocprofv3 PMC passes (it cannot be read live); per row because every launch
         # streams (rows x panels) with the same reuse pattern.
-        traffic = k1_traffic = traffic_src = None
-        try:  # this round's passes (tools/pmc_passes_r04.sh -> profiles/r04_pmc_summary.json, same layout as r02's)
-            pmc = json.loads((ROOT / "profiles" / "r04_pmc_summary.json").read_text())
-            pr = pmc["k_rotate3"]
-            if pr["D"] == D and pr["d"] == d:
-                traffic = (pr["fetch_bytes_x2"] + pr["write_bytes"]) * (rot_rows / rot_launches) / pr["rows_per_launch"]
-                traffic_src = "profiles/r04_pmc_summary.json"
-            pk = pmc.get("k_featuremap")
-            if pk and pk["D"] == D and pk["d"] == d:
-                k1_traffic = pk["hbm_bytes_per_row"]
-        except Exception:
-            pass
+        traffic = k1_traffic = traffic_src = mfma_busy = mfma_busy_src = gram_pmc = None
+        for src in ("r05_pmc_summary.json", "r04_pmc_summary.json"):  # the newest counter passes committed (tools/pmc_passes_r05.sh / _r04.sh, same layout)
+            try:
+                pmc = json.loads((ROOT / "profiles" / src).read_text())
+                pr = pmc["k_rotate3"]
+                if pr["D"] == D and pr["d"] == d and pr.get("fetch_bytes_x2"):
+                    if traffic is None:
+                        traffic = (pr["fetch_bytes_x2"] + pr["write_bytes"]) * (rot_rows / rot_launches) / pr["rows_per_launch"]
+                        traffic_src = f"profiles/{src}"
+                    if mfma_busy is None and pr.get("mfma_busy"):
+                        mfma_busy, mfma_busy_src = pr["mfma_busy"], f"profiles/{src}"
+                    if gram_pmc is None and pmc.get("k_gram3", {}).get("fetch_bytes_x2"):
+                        gram_pmc = dict(pmc["k_gram3"], source=f"profiles/{src}")
+                pk = pmc.get("k_featuremap")
+                if k1_traffic is None and pk and pk["D"] == D and pk["d"] == d and pk.get("hbm_bytes_per_row"):
+                    k1_traffic = pk["hbm_bytes_per_row"]
+            except Exception:
+                pass
         if traffic is None and D == 4096 and d == 128:
             try:  # round 3's passes of the XCD-patch order that is the default now (8 x 5 at D = 4096): 333 440 rows per launch
                 pr = json.loads((ROOT / "profiles" / "r03_pmc_rotate.json").read_text())["p8x5"]["k_rotate3"]
@@ -593,12 +619,19 @@ def main():
                 "peak": FP64_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": rot_exec_tflops / FP64_MFMA_PEAK_TFLOPS,
+                "frac_is": "executed-MFMA utilisation (flops the kernel executes / time / peak); frac_algorithmic is SURVEY 8(d)'s figure",
+                "frac_algorithmic": rot_alg_tflops / FP64_MFMA_PEAK_TFLOPS,
+                "mfma_busy": mfma_busy,
+                "mfma_busy_source": None if mfma_busy is None else f"{mfma_busy_src}: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 matrix pipes), its own rocprofv3 --pmc pass",
                 "traffic": traffic,
                 "traffic_unit": "bytes/launch beyond L2 (2 x FETCH_SIZE + WRITE_SIZE, Infinity-Cache hits included), from separate rocprofv3 --pmc passes",
                 "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": (rot_rows / rot_launches) * 16.0 * (Kf + Np) + 16.0 * Kf * Np,
-                "note": "achieved = EXECUTED MFMA flops (3M complex product: 6 rows Kf Np, Kf = ceil(D/128)*128, Np = ceil((D+1)/64)*64) / kernel "
-                "time, so frac is the matrix-pipe utilisation; the algorithmic 8 rows (D+1)^2 of the four-product form is reported beside it",
+                "traffic_over_algorithmic": None if traffic is None else traffic / ((rot_rows / rot_launches) * 16.0 * (Kf + Np) + 16.0 * Kf * Np),
+                "note": "achieved / frac = EXECUTED MFMA flops (3M complex product: 6 rows Kf Np, Kf = ceil(D/128)*128, Np = ceil((D+1)/64)*64) / kernel "
+                "time: the matrix-pipe utilisation.  frac_algorithmic = SURVEY 8(d)'s algorithmic 8 rows (D+1)^2 flops of the four-product form / time / "
+                "peak: it exceeds the executed figure by algorithmic_gain (3 instead of 4 real products per complex product, D+1 padded to Np) and may "
+                "exceed 1 - the kernel does LESS arithmetic than the formula prices, with results equal to the reference's to 1e-13 (parity)",
                 "algorithmic_tflops": rot_alg_tflops,
                 "algorithmic_gain": rot_alg_tflops / rot_exec_tflops,
                 "avg_launch_ms": 1e3 * stage["rotate"] / rot_launches,
@@ -606,6 +639,22 @@ def main():
                 "whole_fit_algorithmic_tflops": whole_alg,
                 "whole_fit_executed_tflops": whole_exec,
                 "whole_fit_executed_frac": whole_exec / (FP64_MFMA_PEAK_TFLOPS * world),
+            },
+            "roofline_gram": {
+                "kernel": "k_gram3 (Hermitian lower block triangle, 3M, split-K over rows)",
+                "bound": "mfma",
+                "achieved": 3.0 * rows_all * Kf * Kf / max(stage["gram"], 1e-12) / 1e12,
+                "peak": FP64_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": 3.0 * rows_all * Kf * Kf / max(stage["gram"], 1e-12) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                "frac_is": "executed-MFMA utilisation over the whole gram stage (k_gram3 + slab reduction + border sums); 3 rows Kf^2 executed flops",
+                "frac_algorithmic": stage["gram_flops"] / max(stage["gram"], 1e-12) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                "avg_launch_ms": 1e3 * stage["gram"] / max(stage["gram_launches"], 1.0),
+                "mfma_busy": None if not gram_pmc else gram_pmc.get("mfma_busy"),
+                "traffic": None if not gram_pmc else (gram_pmc["fetch_bytes_x2"] + gram_pmc["write_bytes"]) * (rows_all / max(stage["gram_launches"], 1.0)) / gram_pmc["rows_per_launch"],
+                "algorithmic_bytes_per_launch": (rows_all / max(stage["gram_launches"], 1.0)) * 16.0 * Kf + 8.0 * Kf * Kf,
+                "traffic_over_algorithmic": None if not gram_pmc else (gram_pmc["fetch_bytes_x2"] + gram_pmc["write_bytes"]) / (gram_pmc["rows_per_launch"] * 16.0 * Kf + 8.0 * Kf * Kf),
+                "traffic_source": None if not gram_pmc else f"{gram_pmc['source']} ({gram_pmc.get('order')})",
             },
             "roofline_k1": {
                 "kernel": "k_featuremap (+ k_shift_pad)",

@@ -32,5 +32,11 @@ for tag, ks in out.items():
         if "WRITE_SIZE" in c: e["write_bytes_per_launch"] = 1024 * c["WRITE_SIZE"] / max(len(c.get("_disp_WRITE_SIZE", [])), 1)
         if "TCC_HIT_sum" in c: e["l2_hit"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
         if "_ns" in c: e["avg_ms"] = sum(c["_ns"]) / len(c["_ns"]) / 1e6
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
+            # GRBM_GUI_ACTIVE is summed over the 8 XCDs (MI355X_MICROARCH.md): / 8 = chip cycles of the dispatch; 256 CUs x 4 SIMDs = 1024 matrix pipes
+            nb = max(len(c.get("_disp_GRBM_GUI_ACTIVE", [])), 1)
+            cyc = c["GRBM_GUI_ACTIVE"] / nb / 8.0
+            e["mfma_busy"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / nb / (cyc * 1024.0)
+            if "_ns" in c: e["clock_ghz"] = cyc / (sum(c["_ns"]) / len(c["_ns"]))
         res.setdefault(tag, {})[k] = e
 print(json.dumps(res, indent=1))

@@ -340,6 +340,7 @@ extern "C" int nls_dual_fit(nls_ctx* ctx, const nls_dual_fit_args* a) {
   static const bool pin_on = [] { const char* m = std::getenv("NLS_PIN_OUTPUT"); return m && m[0] == '1'; }();
   if (a->L && pin_on) pinL.pin(a->L, sizeof(double) * (size_t)n * n);
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  NLSCHK(trd_check(ctx));  // (in-launch hand-offs of the eigendecomposition: an error word instead of a hang, nls_trd1.h)
   for (int g = 0; g < G; ++g) hobj[g] = is_clf ? (herrs[Gp + g] + herrs[2 * Gp + g]) + herrs[g] : herrs[g];  // :296-302
   int opt = a->gamma_index_in;
   if (opt < 0) {

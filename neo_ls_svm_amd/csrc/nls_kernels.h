@@ -595,6 +595,77 @@ __global__ void __launch_bounds__(Cfg4::NTHREADS, 2)
 }
 
 // ------------------------------------------------------------------------------------------------
+// K5 for SHORT gamma grids (G <= 16 NT: 32 or 64 columns; the 32-point grid of the gamma x sigma sweep, BASELINE config 5):
+//   num = U R,  hs = (Gm R) / c  with R [Np x ldr] (only its first 16 NT columns are read).
+// The 128-wide N tile of the engine above would multiply 96 of its 128 columns by padding.  Here the product is what it is at this shape -
+// a stream of U / Gm from HBM (rows x Np x 8 B per product; 2 x 33 GB per 10^6 rows at D = 4096) against a 1.3 MB operand that lives in L2:
+//   * no LDS: a wave owns 64 rows x 16 NT columns and walks K alone; no barriers;
+//   * A fragments straight from global memory in 32-byte runs: lane (i, kq) loads U[row i][k0 + 4 kq .. + 3] - the four k of one lane feed
+//     four successive MFMAs (the contraction does not care in which order k is visited), so a 16-row tile reads whole 128-byte lines;
+//   * the matching B fragment of MFMA t is R[k0 + 4 kq + t][col j] - 16 lanes x 8 B contiguous, L1 / L2 hits shared by the waves of a CU;
+//   * the next 16-k step's operands are loaded while the current one multiplies.
+// grid = (1, ceil(rows_pad / 256), 2): 4 waves per workgroup, blockIdx.z = 0: U -> num, 1: Gm -> hs.
+// ------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ void __launch_bounds__(256) k_sweep_small(const double* U, const double* Gm, int Np, const double* R, int ldr, double inv_c, double* num,
+                                                     double* hs, int ldo, long out_row0, long rows_pad) {
+  constexpr int MT = 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, kq = lane >> 4;
+  const bool second = blockIdx.z == 1;
+  const long row0 = ((long)blockIdx.y * 4 + wave) * 64;
+  if (row0 >= rows_pad) return;  // (rows_pad is a multiple of 128: the last workgroup may hold two waves only; no barriers in this kernel)
+  const double* A = (second ? Gm : U) + (row0 + li) * (long)Np + 4 * kq;  // + mt * 16 * Np + k0
+  const double* Bp = R + (long)(4 * kq) * ldr + li;                        // + (k0 + t) * ldr + nt * 16
+  v4d acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = v4d{0.0, 0.0, 0.0, 0.0};
+  v2d a0[MT][2], a1[MT][2];
+  double b0[4][NT], b1[4][NT];
+  auto load = [&](v2d (&a)[MT][2], double (&b)[4][NT], int k0) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const v2d* p = reinterpret_cast<const v2d*>(A + (long)mt * 16 * Np + k0);
+      a[mt][0] = p[0];
+      a[mt][1] = p[1];
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) b[t][nt] = Bp[(long)(k0 + t) * ldr + nt * 16];
+  };
+  auto mult = [&](const v2d (&a)[MT][2], const double (&b)[4][NT]) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mt][t >> 1][t & 1], b[t][nt], acc[mt][nt], 0, 0, 0);
+  };
+  load(a0, b0, 0);
+  int k0 = 0;
+  for (; k0 + 32 <= Np; k0 += 32) {  // two steps per trip: the register sets alternate at compile time
+    load(a1, b1, k0 + 16);
+    mult(a0, b0);
+    if (k0 + 32 < Np) load(a0, b0, k0 + 32);
+    mult(a1, b1);
+  }
+  if (k0 < Np) mult(a0, b0);  // (Np is a multiple of 16: an odd number of steps leaves one)
+  double* out = second ? hs : num;
+  const double f = second ? inv_c : 1.0;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long row = out_row0 + row0 + mt * 16 + 4 * r + kq;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) out[row * ldo + nt * 16 + li] = acc[mt][nt][r] * f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // P6/P7: LOO residuals for every (row, gamma) and their weighted column sums.
 //   e = (num - y) / (1 - s^2 hs); classifier: zero on the correct side (_neo_ls_svm.py:153-155)
 //   part[blk][0][g] = sum s |e|, [1] = sum s [|e| >= 1], [2] = sum s max(0, |e| - 1)

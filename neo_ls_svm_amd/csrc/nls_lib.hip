@@ -287,6 +287,7 @@ extern "C" int nls_ws_release(nls_ctx* ctx, size_t min_bytes, size_t* still_held
   if (!ctx) return NLS_ERR_ARG;
   HIPCHK(ctx, hipSetDevice(ctx->device));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->trd_err = nullptr;  // (lives in the workspace: the next reduction sets it again)
   for (auto it = ctx->ws.begin(); it != ctx->ws.end();) {
     if (it->second.p && it->second.bytes >= min_bytes) {
       HIPCHK(ctx, hipFree(it->second.p));
@@ -988,6 +989,7 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
     NLSCHK(ws_get_t(ctx, "sweep.T1", (size_t)st.rc * SWEEP_GN, &T1));
     NLSCHK(ws_get_t(ctx, "sweep.T2", (size_t)st.rc * SWEEP_GN, &T2));
   }
+  static const bool small_sweep = [] { const char* e = std::getenv("NLS_SWEEP_SMALL"); return !(e && e[0] == '0'); }();  // NLS_SWEEP_SMALL=0: the 128-wide tile for every G
   for (long r0 = 0; r0 < n; r0 += st.rc) {
     const long rows = std::min<long>(st.rc, n - r0);
     const long rows_pad = round_up(rows, BM);
@@ -1011,6 +1013,10 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
                            SWEEP_GN, inv_c, T1, T2, 0L);
         hipLaunchKernelGGL(k_sweep, dim3((unsigned)(Gp / BN), (unsigned)(rows_pad / BM), 2), dim3(Cfg4::NTHREADS), SMEM_REAL, ctx->stream,
                            T1, T2, SWEEP_GN, Wd, Gp, 1.0, num, hs, r0);
+      } else if (small_sweep && G <= 32) {  // short grids (the 32-point grid of the gamma x sigma sweep): the streaming form, 32 columns
+        hipLaunchKernelGGL(k_sweep_small<2>, dim3(1, (unsigned)((rows_pad + 255) / 256), 2), dim3(256), 0, ctx->stream, U, Gm, Np, R, Gp, inv_c, num, hs, Gp, r0, rows_pad);
+      } else if (small_sweep && G <= 64) {
+        hipLaunchKernelGGL(k_sweep_small<4>, dim3(1, (unsigned)((rows_pad + 255) / 256), 2), dim3(256), 0, ctx->stream, U, Gm, Np, R, Gp, inv_c, num, hs, Gp, r0, rows_pad);
       } else {
         hipLaunchKernelGGL(k_sweep, dim3((unsigned)(Gp / BN), (unsigned)(rows_pad / BM), 2), dim3(Cfg4::NTHREADS), SMEM_REAL, ctx->stream, U,
                            Gm, Np, R, Gp, inv_c, num, hs, r0);
@@ -1044,6 +1050,7 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
   HIPCHK(ctx, hipMemcpyAsync(herrs.data(), errs, sizeof(double) * 3 * Gp, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipMemcpyAsync(&lam_min, lam, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  NLSCHK(trd_check(ctx));  // (in-launch hand-offs of the eigendecomposition: an error word instead of a hang, nls_trd1.h)
   for (int g = 0; g < G; ++g)  // _neo_ls_svm.py:159-165 (same summation order as the reference)
     hobj[g] = is_clf ? (herrs[Gp + g] + herrs[2 * Gp + g]) + herrs[g] : herrs[g];
   int opt = a->gamma_index_in;

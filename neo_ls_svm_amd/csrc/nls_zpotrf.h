@@ -27,10 +27,9 @@ constexpr int NBO = 256;  // outer block column: the trailing matrix beyond it i
 // 32 x 32 diagonal block itself, in LDS - redundantly: a few microseconds of work against a kernel boundary (the panel is a chain of dependent
 // launches, and a launch costs more than the block) - then solves its rows: L21 = A21 L11^-H by forward substitution along the row,
 // x[c] = (a[c] - sum_{t < c} x[t] conj(L[c][t])) / L[c][c], one row per thread, the row in LDS ([t][thread]: conflict-free), the factor's
-// entries the same for every lane (broadcast reads).  The block is factored by WAVE 0 alone (lane = (row, column parity); LDS operations of one
-// wave complete in order, so its 32 steps need no workgroup barrier) while all waves' row loads are in flight.  Plain loops, a dozen registers
-// (a register-resident form with v_readlane broadcasts - the real leaf's design - spills ~1400 scalar registers here: every lane predicate
-// r == k, c <= r is a 64-bit mask).
+// entries the same for every lane (broadcast reads).  The block is factored by WAVE 0 alone (lane = (row, column parity): each half of the wave
+// owns the columns of one parity; LDS operations of one wave complete in order, so its 32 steps need no workgroup barrier) while all waves'
+// row loads are in flight.
 // Workgroup 0 hands L11 over (strict upper part untouched; see L11out below) and raises info (0 or the global 1-based index of the first bad pivot).
 // With `rhs_run` the right-hand side of beta = cho_solve(L, b) is carried along (the forward substitution of _neo_ls_svm.py:178 without a
 // separate pass over L, and without reading finished columns of L, which the download may already be conjugating): rhs_run holds the running
@@ -76,29 +75,42 @@ __global__ void __launch_bounds__(ZP_THREADS) k_zpotrf_panel(double2* __restrict
   }
   __syncthreads();
   int bad = 0;
-  if (!rowthr) {  // wave 0: lane = row rr (lanes 32 .. 63 mirror 0 .. 31), the row in registers, the pivot row travels by v_readlane
+  if (!rowthr) {
+    // Wave 0: lane = (row rr, half h).  Round 5: the two halves SHARE the row's columns - half h keeps and updates the columns of parity h
+    // (ao_r / ao_i[q] = entry (rr, 2 q + h)) - instead of mirroring each other: 16 instead of 31 column updates per step and lane, and the
+    // pivot column's entries L[c][k] come from the LDS copy the step has just published (two broadcast reads per column, off the VALU) instead
+    // of four v_readlane per column.  The pivot column's own entries travel from its half to both with v_permlane32_swap.  Arithmetic per
+    // element is unchanged (same products, same order): the factor is bit-identical to the mirrored form's.
     const int rr = ftid & (NBZ - 1), h = ftid >> 5;
-    // No lane predicates inside the factorisation (every r == k, c <= r is a 64-bit scalar mask; the compiler keeps all of them alive and
-    // spills): entries above the diagonal are computed as garbage and never read; the diagonal entry of step k is d / sqrt(d).
-    double ar[NBZ], ai[NBZ];
+    // No lane predicates inside the factorisation: entries above the diagonal are computed as garbage and never read; half h's update of a
+    // column <= k (the pivot column itself, once per even step) lands in a register nobody reads again.
+    double ao_r[NBZ / 2], ao_i[NBZ / 2];
 #pragma unroll
-    for (int c = 0; c < NBZ; ++c) {
-      ar[c] = Lr[rr][c];
-      ai[c] = Li[rr][c];
+    for (int q = 0; q < NBZ / 2; ++q) {
+      ao_r[q] = Lr[rr][2 * q + h];
+      ao_i[q] = Li[rr][2 * q + h];
     }
+    // v_permlane32_swap exchanges the upper 32 lanes of one operand with the lower 32 of the other; fed the same register twice, one element
+    // of the result carries the lower half's values in all 64 lanes and the other the upper half's.  Which is which is read off once (a
+    // uniform value), so the code does not depend on the operand order of the instruction.
+    const bool e0_upper = __builtin_amdgcn_readfirstlane((int)__builtin_amdgcn_permlane32_swap(h, h, false, false)[0]) != 0;
+    auto from_half = [e0_upper](double v, int hk) -> double {  // the value lane (rr, hk) holds, in both halves
+      const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(v), __double2loint(v), false, false);
+      const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(v), __double2hiint(v), false, false);
+      const bool first = e0_upper == (hk != 0);  // uniform
+      return __hiloint2double(first ? (int)hi[0] : (int)hi[1], first ? (int)lo[0] : (int)lo[1]);
+    };
 #pragma unroll
     for (int k = 0; k < NBZ; ++k) {
-      double d = potrf::readlane_f64(ar[k], k);
+      const int hk = k & 1, qk = k >> 1;
+      double d = potrf::readlane_f64(ao_r[qk], k + 32 * hk);
       if (!(d > 0.0) || !isfinite(d)) {  // uniform
         if (bad == 0) bad = k + 1;
         d = 1.0;
       }
       const double inv = 1.0 / sqrt(d);
-      const double lr = ar[k] * inv, li = ai[k] * inv;
-      ar[k] = lr;
-      ai[k] = li;
+      const double lr = from_half(ao_r[qk] * inv, hk), li = from_half(ao_i[qk] * inv, hk);
       // column k is final: publish it (rows above the diagonal hold garbage that nobody reads), then the count
-      // (no lane predicates here either: the mirror lanes 32 .. 63 store the same values to the same places)
       dv[k] = inv;
       Lr[rr][k] = lr;
       Li[rr][k] = li;
@@ -106,15 +118,14 @@ __global__ void __launch_bounds__(ZP_THREADS) k_zpotrf_panel(double2* __restrict
       __builtin_amdgcn_wave_barrier();
       __hip_atomic_store(&cols_done, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
-      for (int c = k + 1; c < NBZ; ++c) {  // a[rr][c] -= l[rr] conj(l[c])   (meaningful for rr >= c)
-        const double cr = potrf::readlane_f64(lr, c), ci = potrf::readlane_f64(li, c);
-        ar[c] -= lr * cr + li * ci;
+      for (int q = (k + 1) / 2; q < NBZ / 2; ++q) {  // a[rr][c] -= l[rr] conj(l[c]),  c = 2 q + h   (meaningful for rr >= c > k)
+        const double cr = Lr[2 * q + h][k], ci = Li[2 * q + h][k];  // (this wave's own stores: LDS operations of one wave complete in order)
+        ao_r[q] -= lr * cr + li * ci;
         // two ROUNDED products, not a fused pair: on the diagonal (rr == c) they are the same product and must cancel exactly - the diagonal
         // of the factor is real (HIP's __dmul_rn is a plain multiplication and gets contracted; the empty asm pins the rounding)
         double p1 = li * cr, p2 = lr * ci;
         asm volatile("" : "+v"(p1), "+v"(p2));
-        ai[c] -= p1 - p2;
-        if ((c & 7) == 7) __builtin_amdgcn_sched_barrier(0);  // (the broadcasts are scalar registers: keep their live ranges short)
+        ao_i[q] -= p1 - p2;
       }
       __builtin_amdgcn_sched_barrier(0);
     }

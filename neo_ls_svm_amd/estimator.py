@@ -183,7 +183,11 @@ class RandomFourierFeatures(BaseEstimator):
         else:
             gen = self.random_state if isinstance(self.random_state, np.random.RandomState) else np.random.RandomState(self.random_state)
             self.Z_ = gen.randn(d_in, self.num_features)
-        self.B_ = A @ self.Z_ if A is not None else self.Z_
+        # The fold A Z is a small product (d x r by r x D).  On the BLAS's default thread count (64 on the GPU box) its worker threads keep
+        # spinning for tens of milliseconds after the call, and the solver call that follows - a host thread that launches thousands of
+        # kernels and waits on the stream a handful of times - took 84 instead of 41 ms at n = 1e5 (profiles/r05_c2_idle.md: not the idle GPU).
+        with _prestep.blas_threads(8):
+            self.B_ = A @ self.Z_ if A is not None else self.Z_
         self.shift_, self.scale_ = np.ravel(np.asarray(shift, dtype=np.float64)), np.ravel(np.asarray(scale, dtype=np.float64))
         self.n_features_in_ = np.asarray(X).shape[1]
         return self

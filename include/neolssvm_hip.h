@@ -211,7 +211,9 @@ typedef struct nls_primal_fit_args {
   double* loo_residuals; /* n         column of the selected gamma                            */
   double* loo_leverage;  /* n                                                                 */
   double* loo_std;       /* n                                                                 */
-  double* residuals;     /* n         Re(phi beta) - y after the Cholesky re-solve            */
+  double* residuals;     /* n         Re(phi beta) - y at gamma* (_neo_ls_svm.py:179).  Read off the sweep's table, i.e. with the */
+                         /*           eigendecomposition's beta(gamma*); `beta` itself is cho_solve(L, b) - the same vector to        */
+                         /*           cond(gamma* C + A) eps, so Re(phi beta) - y equals this to that accuracy (tested: 1e-9 relative) */
   double* loo_score;     /* 1         weighted accuracy / R^2 of the LOO predictions          */
   int32_t* gamma_index;  /* 1         selected grid index                                     */
   int32_t* finished;     /* 1         1 when P8 / P9 ran (beta, L, residuals, row outputs written), else 0 */

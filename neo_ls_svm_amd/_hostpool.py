@@ -40,7 +40,7 @@ OFFSET = 64
 PIN_OUTPUTS = False  # False | "reuse" | True, see the module docstring
 LAST_REGISTER_RC = None  # return code of the most recent nls_host_register (diagnostic)
 
-_lock = threading.Lock()
+_lock = threading.RLock()  # re-entrant: a cyclic-GC pass triggered by an allocation inside a locked region may finalise another lease on this thread
 _free: dict[int, list[mmap.mmap]] = {}
 _registered: dict[int, object] = {}  # id(mapping) -> the ctypes library that page-locked it
 

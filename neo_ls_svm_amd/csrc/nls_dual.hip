@@ -340,7 +340,6 @@ extern "C" int nls_dual_fit(nls_ctx* ctx, const nls_dual_fit_args* a) {
   static const bool pin_on = [] { const char* m = std::getenv("NLS_PIN_OUTPUT"); return m && m[0] == '1'; }();
   if (a->L && pin_on) pinL.pin(a->L, sizeof(double) * (size_t)n * n);
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  NLSCHK(trd_check(ctx));  // (in-launch hand-offs of the eigendecomposition: an error word instead of a hang, nls_trd1.h)
   for (int g = 0; g < G; ++g) hobj[g] = is_clf ? (herrs[Gp + g] + herrs[2 * Gp + g]) + herrs[g] : herrs[g];  // :296-302
   int opt = a->gamma_index_in;
   if (opt < 0) {
@@ -385,6 +384,7 @@ extern "C" int nls_dual_fit(nls_ctx* ctx, const nls_dual_fit_args* a) {
     enum { LANES = 2 };  // (four lanes: no further gain)
     std::thread t[LANES];
     int rc[LANES] = {NLS_OK, NLS_OK};
+    std::string msg[LANES];  // each lane's own failure message (tls_err_sink): ctx->err belongs to the calling thread
     void join() {
       for (auto& th : t)
         if (th.joinable()) th.join();
@@ -421,13 +421,16 @@ extern "C" int nls_dual_fit(nls_ctx* ctx, const nls_dual_fit_args* a) {
       void* hostL = a->L;
       for (int lane = 0; lane < HelperJoin::LANES; ++lane)
         dl.t[lane] = std::thread([ctx, hostL, M2, n, n_pad, lane, &dl] {
+          tls_err_sink = &dl.msg[lane];  // (this thread's failures go to its own slot, never to ctx->err: the caller reports them after the join)
           hipStream_t cs = lane == 0 ? ctx->copy_stream : ctx->copy_lane[lane - 1];
-          if (hipSetDevice(ctx->device) != hipSuccess) {
-            dl.rc[lane] = NLS_ERR_HIP;
+          hipError_t e = hipSetDevice(ctx->device);
+          if (e != hipSuccess) {
+            dl.rc[lane] = fail(ctx, NLS_ERR_HIP, "hipSetDevice in download lane %d: %s", lane, hipGetErrorString(e));
             return;
           }
           dl.rc[lane] = download_block_columns(ctx, hostL, M2, (int)n, n_pad, sizeof(double), 512, false, lane, HelperJoin::LANES, cs);
-          if (dl.rc[lane] == NLS_OK && hipStreamSynchronize(cs) != hipSuccess) dl.rc[lane] = NLS_ERR_HIP;
+          if (dl.rc[lane] == NLS_OK && (e = hipStreamSynchronize(cs)) != hipSuccess)
+            dl.rc[lane] = fail(ctx, NLS_ERR_HIP, "hipStreamSynchronize in download lane %d: %s", lane, hipGetErrorString(e));
         });
     }
     // alpha = cho_solve(L_, y) (_neo_ls_svm.py:314: "resolve the linear system for better accuracy"): two triangular solves with one right-hand
@@ -466,7 +469,7 @@ extern "C" int nls_dual_fit(nls_ctx* ctx, const nls_dual_fit_args* a) {
     // Column-major lower Cholesky factor == row-major upper factor U (M2 = U^T U): scipy's lower=False layout.
     dl.join();
     for (int lane = 0; lane < HelperJoin::LANES; ++lane)
-      if (dl.rc[lane] != NLS_OK) return dl.rc[lane] == NLS_ERR_HIP ? fail(ctx, NLS_ERR_HIP, "download of the Cholesky factor failed") : dl.rc[lane];
+      if (dl.rc[lane] != NLS_OK) return fail(ctx, dl.rc[lane], "download of the Cholesky factor (lane %d): %s", lane, dl.msg[lane].c_str());
     if (pipelined_L) HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));
   }
   NLSCHK(spans_collect(ctx, tm));

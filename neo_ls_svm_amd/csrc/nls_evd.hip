@@ -6,7 +6,6 @@
 #include "nls_trd.h"
 #include "nls_sb.h"
 #include "nls_chase.h"
-#include "nls_trd1.h"
 #include "nls_q2.h"
 #include "nls_stedc.h"
 
@@ -34,12 +33,6 @@ static bool trd_three_kernels(int n) {
   if (m && m[0] == '3') return true;
   if (m && m[0] == '2') return false;
   return n > 6144;
-}
-// One launch per column (nls_trd1.h: the finish blocks ride in the matrix-vector launch behind a flag hand-off) where two kernels per column
-// are used today; NLS_TRD_LAUNCHES=2 keeps the two-launch form of nls_trd.h (bit-identical results).
-static bool trd_one_launch() {
-  const char* m = std::getenv("NLS_TRD_LAUNCHES");
-  return !(m && m[0] == '2');
 }
 static int trd_dotgroups(int n) {  // 64-row groups per dot block (NLS_TRD_DOTGROUPS overrides the size rule; test hook)
   if (const char* m = std::getenv("NLS_TRD_DOTGROUPS")) {
@@ -84,23 +77,17 @@ static int trd_fused(nls_ctx* ctx, T* A, int n, long lda, double* d, double* e, 
   HIPCHK(ctx, hipMemsetAsync(a.W, 0, sizeof(T) * (size_t)n * NB, ctx->stream));
   BLASCHK(ctx, rocblas_set_stream(ctx->blas, ctx->stream));
   const bool two_kernels = !trd_three_kernels(n);
-  const bool one_launch = two_kernels && trd_one_launch();
   T *wt[2] = {a.wtmp, nullptr}, *sp[2] = {a.spart, nullptr};
-  unsigned* flags = nullptr;
-  const size_t nflags = (size_t)NSC * (NSC + 1) / 2 + (size_t)ndot_max + 8;
   if (two_kernels) {
     NLSCHK(ws_get_t(ctx, "trd.wtmp2", (size_t)n, &wt[1]));
     NLSCHK(ws_get_t(ctx, "trd.spart2", (size_t)nrb, &sp[1]));
     NLSCHK(ws_get_t(ctx, "trd.bvec", (size_t)n, &a.bvec));
   }
-  if (one_launch) {  // producer flags of a column (epoch = column + 1: zeroed once per reduction) followed by the error word
-    NLSCHK(ws_get_t(ctx, "trd.flags", nflags + 8, &flags));
-    HIPCHK(ctx, hipMemsetAsync(flags, 0, sizeof(unsigned) * (nflags + 8), ctx->stream));
-    ctx->trd_err = flags + nflags;
-  }
   // 2-3 kernels per column, ~8200 launches at n = 4097.  (A hipGraph replay of this sequence and a persistent one-launch
-  // panel were built and measured slower in round 2 - the cost is the GPU's own dependent-dispatch latency: profiles/r02_trd_graph.log,
-  // profiles/r02_trd_persistent.log; they are in the history, not in the library.)
+  // panel were built and measured slower in round 2 - profiles/r02_trd_graph.log, profiles/r02_trd_persistent.log - and so was, in round 5,
+  // a ONE-launch column whose finish blocks ride behind the matrix-vector blocks on a flag hand-off (write-through stores + polled flags, the
+  // bulge chase's protocol): bit-identical, 110.6 against 100.6 ms at n = 4097 - profiles/r05_evd_one_launch.md.  The kernel times of a column add
+  // up to its wall time: there is no launch gap to remove, only the kernels' own dependent round trips.  None of the three is in the library.)
   auto enqueue = [&]() -> int {
   int cur = 0;  // buffer that the column being finished writes (two-kernel variant)
   for (int j0 = 0; j0 < n; j0 += NB) {
@@ -117,12 +104,6 @@ static int trd_fused(nls_ctx* ctx, T* A, int n, long lda, double* d, double* e, 
         a.spart_prev = sp[cur ^ 1];
         a.ndot = (n - j + RD - 1) / RD;  // dot blocks start at row j
         a.make_base = j + 1 < jend;
-        if (one_launch && j < n - 1) {
-          const Fuse f{flags, flags + nflags, (unsigned)(j + 1)};
-          hipLaunchKernelGGL(k_trd_col1<T>, dim3(ntiles + a.ndot + nrb), dim3(256), 0, ctx->stream, a, S0, ntiles, NSR, f);
-          cur ^= 1;
-          continue;
-        }
         hipLaunchKernelGGL(k_trd_hemv2<T>, dim3((j < n - 1 ? ntiles : 0) + a.ndot), dim3(256), 0, ctx->stream, a, S0, j < n - 1 ? ntiles : 0);
         if (j < n - 1) {
           hipLaunchKernelGGL(k_trd_finish2<T>, dim3(nrb), dim3(ROWT * TPR), 0, ctx->stream, a, S0, NSR);
@@ -1015,7 +996,6 @@ extern "C" int nls_tridiag_only(nls_ctx* ctx, void* A, int n, int is_complex, do
     HIPCHK(ctx, hipMemcpyAsync(tau, dtau, esz * (size_t)(n - 1), hipMemcpyDeviceToHost, ctx->stream));
   }
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  NLSCHK(trd_check(ctx));
   return NLS_OK;
 }
 
@@ -1045,7 +1025,6 @@ extern "C" int nls_eigh_only(nls_ctx* ctx, void* A, int n, int is_complex, doubl
   HIPCHK(ctx, hipMemcpyAsync(A, Q, esz * (size_t)n * n, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipMemcpyAsync(lam, dlam, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  NLSCHK(trd_check(ctx));
   return NLS_OK;
 }
 

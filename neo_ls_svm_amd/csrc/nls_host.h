@@ -87,7 +87,6 @@ struct nls_ctx {
   int gram_order = -1;
   int k1_stagger_ticks = 0;  // NLS_K1_STAGGER_US: period over which the first-round workgroups of K1 are spread (k1_stagger)
   int rot_kstagger = 0;  // NLS_ROT_KSTAGGER=S: K-walk phase (tr + tc) % S slices per workgroup (see mainloop_3m)
-  unsigned* trd_err = nullptr;  // device word raised by the one-launch-per-column tridiagonalisation when a poll timed out (nls_trd1.h; checked at the next host sync)
   bool no_resident = false;  // NLS_NO_RESIDENT_PLANES=1: recompute the feature planes per phase even when they would fit
   // stage timing
   struct Span {
@@ -101,13 +100,19 @@ struct nls_ctx {
 
 extern std::string g_create_error;
 
+// Helper threads of a call (the dual fit's download lanes) must not write ctx->err while the calling thread may be failing too: a thread that
+// sets this sink gets its messages there and the caller reports them after the join.
+static thread_local std::string* tls_err_sink = nullptr;
+
 static int fail(nls_ctx* ctx, int code, const char* fmt, ...) {
   char buf[1024];
   va_list ap;
   va_start(ap, fmt);
   vsnprintf(buf, sizeof(buf), fmt, ap);
   va_end(ap);
-  if (ctx)
+  if (tls_err_sink)
+    *tls_err_sink = buf;
+  else if (ctx)
     ctx->err = buf;
   else
     g_create_error = buf;
@@ -443,20 +448,6 @@ __global__ void k_merge_block_info(const int* infos, int nblk, int nbk, int* out
   for (int b = 0; b < nblk && r == 0; ++b)
     if (infos[b] != 0) r = b * nbk + infos[b];
   *out = r;
-}
-
-// The one-launch-per-column tridiagonalisation (nls_trd1.h) raises a device word instead of hanging when a hand-off inside a launch timed out.
-// Synchronises the stream; call where the host waits anyway.
-static int trd_check(nls_ctx* ctx) {
-  if (!ctx->trd_err) return NLS_OK;
-  unsigned h = 0;
-  HIPCHK(ctx, hipMemcpyAsync(&h, ctx->trd_err, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  if (h != 0) {
-    HIPCHK(ctx, hipMemsetAsync(ctx->trd_err, 0, sizeof(unsigned), ctx->stream));
-    return fail(ctx, NLS_ERR_HIP, "tridiagonalisation: a hand-off inside the one-launch column kernel timed out (NLS_TRD_LAUNCHES=2 selects the two-launch form)");
-  }
-  return NLS_OK;
 }
 
 static int check_info(nls_ctx* ctx, rocblas_int* dinfo, const char* what) {

@@ -320,16 +320,40 @@ __global__ void __launch_bounds__(m3::NT3, 1)
   // row split, same or adjacent tj - and share their A panel (and most B panels) in that L2, instead of every XCD streaming every panel.
   // The grid is padded to a multiple of 8; the order never enters the arithmetic (one slab slot per (split, tile)).
   long lin = blockIdx.x;
-  if (xcd_contig) {
-    const long per = (nblocks + 7) / 8;
-    lin = (long)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    if (lin >= nblocks) return;
+  int tj, tk64, split;
+  if (xcd_contig == 2) {
+    // XCD PATCH order (round 5): the 32 workgroups an XCD runs at a time form a patch of 4 tile rows x 8 half-tile columns of ONE row split:
+    // 4 A panels (128 columns each) + 8 B panels (64 each) = 16 panel-units of 64 columns through that L2 for 32 tiles, against 34 in the
+    // contiguous order (one tile row, 32 different B panels) and up to 96 in the plain one.  Patches tile the block triangle (patch (a, b), b <= a;
+    // the diagonal patches are 20 / 32 full: their padding blocks return at once).  nblocks here = patches x 32.
+    const int nt = (int)((sqrt(4.0 * nhalf + 1.0) - 1.0) * 0.5 + 0.5);  // nhalf = nt (nt + 1)
+    const int pa = (nt + 3) / 4, npatch = pa * (pa + 1) / 2;
+    const long xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const long patch = (slot / 32) * 8 + xcd;
+    const int within = (int)(slot % 32);
+    split = (int)(patch / npatch);
+    const int pid = (int)(patch % npatch);
+    int a = (int)((sqrt(8.0 * pid + 1.0) - 1.0) * 0.5);
+    while ((a + 1) * (a + 2) / 2 <= pid) ++a;
+    while (a * (a + 1) / 2 > pid) --a;
+    const int b = pid - a * (a + 1) / 2;
+    tj = 4 * a + within / 8;
+    tk64 = 8 * b + within % 8;
+    if ((long)split * rows_per_split >= rows_pad || tj >= nt || tk64 > 2 * tj + 1) return;
+    lin = 0;
+  } else {
+    if (xcd_contig) {
+      const long per = (nblocks + 7) / 8;
+      lin = (long)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+      if (lin >= nblocks) return;
+    }
+    const int half = (int)(lin % nhalf);
+    split = (int)(lin / nhalf);
+    tj = (int)((sqrt(4.0 * half + 1.0) - 1.0) * 0.5);
+    while ((tj + 1) * (tj + 2) <= half) ++tj;
+    while (tj * (tj + 1) > half) --tj;
+    tk64 = half - tj * (tj + 1);
   }
-  const int half = (int)(lin % nhalf), split = (int)(lin / nhalf);
-  int tj = (int)((sqrt(4.0 * half + 1.0) - 1.0) * 0.5);
-  while ((tj + 1) * (tj + 2) <= half) ++tj;
-  while (tj * (tj + 1) > half) --tj;
-  const int tk64 = half - tj * (tj + 1);
   const long r0 = (long)split * rows_per_split;
   long r1 = r0 + rows_per_split;
   if (r1 > rows_pad) r1 = rows_pad;

@@ -164,7 +164,7 @@ extern "C" int nls_ctx_create(int device, nls_ctx** out) {
   ctx->cus = prop.multiProcessorCount;
   if (const char* ep = std::getenv("NLS_ROT_PATCH")) ctx->rot_patch_set = std::sscanf(ep, "%dx%d", &ctx->rot_pr, &ctx->rot_pc) == 2;
   if (const char* er = std::getenv("NLS_NO_RESIDENT_PLANES")) ctx->no_resident = er[0] == '1';
-  if (const char* eg = std::getenv("NLS_GRAM_ORDER")) ctx->gram_order = std::string(eg) != "plain" ? 1 : 0;
+  if (const char* eg = std::getenv("NLS_GRAM_ORDER")) ctx->gram_order = std::string(eg) == "patch" ? 2 : (std::string(eg) != "plain" ? 1 : 0);
   if (const char* es = std::getenv("NLS_K1_STAGGER_US")) ctx->k1_stagger_ticks = std::max(0, std::min(100000, (int)(std::atof(es) * 100.0)));
   if (const char* et = std::getenv("NLS_K1_SINCOS")) ctx->k1_table = std::string(et) == "table";
   if (const char* ek = std::getenv("NLS_ROT_KSTAGGER")) ctx->rot_kstagger = std::max(0, std::min(16, std::atoi(ek)));
@@ -287,7 +287,6 @@ extern "C" int nls_ws_release(nls_ctx* ctx, size_t min_bytes, size_t* still_held
   if (!ctx) return NLS_ERR_ARG;
   HIPCHK(ctx, hipSetDevice(ctx->device));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  ctx->trd_err = nullptr;  // (lives in the workspace: the next reduction sets it again)
   for (auto it = ctx->ws.begin(); it != ctx->ws.end();) {
     if (it->second.p && it->second.bytes >= min_bytes) {
       HIPCHK(ctx, hipFree(it->second.p));
@@ -533,9 +532,14 @@ static int primal_gram_phase(nls_ctx* ctx, PrimalState& st, double* timings) {
       const long rps = round_up((rows_pad + nsplit - 1) / nsplit, BK);
       const long ns = (rows_pad + rps - 1) / rps;
       const long gblocks = half_tiles * ns;
-      const bool contig = ctx->gram_order >= 0 ? ctx->gram_order == 1 : multi_rank(ctx);
-      hipLaunchKernelGGL(k_gram3, dim3((unsigned)(contig ? round_up(gblocks, 8) : gblocks)), dim3(m3::NT3), m3::SMEM3, ctx->stream,
-                         planes_c(st, r0), planes_s(st, r0), mp.Kf, rows_pad, st.ntri, rps, slab, gblocks, contig ? 1 : 0);
+      const int order = ctx->gram_order >= 0 ? ctx->gram_order : (multi_rank(ctx) ? 1 : 0);  // 0 plain, 1 XCD-contiguous, 2 XCD patches (k_gram3)
+      long ggrid = order == 1 ? round_up(gblocks, 8) : gblocks;
+      if (order == 2) {
+        const long pa = (st.nt + 3) / 4, npatch = pa * (pa + 1) / 2;
+        ggrid = round_up(ns * npatch, 8) * 32;
+      }
+      hipLaunchKernelGGL(k_gram3, dim3((unsigned)ggrid), dim3(m3::NT3), m3::SMEM3, ctx->stream,
+                         planes_c(st, r0), planes_s(st, r0), mp.Kf, rows_pad, st.ntri, rps, slab, gblocks, order);
       HIPCHK(ctx, hipGetLastError());
       hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)((st.tile_elems + 255) / 256)), dim3(256), 0, ctx->stream, slab, (int)ns,
                          (long)st.tile_elems, st.gacc);
@@ -1050,7 +1054,6 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
   HIPCHK(ctx, hipMemcpyAsync(herrs.data(), errs, sizeof(double) * 3 * Gp, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipMemcpyAsync(&lam_min, lam, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  NLSCHK(trd_check(ctx));  // (in-launch hand-offs of the eigendecomposition: an error word instead of a hang, nls_trd1.h)
   for (int g = 0; g < G; ++g)  // _neo_ls_svm.py:159-165 (same summation order as the reference)
     hobj[g] = is_clf ? (herrs[Gp + g] + herrs[2 * Gp + g]) + herrs[g] : herrs[g];
   int opt = a->gamma_index_in;

@@ -54,21 +54,6 @@ def test_tridiagonalisation_reads_only_the_lower_triangle(hp):
     assert np.array_equal(d, d0) and np.array_equal(e, e0)
 
 
-@pytest.mark.parametrize("cplx", [True, False])
-@pytest.mark.parametrize("n", [2, 33, 130, 700, 1025, 2500])
-def test_one_launch_per_column_equals_the_two_launch_form(n, cplx, hp, monkeypatch):
-    """Round 5: the finish blocks of a column ride in the matrix-vector launch behind a flag hand-off (``csrc/nls_trd1.h``; one launch per column
-    instead of two).  Same arithmetic, same summation orders: d, e, tau and the reflectors are bit-identical to the two-launch form
-    (``NLS_TRD_LAUNCHES=2``), and the error word of the hand-off stays clear (a time-out would surface as a RuntimeError here)."""
-    A = _hermitian(n, cplx, 300 + n)
-    monkeypatch.setenv("NLS_TRD_LAUNCHES", "2")
-    two = hp.tridiagonalize(A)
-    monkeypatch.delenv("NLS_TRD_LAUNCHES")
-    for _ in range(3):  # (repeated: the hand-off is a race if it is wrong)
-        one = hp.tridiagonalize(A)
-        assert all(np.array_equal(a, b) for a, b in zip(one, two))
-
-
 def test_tridiagonalisation_is_bit_reproducible(hp):
     A = _hermitian(300, True, 6)
     r1, r2 = hp.tridiagonalize(A), hp.tridiagonalize(A)

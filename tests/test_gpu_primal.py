@@ -173,6 +173,44 @@ def test_primal_fit_device_resident_inputs_and_chunking(golden_loader, hp):
     assert r2["opt"] == r0["opt"]
 
 
+def test_gram_tile_orders_are_bit_identical(golden_loader, monkeypatch):
+    """The Gram kernel's workgroup order (plain / XCD-contiguous / XCD patches, ``NLS_GRAM_ORDER``) decides which L2 sees which operand panel,
+    never the arithmetic: one slab slot per (row split, tile), fixed-order reduction - A and b are bit-identical in all three."""
+    import neo_ls_svm_amd as pkg
+
+    rng = np.random.default_rng(11)
+    n, d, D = 9000, 16, 700  # 6 tile rows: one full 4-row patch band, one partial
+    X = rng.standard_normal((n, d))
+    y = rng.standard_normal(n)
+    s = rng.uniform(0.5, 2.0, n)
+    B = pkg.orf_frequencies(d, D) * 0.3
+    out = {}
+    for order in ("plain", "contiguous", "patch"):
+        monkeypatch.setenv("NLS_GRAM_ORDER", order)
+        ctx = pkg.Context(0)
+        out[order] = pkg.gram(X, y, s, np.zeros(d), np.ones(d), B, ctx=ctx)
+        ctx.close()
+    for order in ("contiguous", "patch"):
+        assert np.array_equal(out[order][0], out["plain"][0]) and np.array_equal(out[order][1], out["plain"][1]), order
+    A, b = orc.primal_gram(orc.feature_map(X, np.zeros(d), np.ones(d), B), y, s)[:2]
+    assert relerr(out["patch"][0], A) < 1e-12 and relerr(out["patch"][1], b) < 1e-12
+
+
+def test_returned_residuals_are_those_of_the_returned_beta(golden_loader, hp):
+    """``residuals`` comes from the sweep's table (the eigendecomposition's beta at gamma*), ``beta`` from the Cholesky re-solve
+    (``_neo_ls_svm.py:176-179``): the returned pair must agree, Re(phi(X) beta) - y == residuals, to cond * eps (header note)."""
+    for name in ("primal_reg_n3000_d20_D256", "primal_clf_n3000_d16_D256_wz"):
+        g = golden_loader(name)
+        y = signed_targets(g)
+        clf = g["task"] == "clf"
+        r = hp.primal_fit(g["X"], y, g["s"], g["shift"], g["scale"], g["B"], clf)
+        yhat, _ = hp.primal_predict(g["X"], g["shift"], g["scale"], g["B"], beta=r["beta"])
+        e = yhat - y
+        if clf:  # residual clipping of the classifier (_neo_ls_svm.py:180-182)
+            e = np.where(y * e > 0, 0.0, e)
+        assert np.max(np.abs(e - r["residuals"])) <= 1e-9 * max(np.max(np.abs(r["residuals"])), 1e-300), name
+
+
 def test_sigma_grid_matches_reference(golden_loader, hp):
     """gamma x sigma grid of SURVEY.md 8(d): B / sigma_k with the 32-point sub-grid gammas[::33]."""
     sg = golden_loader("sigma_grid_reg_n3000")

@@ -18,7 +18,8 @@
  *   nls_bin_stats           per-bin weighted medians / deviations        _affine_normalizer.py:72-79
  *   nls_dual_predict        decision_function / predict_std (dual)       _neo_ls_svm.py:666-671, 470-477
  *   nls_factor_create       cho_solve(self.L_, .) state of predict_std   _neo_ls_svm.py:464-469 (the factor kept on the device)
- *   nls_comm_*              (no counterpart: the reference is single-process)
+ *   nls_primal_fit_grid     the gamma x sigma grid (extension): the fit above once per sigma, one call
+ *   nls_comm_*, nls_group_* (no counterpart: the reference is single-process; SURVEY.md 8(b) "multi-GPU is internal to the ctx", 8(e))
  *
  * Conventions
  *   - Every call returns 0 on success, non-zero on failure; nls_last_error() gives the message.
@@ -37,7 +38,8 @@
  *     run alone.  (Round 3's failures in this mode were rocsolver_zpotrf, which is not safe on two handles at once in this ROCm build -
  *     profiles/r04_two_contexts.md; the fit path no longer calls it.  NLS_POTRF=rocsolver, a diagnostic knob, brings it back: single context only.)
  *     The library never uses a CPU fallback.
- *   - Multi-GPU: one process and one context per GPU, rows sharded by the caller.  The path exchanges data at
+ *   - Multi-GPU: one context per GPU - the contexts of N launched processes (nls_comm_init_rank, rows sharded by the caller), or the member
+ *     contexts of ONE process's group (nls_group_create: rows sharded inside nls_group_primal_fit).  Either way the path exchanges data at
  *     four points: {sum s, sum s*y, n}, the Hermitian block A||b (sum all-reduce), the eigenvectors (rank 0 runs the
  *     tridiagonal eigensolver and broadcasts; every rank back-transforms one column block; all-gather) and the
  *     per-gamma error vectors (sum all-reduce).  The collectives are RCCL calls on the library's own stream once

@@ -15,7 +15,8 @@
  *                           fused with the transform that feeds it       _neo_ls_svm.py:386,401-402
  *   nls_primal_predict      decision_function / predict_std (primal)     _neo_ls_svm.py:661-665, 464-469,477
  *   nls_dual_fit            NeoLSSVM._optimize_alpha_gamma(X, y, s)      _neo_ls_svm.py:191-325
- *   nls_bin_stats           per-bin weighted medians / deviations        _affine_normalizer.py:72-79
+ *   nls_bin_stats(_labels)  per-bin weighted medians / deviations        _affine_normalizer.py:72-79
+ *   nls_rank_codes          np.unique(y, return_inverse) of the quantiser _quantizer.py:246-253
  *   nls_dual_predict        decision_function / predict_std (dual)       _neo_ls_svm.py:666-671, 470-477
  *   nls_factor_create       cho_solve(self.L_, .) state of predict_std   _neo_ls_svm.py:464-469 (the factor kept on the device)
  *   nls_primal_fit_grid     the gamma x sigma grid (extension): the fit above once per sigma, one call
@@ -356,6 +357,15 @@ int nls_primal_predict(nls_ctx* ctx, const double* X, int64_t m, int d, const do
  * centers, spreads: nbins x d, host. */
 int nls_bin_stats(nls_ctx* ctx, const double* X, const double* s, int64_t n, int d, const int32_t* perm,
                   const int64_t* bin_off, int nbins, double* centers, double* spreads);
+/* The same statistics from the per-row bin labels (0 .. nbins - 1, host): the grouping (numpy's argsort(labels, kind="stable") + bincount /
+ * cumsum in the call above's caller) runs on the device - one stable radix sort of (label, row) pairs - and yields the same permutation, hence
+ * bit-identical statistics. */
+int nls_bin_stats_labels(nls_ctx* ctx, const double* X, const double* s, int64_t n, int d, const int32_t* labels, int nbins,
+                         double* centers, double* spreads);
+/* Rank codes of the targets: inverse[i] = rank of y[i] among the distinct values of y, *nunique = their number - what
+ * numpy.unique(y, return_inverse=True) gives the target quantiser (sample_bins_quantized_ecdf, _quantizer.py:246-253).  y: n finite doubles,
+ * host | device; inverse: n int64, host.  (-0.0 and +0.0 are one value, as numpy compares them.) */
+int nls_rank_codes(nls_ctx* ctx, const double* y, int64_t n, int64_t* inverse, int64_t* nunique);
 
 /* ---- dual fit --------------------------------------------------------------------------------- */
 typedef struct nls_dual_fit_args {

@@ -207,6 +207,11 @@ SIGNATURES = {
         C.c_int,
         [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p],
     ),
+    "nls_bin_stats_labels": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p],
+    ),
+    "nls_rank_codes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int64)]),
     "nls_dual_fit": (C.c_int, [C.c_void_p, C.POINTER(DualFitArgs)]),
     "nls_dual_predict": (
         C.c_int,

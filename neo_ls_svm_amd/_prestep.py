@@ -134,17 +134,22 @@ def _ecdf_bin_edges(values, max_bin_error=0.0125, max_bin_size=0.125, merge_bin_
     return np.asarray(edges, dtype=np.float64)
 
 
-def target_bins(y: np.ndarray) -> np.ndarray:
+def target_bins(y: np.ndarray, unique=None) -> np.ndarray:
     """Integer class-bin label per sample: ``sample_bins_quantized_ecdf``, ``_quantizer.py:246-253``.
 
     Few distinct targets (<= ceil(sqrt(n))) are their own bins (classification); otherwise the target's
-    ECDF is quantised into dynamically sized bins.
+    ECDF is quantised into dynamically sized bins.  ``unique(y) -> (inverse, number of distinct values)`` replaces
+    ``numpy.unique(y, return_inverse=True)`` (``hotpath.rank_codes``: the same codes from a radix sort on the GPU).
     """
     y = np.asarray(y)
     memo = _BINS_MEMO.get("last")  # fit() bins the same target twice (normaliser, separator): reuse the labels
     if memo is not None and memo[0].shape == y.shape and memo[0].dtype == y.dtype and np.array_equal(memo[0], y):
         return memo[1]
-    uniq, inv = np.unique(y, return_inverse=True)
+    if unique is not None and y.dtype == np.float64 and y.size > 4096:
+        inv, nuniq = unique(y)
+        uniq = range(nuniq)
+    else:
+        uniq, inv = np.unique(y, return_inverse=True)
     if len(uniq) <= np.ceil(np.sqrt(len(y))):
         labels = inv
     else:
@@ -192,7 +197,7 @@ def _split_bins(X, y, sw):
     return masks, X_bins, n_bins, s_bins
 
 
-def fit_affine_normalizer(X: np.ndarray, y: np.ndarray, sample_weight: np.ndarray | None = None, stats=None):
+def fit_affine_normalizer(X: np.ndarray, y: np.ndarray, sample_weight: np.ndarray | None = None, stats=None, unique=None):
     """(shift, scale), each 1 x d: ``AffineNormalizer.fit``, ``_affine_normalizer.py:50-117``.
 
     Per-bin weighted medians and mean absolute deviations; every pair of bins votes for a separating
@@ -205,7 +210,7 @@ def fit_affine_normalizer(X: np.ndarray, y: np.ndarray, sample_weight: np.ndarra
     sw = (np.ones(y.shape) if sample_weight is None else np.ravel(np.asarray(sample_weight))).astype(y.dtype)
     d = X.shape[1]
     if stats is not None:
-        labels = target_bins(y)
+        labels = target_bins(y, unique)
         nb = int(labels.max() - labels.min()) + 1
         if nb <= 1:
             return np.zeros((1, d), dtype=X.dtype), np.ones((1, d), dtype=X.dtype)
@@ -283,6 +288,7 @@ def fit_affine_separator(
     edge_search_multiplier: int = 4,
     random_state=42,
     normalizer=None,
+    unique=None,
 ):
     """(shift, scale, A): ``AffineSeparator.fit``, ``_affine_separator.py:107-210``.  A is None for one bin.
 
@@ -302,12 +308,12 @@ def fit_affine_separator(
     # The edge-sample products below are a few hundred rows wide: on a 64-thread BLAS they spend their time in thread
     # hand-offs (13 ms per 1536 x 128 x 1536 product against 3 ms on 8 threads).
     with blas_threads(8):
-        return _separator_directions(X, y, sample_weight, shift, scale, rank_threshold, edge_sample_size, edge_search_multiplier, random_state)
+        return _separator_directions(X, y, sample_weight, shift, scale, rank_threshold, edge_sample_size, edge_search_multiplier, random_state, unique)
 
 
-def _separator_directions(X, y, sample_weight, shift, scale, rank_threshold, edge_sample_size, edge_search_multiplier, random_state):
+def _separator_directions(X, y, sample_weight, shift, scale, rank_threshold, edge_sample_size, edge_search_multiplier, random_state, unique=None):
     sw = (np.ones(y.shape) if sample_weight is None else np.ravel(np.asarray(sample_weight))).astype(y.dtype)
-    labels = target_bins(y)
+    labels = target_bins(y, unique)
     ids = [np.flatnonzero(labels == i) for i in range(np.min(labels), np.max(labels) + 1)]
     if len(ids) <= 1:
         return shift, scale, None

@@ -139,13 +139,9 @@ __global__ void k_segment_median(const double* a_all, const int* v_all, const do
 
 }  // namespace
 
-// centers, spreads: nbins x d (host).  perm: the n row indices grouped by bin (stable), bin_off: nbins + 1 offsets into perm.
-extern "C" int nls_bin_stats(nls_ctx* ctx, const double* X, const double* s, int64_t n, int d, const int32_t* perm,
-                             const int64_t* bin_off, int nbins, double* centers, double* spreads) {
-  if (!ctx) return NLS_ERR_ARG;
-  if (!X || !s || !perm || !bin_off || !centers || !spreads || n < 1 || d < 1 || nbins < 1)
-    return fail(ctx, NLS_ERR_ARG, "nls_bin_stats: NULL argument or empty problem");
-  HIPCHK(ctx, hipSetDevice(ctx->device));
+// Shared core: dperm (the n row indices grouped by bin, stable) and doff (nbins + 1 offsets into it) are on the device.
+static int bin_stats_core(nls_ctx* ctx, const double* X, const double* s, int64_t n, int d, const int* dperm, const long* doff, int nbins,
+                          double* centers, double* spreads) {
   // Column groups keep one segmented sort below 2^30 keys (hipCUB counts items in an int) and ~24 bytes/key of workspace.
   const int dg = (int)std::max<int64_t>(1, std::min<int64_t>(d, ((int64_t)1 << 30) / n));
   if ((int64_t)n > ((int64_t)1 << 30)) return fail(ctx, NLS_ERR_ARG, "nls_bin_stats: n too large");
@@ -153,11 +149,9 @@ extern "C" int nls_bin_stats(nls_ctx* ctx, const double* X, const double* s, int
   const double *dX = nullptr, *ds = nullptr;
   NLSCHK(resident(ctx, "in.X", X, (size_t)n * d, &dX));
   NLSCHK(resident(ctx, "in.s", s, (size_t)n, &ds));
-  int *dperm = nullptr, *Vin = nullptr, *Vout = nullptr;
-  long *doff = nullptr, *sbeg = nullptr, *send = nullptr;
+  int *Vin = nullptr, *Vout = nullptr;
+  long *sbeg = nullptr, *send = nullptr;
   double *Kin = nullptr, *Kout = nullptr, *ws = nullptr, *dcen = nullptr, *dspr = nullptr;
-  NLSCHK(ws_get_t(ctx, "pre.perm", (size_t)n, &dperm));
-  NLSCHK(ws_get_t(ctx, "pre.off", (size_t)nbins + 1, &doff));
   NLSCHK(ws_get_t(ctx, "pre.sbeg", (size_t)dg * nbins, &sbeg));
   NLSCHK(ws_get_t(ctx, "pre.send", (size_t)dg * nbins, &send));
   NLSCHK(ws_get_t(ctx, "pre.Kin", (size_t)Ng, &Kin));
@@ -167,9 +161,6 @@ extern "C" int nls_bin_stats(nls_ctx* ctx, const double* X, const double* s, int
   NLSCHK(ws_get_t(ctx, "pre.ws", (size_t)n, &ws));
   NLSCHK(ws_get_t(ctx, "pre.cen", (size_t)d * nbins, &dcen));
   NLSCHK(ws_get_t(ctx, "pre.spr", (size_t)d * nbins, &dspr));
-  HIPCHK(ctx, hipMemcpyAsync(dperm, perm, sizeof(int) * n, hipMemcpyHostToDevice, ctx->stream));
-  static_assert(sizeof(long) == sizeof(int64_t), "offsets are 64-bit");
-  HIPCHK(ctx, hipMemcpyAsync(doff, bin_off, sizeof(long) * (nbins + 1), hipMemcpyHostToDevice, ctx->stream));
   hipLaunchKernelGGL(k_gather_weights, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ds, dperm, (long)n, ws);
   HIPCHK(ctx, hipGetLastError());
   for (int j0 = 0; j0 < d; j0 += dg) {
@@ -195,5 +186,122 @@ extern "C" int nls_bin_stats(nls_ctx* ctx, const double* X, const double* s, int
   HIPCHK(ctx, hipMemcpyAsync(centers, dcen, sizeof(double) * d * nbins, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipMemcpyAsync(spreads, dspr, sizeof(double) * d * nbins, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return NLS_OK;
+}
+
+// centers, spreads: nbins x d (host).  perm: the n row indices grouped by bin (stable), bin_off: nbins + 1 offsets into perm.
+extern "C" int nls_bin_stats(nls_ctx* ctx, const double* X, const double* s, int64_t n, int d, const int32_t* perm,
+                             const int64_t* bin_off, int nbins, double* centers, double* spreads) {
+  if (!ctx) return NLS_ERR_ARG;
+  if (!X || !s || !perm || !bin_off || !centers || !spreads || n < 1 || d < 1 || nbins < 1)
+    return fail(ctx, NLS_ERR_ARG, "nls_bin_stats: NULL argument or empty problem");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int* dperm = nullptr;
+  long* doff = nullptr;
+  NLSCHK(ws_get_t(ctx, "pre.perm", (size_t)n, &dperm));
+  NLSCHK(ws_get_t(ctx, "pre.off", (size_t)nbins + 1, &doff));
+  HIPCHK(ctx, hipMemcpyAsync(dperm, perm, sizeof(int) * n, hipMemcpyHostToDevice, ctx->stream));
+  static_assert(sizeof(long) == sizeof(int64_t), "offsets are 64-bit");
+  HIPCHK(ctx, hipMemcpyAsync(doff, bin_off, sizeof(long) * (nbins + 1), hipMemcpyHostToDevice, ctx->stream));
+  return bin_stats_core(ctx, X, s, n, d, dperm, doff, nbins, centers, spreads);
+}
+
+namespace {
+__global__ void k_iota(int* v, long n) {
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i < n) v[i] = (int)i;
+}
+// off[b] = first position of the sorted labels that holds a label >= b (b = 0 .. nbins): the bins' offsets into the grouped order
+__global__ void k_label_offsets(const int* sorted, long n, int nbins, long* off) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b > nbins) return;
+  long lo = 0, hi = n;
+  while (lo < hi) {
+    const long mid = (lo + hi) >> 1;
+    if (sorted[mid] < b) lo = mid + 1; else hi = mid;
+  }
+  off[b] = lo;
+}
+// rank codes of the sorted keys: flag[i] = keys[i] != keys[i - 1] (IEEE comparison: -0.0 == +0.0, as numpy.unique compares)
+__global__ void k_new_value_flags(const double* keys, long n, long* flag) {
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i < n) flag[i] = (i > 0 && keys[i] != keys[i - 1]) ? 1 : 0;
+}
+__global__ void k_scatter_codes(const long* code, const int* idx, long n, long* inv) {
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i < n) inv[idx[i]] = code[i];
+}
+}  // namespace
+
+// The same statistics from the per-row bin labels (0 .. nbins - 1; host): the grouping - numpy's argsort(labels, kind="stable") and the
+// bincount / cumsum offsets, 60-80 ms of host time at n = 1e6 - runs on the device (one stable radix sort of (label, row) pairs + nbins + 1
+// binary searches): the same permutation, hence bit-identical statistics.
+extern "C" int nls_bin_stats_labels(nls_ctx* ctx, const double* X, const double* s, int64_t n, int d, const int32_t* labels, int nbins,
+                                    double* centers, double* spreads) {
+  if (!ctx) return NLS_ERR_ARG;
+  if (!X || !s || !labels || !centers || !spreads || n < 1 || d < 1 || nbins < 1)
+    return fail(ctx, NLS_ERR_ARG, "nls_bin_stats_labels: NULL argument or empty problem");
+  if ((int64_t)n > ((int64_t)1 << 30)) return fail(ctx, NLS_ERR_ARG, "nls_bin_stats_labels: n too large");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int *lab_in = nullptr, *lab_out = nullptr, *idx_in = nullptr, *dperm = nullptr;
+  long* doff = nullptr;
+  NLSCHK(ws_get_t(ctx, "pre.lab_in", (size_t)n, &lab_in));
+  NLSCHK(ws_get_t(ctx, "pre.lab_out", (size_t)n, &lab_out));
+  NLSCHK(ws_get_t(ctx, "pre.idx_in", (size_t)n, &idx_in));
+  NLSCHK(ws_get_t(ctx, "pre.perm", (size_t)n, &dperm));
+  NLSCHK(ws_get_t(ctx, "pre.off", (size_t)nbins + 1, &doff));
+  HIPCHK(ctx, hipMemcpyAsync(lab_in, labels, sizeof(int) * n, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_iota, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, idx_in, (long)n);
+  HIPCHK(ctx, hipGetLastError());
+  int bits = 1;
+  while (bits < 31 && (1L << bits) < (long)nbins) ++bits;
+  size_t temp_bytes = 0;
+  HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, lab_in, lab_out, idx_in, dperm, (int)n, 0, bits, ctx->stream));
+  void* temp = nullptr;
+  NLSCHK(ws_get(ctx, "pre.sort_tmp", std::max<size_t>(temp_bytes, 8), &temp));
+  HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, lab_in, lab_out, idx_in, dperm, (int)n, 0, bits, ctx->stream));
+  hipLaunchKernelGGL(k_label_offsets, dim3((unsigned)((nbins + 1 + 255) / 256)), dim3(256), 0, ctx->stream, lab_out, (long)n, nbins, doff);
+  HIPCHK(ctx, hipGetLastError());
+  return bin_stats_core(ctx, X, s, n, d, dperm, doff, nbins, centers, spreads);
+}
+
+// inverse[i] = rank of y[i] among the distinct values of y, *nunique = their number: numpy.unique(y, return_inverse=True)[1] and len(...[0]) -
+// the first step of the target quantiser (sample_bins_quantized_ecdf, _quantizer.py:246-253; 48 ms of host time at n = 1e6) - by one radix
+// sort of (value, row) pairs, a flag / inclusive-scan pass and a scatter.  y: finite doubles, host | device; inverse: n int64, host.
+extern "C" int nls_rank_codes(nls_ctx* ctx, const double* y, int64_t n, int64_t* inverse, int64_t* nunique) {
+  if (!ctx) return NLS_ERR_ARG;
+  if (!y || !inverse || !nunique || n < 1) return fail(ctx, NLS_ERR_ARG, "nls_rank_codes: NULL argument or n < 1");
+  if ((int64_t)n > ((int64_t)1 << 30)) return fail(ctx, NLS_ERR_ARG, "nls_rank_codes: n too large");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const double* dy = nullptr;
+  NLSCHK(resident(ctx, "rank.y", y, (size_t)n, &dy));
+  double* keys = nullptr;
+  int *idx_in = nullptr, *idx_out = nullptr;
+  long *flag = nullptr, *code = nullptr, *dinv = nullptr;
+  NLSCHK(ws_get_t(ctx, "rank.keys", (size_t)n, &keys));
+  NLSCHK(ws_get_t(ctx, "pre.idx_in", (size_t)n, &idx_in));
+  NLSCHK(ws_get_t(ctx, "rank.idx_out", (size_t)n, &idx_out));
+  NLSCHK(ws_get_t(ctx, "rank.flag", (size_t)n, &flag));
+  NLSCHK(ws_get_t(ctx, "rank.code", (size_t)n, &code));
+  NLSCHK(ws_get_t(ctx, "rank.inv", (size_t)n, &dinv));
+  hipLaunchKernelGGL(k_iota, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, idx_in, (long)n);
+  HIPCHK(ctx, hipGetLastError());
+  size_t tb1 = 0, tb2 = 0;
+  HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tb1, dy, keys, idx_in, idx_out, (int)n, 0, 64, ctx->stream));
+  HIPCHK(ctx, hipcub::DeviceScan::InclusiveSum(nullptr, tb2, flag, code, (int)n, ctx->stream));
+  void* temp = nullptr;
+  NLSCHK(ws_get(ctx, "pre.sort_tmp", std::max<size_t>(std::max(tb1, tb2), 8), &temp));
+  HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(temp, tb1, dy, keys, idx_in, idx_out, (int)n, 0, 64, ctx->stream));
+  hipLaunchKernelGGL(k_new_value_flags, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, keys, (long)n, flag);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipcub::DeviceScan::InclusiveSum(temp, tb2, flag, code, (int)n, ctx->stream));
+  hipLaunchKernelGGL(k_scatter_codes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, code, idx_out, (long)n, dinv);
+  HIPCHK(ctx, hipGetLastError());
+  static_assert(sizeof(long) == sizeof(int64_t), "codes are 64-bit");
+  long last = 0;
+  HIPCHK(ctx, hipMemcpyAsync(inverse, dinv, sizeof(long) * n, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(&last, code + (n - 1), sizeof(long), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  *nunique = last + 1;
   return NLS_OK;
 }

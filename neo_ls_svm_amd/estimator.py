@@ -96,7 +96,8 @@ class AffineNormalizer(AffineFeatureMap):
         X, y = check_X_y(X, y, dtype=np.float64)
         ctx = ctx or default_context(int(self.device))
         self.shift_, self.scale_ = _prestep.fit_affine_normalizer(
-            X, np.asarray(y, dtype=np.float64), sample_weight, stats=lambda A, lab, w: hotpath.bin_stats(A, lab, w, ctx=ctx)
+            X, np.asarray(y, dtype=np.float64), sample_weight, stats=lambda A, lab, w: hotpath.bin_stats(A, lab, w, ctx=ctx),
+            unique=lambda t: hotpath.rank_codes(t, ctx=ctx),
         )
         self.A_ = None
         self.n_features_in_ = X.shape[1]
@@ -121,14 +122,18 @@ class AffineSeparator(AffineFeatureMap):
             X, y = check_X_y(X, y, dtype=np.float64)
         ctx = ctx or default_context(int(self.device))
 
-        def normalizer(Xa, ya, swa):  # per-bin weighted medians / deviations on the GPU (nls_bin_stats)
-            return _prestep.fit_affine_normalizer(Xa, ya, swa, stats=lambda A, lab, w: hotpath.bin_stats(A, lab, w, ctx=ctx))
+        def unique(t):  # the quantiser's np.unique(y, return_inverse=True) as a radix sort on the GPU (nls_rank_codes)
+            return hotpath.rank_codes(t, ctx=ctx)
+
+        def normalizer(Xa, ya, swa):  # per-bin weighted medians / deviations on the GPU (nls_bin_stats_labels)
+            return _prestep.fit_affine_normalizer(Xa, ya, swa, stats=lambda A, lab, w: hotpath.bin_stats(A, lab, w, ctx=ctx), unique=unique)
 
         self.shift_, self.scale_, self.A_ = _prestep.fit_affine_separator(
             X,
             y,
             sample_weight,
             normalizer=normalizer,
+            unique=unique,
             rank_threshold=self.rank_threshold,
             edge_sample_size=self.edge_sample_size,
             edge_search_multiplier=self.edge_search_multiplier,

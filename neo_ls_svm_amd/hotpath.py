@@ -27,6 +27,7 @@ __all__ = [
     "gram",
     "rotate",
     "bin_stats",
+    "rank_codes",
     "tridiagonalize",
     "eigh",
     "stedc",
@@ -273,7 +274,9 @@ def twostage_stage(stage: int, A, bw: int, aux=None, ctx: Context | None = None)
 
 def bin_stats(X, labels, sample_weight=None, ctx: Context | None = None):
     """(centers, spreads), each nbins x d: per class bin the weighted median and weighted mean absolute deviation of
-    every input column (``_affine_normalizer.py:72-79``) on the GPU (segmented radix sort + one scan per segment)."""
+    every input column (``_affine_normalizer.py:72-79``) on the GPU (``nls_bin_stats_labels``: the rows are grouped by bin with a stable
+    radix sort of (label, row) pairs on the device - numpy's ``argsort(labels, kind="stable")`` order - then one segmented radix sort of all
+    d x nbins segments and one scan per segment)."""
     ctx = ctx or default_context()
     X = _f64(ctx.held(X), "X")
     n, d = X.shape
@@ -281,15 +284,23 @@ def bin_stats(X, labels, sample_weight=None, ctx: Context | None = None):
     lo, hi = int(labels.min()), int(labels.max())
     nbins = hi - lo + 1
     sw = np.ones(n) if sample_weight is None else np.ascontiguousarray(sample_weight, dtype=np.float64)
-    perm = np.argsort(labels, kind="stable").astype(np.int32)
-    off = np.zeros(nbins + 1, dtype=np.int64)
-    off[1:] = np.cumsum(np.bincount(labels - lo, minlength=nbins))
+    lab32 = np.ascontiguousarray(labels - lo, dtype=np.int32)
     centers, spreads = np.empty((nbins, d)), np.empty((nbins, d))
     ctx._check(
-        ctx.lib.nls_bin_stats(ctx.handle, _lib._ptr(X), sw.ctypes.data, n, d, perm.ctypes.data, off.ctypes.data, nbins,
-                              centers.ctypes.data, spreads.ctypes.data)
-    )  # fmt: skip
+        ctx.lib.nls_bin_stats_labels(ctx.handle, _lib._ptr(X), sw.ctypes.data, n, d, lab32.ctypes.data, nbins, centers.ctypes.data, spreads.ctypes.data)
+    )
     return centers, spreads
+
+
+def rank_codes(y, ctx: Context | None = None):
+    """(inverse, number of distinct values) of ``numpy.unique(y, return_inverse=True)`` on the GPU (``nls_rank_codes``): the first step of the
+    target quantiser (``_quantizer.py:246-253``) - a radix sort of n doubles instead of 48 ms of host sorting at n = 1e6."""
+    ctx = ctx or default_context()
+    y = np.ascontiguousarray(y, dtype=np.float64).ravel()
+    inv = np.empty(y.size, dtype=np.int64)
+    nu = C.c_int64()
+    ctx._check(ctx.lib.nls_rank_codes(ctx.handle, y.ctypes.data, y.size, inv.ctypes.data, C.byref(nu)))
+    return inv, int(nu.value)
 
 
 def _primal_args(X, y, s, shift, scale, B, is_classifier, gammas, gamma_index, ctx, want_L, want_rows, sweep_only, finish_below,

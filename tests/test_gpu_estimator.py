@@ -96,6 +96,44 @@ def test_gpu_bin_stats_match_numpy(name, golden_loader):
         assert relerr(spr[b], ((s[m] / s[m].sum())[None, :] @ np.abs(X[m] - mu))[0]) < 1e-12
 
 
+def test_gpu_grouping_and_rank_codes_equal_numpy():
+    """Round 5: the pre-step's two host sorts moved to the device.  ``nls_rank_codes`` == ``numpy.unique(y, return_inverse=True)`` (inverse and
+    count: distinct values, heavy ties, +-0.0, two classes); ``nls_bin_stats_labels`` (rows grouped by a stable radix sort of (label, row) on
+    the device) == ``nls_bin_stats`` fed numpy's ``argsort(labels, kind="stable")`` - the same permutation, bit-identical statistics."""
+    import ctypes as C
+
+    import neo_ls_svm_amd as hp
+    from neo_ls_svm_amd import _prestep, hotpath
+
+    ctx = hp.default_context()
+    rng = np.random.default_rng(3)
+    cases = [rng.standard_normal(100_003), np.round(rng.standard_normal(50_000), 2), np.where(rng.random(20_000) > 0.3, 1.0, -1.0),
+             np.concatenate([np.zeros(3000), -np.zeros(3000), rng.standard_normal(4000)]), np.array([2.5]), np.arange(7.0)[::-1].copy()]  # fmt: skip
+    for y in cases:
+        uniq, inv = np.unique(y, return_inverse=True)
+        got_inv, got_n = hotpath.rank_codes(y, ctx=ctx)
+        assert got_n == len(uniq) and got_inv.dtype == np.int64 and np.array_equal(got_inv, inv)
+    # the quantiser's labels are the same whichever unique it is given
+    y = np.sin(rng.standard_normal(60_000)) + 0.1 * rng.standard_normal(60_000)
+    _prestep._BINS_MEMO.clear()
+    lab_np = _prestep.target_bins(y).copy()
+    _prestep._BINS_MEMO.clear()
+    lab_gpu = _prestep.target_bins(y, unique=lambda t: hotpath.rank_codes(t, ctx=ctx))
+    assert np.array_equal(lab_np, lab_gpu) and lab_np.max() >= 2
+    # grouping on the device == grouping on the host
+    n, d = y.size, 9
+    X = rng.standard_normal((n, d))
+    s = rng.uniform(0.2, 2.0, n)
+    cen, spr = hotpath.bin_stats(X, lab_np, s, ctx=ctx)
+    nbins = int(lab_np.max()) + 1
+    perm = np.argsort(lab_np, kind="stable").astype(np.int32)
+    off = np.zeros(nbins + 1, dtype=np.int64)
+    off[1:] = np.cumsum(np.bincount(lab_np, minlength=nbins))
+    cen0, spr0 = np.empty((nbins, d)), np.empty((nbins, d))
+    ctx._check(ctx.lib.nls_bin_stats(ctx.handle, X.ctypes.data, s.ctypes.data, n, d, perm.ctypes.data, off.ctypes.data, nbins, cen0.ctypes.data, spr0.ctypes.data))
+    assert np.array_equal(cen, cen0) and np.array_equal(spr, spr0)
+
+
 def test_auto_switch_pandas_and_score():
     import pandas as pd
     from sklearn.datasets import load_breast_cancer, load_diabetes

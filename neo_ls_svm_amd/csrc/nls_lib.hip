@@ -779,6 +779,14 @@ static int zpotrf_lower(nls_ctx* ctx, hipStream_t stream, rocblas_handle blas, d
       hipFuncSetAttribute(reinterpret_cast<const void*>(k_zpotrf_herk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_REAL) != hipSuccess)
     return fail(ctx, NLS_ERR_HIP, "complex Cholesky kernels: %zu / %zu bytes of LDS refused", ZP_LDS, SMEM_REAL);
   if (event_cols > 0 && event_cols % NBO != 0) return fail(ctx, NLS_ERR_ARG, "zpotrf_lower: block-column events come in multiples of %d columns", NBO);
+  // NLS_ZPOTRF_STAMP=1 (diagnostic): the in-kernel time line of the panel that starts at column 1024 (workgroup 0), printed by the caller's next sync
+  static const bool want_stamps = [] { const char* m = std::getenv("NLS_ZPOTRF_STAMP"); return m && m[0] == '1'; }();
+  const int stamp_k0 = std::min(1024, ((n - 1) / NBZ / 2) * NBZ);
+  long long* dstamps = nullptr;
+  if (want_stamps) {
+    NLSCHK(ws_get_t(ctx, "zpotrf.stamps", (size_t)8, &dstamps));
+    HIPCHK(ctx, hipMemsetAsync(dstamps, 0, 8 * sizeof(long long), stream));
+  }
   const bool carry = rhs != nullptr && ysol != nullptr;
   double2* rhs_run = nullptr;  // the running right-hand side of the carried forward substitution
   if (carry) {
@@ -794,8 +802,9 @@ static int zpotrf_lower(nls_ctx* ctx, hipStream_t stream, rocblas_handle blas, d
       const int m_pad = (int)round_up(mrows, BM);
       const int pgrid = std::max(1, (m_pad + ZP_ROWS - 1) / ZP_ROWS);
       const long ko = (long)(k0 - K0) * ldp;  // this panel's 32 k-rows inside the halves of the outer stacks
+      long long* stamps = (want_stamps && k0 == stamp_k0) ? dstamps : nullptr;
       hipLaunchKernelGGL(k_zpotrf_panel, dim3((unsigned)pgrid), dim3(ZP_THREADS), ZP_LDS, stream, D, lda, w, k0, mrows, m_pad, S1, S2, S3, ldp, O1 + ko, O2 + ko,
-                         O3 + ko, (long)NBO, K0 + W - (k0 + w), L11w, rhs_run, ysol, dinfo);
+                         O3 + ko, (long)NBO, K0 + W - (k0 + w), L11w, rhs_run, ysol, dinfo, stamps);
       const int icols = K0 + W - (k0 + w);  // columns of the outer block right of the panel: the panel's own (tall) update
       if (icols > 0) {
         const int nt = m_pad / BM, nct = std::min(nt, (icols + BM - 1) / BM);
@@ -814,6 +823,14 @@ static int zpotrf_lower(nls_ctx* ctx, hipStream_t stream, rocblas_handle blas, d
       HIPCHK(ctx, hipGetLastError());
     }
     if (event_cols > 0 && ((K0 + NBO) % event_cols == 0 || K0 + NBO >= n)) HIPCHK(ctx, hipEventRecord(ctx->blk_ev[K0 / event_cols], stream));
+  }
+  if (want_stamps) {  // diagnostic: synchronises
+    long long h[8];
+    HIPCHK(ctx, hipMemcpyAsync(h, dstamps, sizeof(h), hipMemcpyDeviceToHost, stream));
+    HIPCHK(ctx, hipStreamSynchronize(stream));
+    std::fprintf(stderr, "[zpotrf stamps] n %d panel at column %d, workgroup 0 (us): block in LDS %.2f | factored +%.2f | rhs solved +%.2f | rows solved at %.2f | "
+                         "barrier at %.2f | stores drained at %.2f\n", n, stamp_k0, (h[1] - h[0]) * 0.01, (h[2] - h[1]) * 0.01, (h[3] - h[2]) * 0.01,
+                 (h[4] - h[0]) * 0.01, (h[5] - h[0]) * 0.01, (h[6] - h[0]) * 0.01);
   }
   if (ysol_valid) *ysol_valid = carry;
   return NLS_OK;

@@ -44,7 +44,8 @@ constexpr size_t ZP_LDS = (size_t)2 * NBZ * (NBZ + 1) * sizeof(double) + (size_t
 __global__ void __launch_bounds__(ZP_THREADS) k_zpotrf_panel(double2* __restrict__ A, long lda, int w, int k0, int m, int m_pad, double* __restrict__ S1,
                                                           double* __restrict__ S2, double* __restrict__ S3, long ldp, double* __restrict__ O1,
                                                           double* __restrict__ O2, double* __restrict__ O3, long ohalf, int orow0,
-                                                          double2* __restrict__ L11out, double2* __restrict__ rhs_run, double2* __restrict__ ysol, int* info) {
+                                                          double2* __restrict__ L11out, double2* __restrict__ rhs_run, double2* __restrict__ ysol, int* info,
+                                                          long long* stamps /* diagnostic (NLS_ZPOTRF_STAMP=1; nullptr: none): workgroup 0's time line, 100 MHz ticks */) {
   extern __shared__ __attribute__((aligned(16))) unsigned char zp_smem[];
   double(*Lr)[NBZ + 1] = reinterpret_cast<double(*)[NBZ + 1]>(zp_smem);
   double(*Li)[NBZ + 1] = reinterpret_cast<double(*)[NBZ + 1]>(zp_smem + (size_t)NBZ * (NBZ + 1) * sizeof(double));
@@ -62,6 +63,8 @@ __global__ void __launch_bounds__(ZP_THREADS) k_zpotrf_panel(double2* __restrict
   const bool live = rowthr && r < m;
   double2* A21 = A + w;
   if (ftid == 0) cols_done = 0;
+  const bool st = stamps != nullptr && blockIdx.x == 0;
+  if (st && ftid == 0) stamps[0] = wall_clock64();
   // ---- this thread's row of the panel: loads in flight while the block is factored ----
   if (rowthr)
     for (int c = 0; c < NBZ; ++c) xs[c][tid] = (live && c < w) ? A21[r + (long)c * lda] : make_double2(0.0, 0.0);
@@ -74,6 +77,7 @@ __global__ void __launch_bounds__(ZP_THREADS) k_zpotrf_panel(double2* __restrict
     Li[rr][c] = rr == c ? 0.0 : v.y;  // the diagonal of a Hermitian matrix is real (LAPACK ignores its imaginary part too)
   }
   __syncthreads();
+  if (st && ftid == 0) stamps[1] = wall_clock64();  // diagonal block in LDS
   int bad = 0;
   if (!rowthr) {
     // Wave 0: lane = (row rr, half h).  Round 5: the two halves SHARE the row's columns - half h keeps and updates the columns of parity h
@@ -130,6 +134,7 @@ __global__ void __launch_bounds__(ZP_THREADS) k_zpotrf_panel(double2* __restrict
       __builtin_amdgcn_sched_barrier(0);
     }
     // (every column went to Lr / Li as it was finished; the diagonal's imaginary part stays exactly zero: see above)
+    if (st && ftid == 0) stamps[2] = wall_clock64();  // block factored
     if (rhs_run) {  // y[k0 .. k0 + w): L11 y = (running right-hand side), forward substitution across the lanes
       double2 acc = (h == 0 && rr < w) ? rhs_run[k0 + rr] : make_double2(0.0, 0.0);
       for (int t = 0; t < NBZ; ++t) {
@@ -145,6 +150,7 @@ __global__ void __launch_bounds__(ZP_THREADS) k_zpotrf_panel(double2* __restrict
       }
       if (blockIdx.x == 0 && h == 0 && rr < w) ysol[k0 + rr] = ysh[rr];
     }
+    if (st && ftid == 0) stamps[3] = wall_clock64();  // the panel's unknowns of the carried substitution solved
   }
   if (rowthr) {
     // ---- this workgroup's rows of the panel below the block: column c as soon as the block's column c is final ----
@@ -164,8 +170,10 @@ __global__ void __launch_bounds__(ZP_THREADS) k_zpotrf_panel(double2* __restrict
       }
       xs[c][tid] = make_double2(sr * dv[c], si * dv[c]);  // (read back by this thread only: no barrier)
     }
+    if (st && tid == 0) stamps[4] = wall_clock64();  // this workgroup's rows solved
   }
   __syncthreads();  // the factor, ysh and every row are complete
+  if (st && ftid == 0) stamps[5] = wall_clock64();
   if (blockIdx.x == 0) {
     // L11 goes back into A directly only when no other workgroup exists that may still be reading the un-factored block; otherwise into
     // L11out, from where the update kernel (the next launch) puts it in place.
@@ -208,6 +216,10 @@ __global__ void __launch_bounds__(ZP_THREADS) k_zpotrf_panel(double2* __restrict
       O3[oo] = x.y;
       O3[oh + oo] = x.x;
     }
+  }
+  if (st && tid == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamps[6] = wall_clock64();  // stores of the panel and its planes drained
   }
 }
 

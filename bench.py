@@ -207,6 +207,18 @@ def cpu_baseline(cfg, shift, scale, B, gammas, gpu_fit, gpu_full=None):
             "(c2) is in profiles/ (bench.py --config c2); the x n / n_s extrapolation of the row stages is checked once against a FULL-size "
             "Mode-S run of c3 on the same kind of host: profiles/r05_cpu_modeS_c3_full.json (tools/cpu_modeS_full.py)",
         )
+    try:  # the one full-size run of this schedule on the same kind of host (tools/cpu_modeS_full.py): how far off the extrapolation is
+        full = json.loads((ROOT / "profiles" / "r05_cpu_modeS_c3_full.json").read_text())
+        if full.get("workload") == cfg["name"]:
+            out["full_size_check"] = {
+                "source": "profiles/r05_cpu_modeS_c3_full.json",
+                "seconds_measured_full_size": full["seconds_full_size"],
+                "seconds_extrapolated_in_that_run": full["seconds_extrapolated_from_sample"],
+                "extrapolation_over_measured": full["extrapolation_over_measured"],
+                "reading": "the extrapolated figure UNDER-states the CPU time (feature-map and rotation stages fall out of the host's caches at full size): value is conservative",
+            }
+    except Exception:
+        pass
     g = gpu_fit(X, y, s, None)
     argmin_equal = g["opt"] == o["opt"]
     if not argmin_equal:

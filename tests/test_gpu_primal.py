@@ -239,6 +239,46 @@ def test_sigma_grid_driver(golden_loader, hp):
     assert relerr(merged, sg["loo_errors"]) < TOL
 
 
+def test_sigma_grid_edge_cases(golden_loader, hp):
+    """``nls_primal_fit_grid`` on the edges: one sigma; one gamma; a classifier with zero-weight rows; unsorted sigmas (visiting order is by
+    |ln sigma|, the table is indexed as given); argument errors come back as ValueError before any GPU work."""
+    sys_path_tests = str(__import__("pathlib").Path(__file__).resolve().parent)
+    import sys
+
+    if sys_path_tests not in sys.path:
+        sys.path.insert(0, sys_path_tests)
+    import _grid_reference_driver as ref
+
+    ctx = hp.default_context()
+    for name in ("primal_reg_n3000_d20_D256", "primal_clf_n3000_d16_D256_wz"):
+        g = golden_loader(name)
+        y, clf = signed_targets(g), g["task"] == "clf"
+        args = (g["X"], y, g["s"], g["shift"], g["scale"])
+        for sig, gam in (([1.3], hp.gamma_grid(1024)[::33]), ([2.0, 0.5, 1.0, 0.8], hp.gamma_grid(64)), ([0.9, 1.1], np.array([1e-3]))):
+            sig = np.asarray(sig)
+
+            def fit(Bs, finish_below, gam=gam):
+                return hp.primal_fit(*args, Bs, clf, gammas=gam, ctx=ctx, finish_below=finish_below)
+
+            want = ref.grid(fit, g["B"], sig, gam)
+            got = hp.primal_fit_sigma_grid(*args, g["B"], clf, sig, gammas=gam, ctx=ctx)
+            assert got["loo_errors"].shape == (len(sig), len(gam))
+            assert np.array_equal(got["loo_errors"], want["loo_errors"]) and np.array_equal(got["objective"], want["objective"])
+            assert (got["sigma_index"], got["gamma_index"], got["finished_count"]) == (want["sigma_index"], want["gamma_index"], want["finished_count"])
+            for k in ("beta", "loo_residuals", "loo_std", "residuals"):
+                assert np.array_equal(got["best"][k], want["best"][k]), (name, k)
+            assert got["best"]["loo_score"] == want["best"]["loo_score"]
+    g = golden_loader("primal_reg_n3000_d20_D256")
+    args = (g["X"], g["y"], g["s"], g["shift"], g["scale"], g["B"], False)
+    for bad in ([], [1.0, -2.0], [0.0], [np.inf]):
+        with pytest.raises(ValueError):
+            hp.primal_fit_sigma_grid(*args, bad, ctx=ctx)
+    with pytest.raises(ValueError):  # rank outside the world
+        hp.primal_fit_sigma_grid(*args, [1.0, 2.0], ctx=ctx, rank=2, world=2)
+    with pytest.raises(ValueError):  # the merge context must not be the fitting context
+        hp.primal_fit_sigma_grid(*args, [1.0, 2.0], ctx=ctx, rank=0, world=2, merge_ctx=ctx)
+
+
 @pytest.mark.parametrize("task", ["reg", "clf"])
 def test_primal_fit_vs_oracle_seeded(task, hp):
     """Seeded synthetic problem of the BASELINE generator at a size the oracle finishes in seconds."""

@@ -52,13 +52,16 @@ def _affine_params(fm):
 
 
 class AffineFeatureMap(BaseEstimator):
-    """(x - shift) diag(1/scale) A with GIVEN parameters: reference ``_affine_feature_map.py:17-92`` (``append_features`` is
-    not part of the hot path and not mirrored).  ``fit`` validates as the reference does (``:52-69``); subclasses learn them."""
+    """(x - shift) diag(1 / scale) A with GIVEN parameters: reference ``_affine_feature_map.py:17-136``.  ``fit`` validates as the reference
+    does (``:52-69``); subclasses learn the parameters.  ``append_features=True`` (``:26-38,90-91``) appends the mapped columns to the given
+    ones - honoured by ``transform`` / ``inverse_transform`` / ``get_feature_names_out`` and hence by the dual path (which consumes
+    ``transform``'s output); a random-feature map folds (shift, scale, A) into its projection and refuses an appending map."""
 
-    def __init__(self, *, scale, shift, A=None):
+    def __init__(self, *, scale, shift, A=None, append_features=False):
         self.scale = scale
         self.shift = shift
         self.A = A
+        self.append_features = append_features
 
     def fit(self, X, y=None, sample_weight=None, ctx=None):
         X = check_array(X, dtype=np.float64)
@@ -73,23 +76,51 @@ class AffineFeatureMap(BaseEstimator):
             raise ValueError("The matrix A must be finite with rows equal to the number of features in X")
         return self
 
+    def _appends(self, A):
+        return bool(getattr(self, "append_features", False)) and A is not None
+
     def transform(self, X):
         """Affine map only (used by the dual path: ``_neo_ls_svm.py:394,668``); n x r output, host GEMM, with the
-        reference's memory-order switch (``_affine_feature_map.py:81-89``)."""
+        reference's memory-order switch (``_affine_feature_map.py:81-89``); ``append_features``: [X, mapped X] (``:90-91``)."""
         X = check_array(X, dtype=np.float64)
         shift, scale, A = _affine_params(self)
         shift, scale = np.reshape(shift, (1, -1)), np.reshape(scale, (1, -1))
         if A is None:
             return (X - shift) / scale
         As = A / scale.T
-        return X @ As - shift @ As if A.shape[1] < A.shape[0] else (X - shift) @ As
+        out = X @ As - shift @ As if A.shape[1] < A.shape[0] else (X - shift) @ As
+        return np.hstack((X, out)) if self._appends(A) else out
+
+    def inverse_transform(self, X_transformed):
+        """Approximate inverse (``_affine_feature_map.py:101-114``): the given columns themselves when they were appended, else the
+        pseudo-inverse of A undone, then scale and shift."""
+        Xt = check_array(X_transformed, dtype=np.float64)
+        shift, scale, A = _affine_params(self)
+        if self._appends(A):
+            return Xt[:, : np.shape(A)[0]].copy()
+        if A is not None:
+            Xt = Xt @ np.linalg.pinv(np.asarray(A, dtype=np.float64))
+        return Xt * np.reshape(scale, (1, -1)) + np.reshape(shift, (1, -1))
+
+    def get_feature_names_out(self, input_features=None):
+        """Output column names (``_affine_feature_map.py:116-133``): ``<name>_shifted_scaled`` without a matrix, else one shared
+        ``<all names>_affine_map`` label per mapped column; the input names first when they are appended."""
+        from sklearn.utils.validation import _check_feature_names_in
+
+        _, _, A = _affine_params(self)
+        names = np.asarray(_check_feature_names_in(self, input_features), dtype=object)
+        if A is None:
+            return np.asarray([f"{n}_shifted_scaled" for n in names], dtype=object)
+        mapped = np.asarray([f"{','.join(names)}_affine_map"] * np.shape(A)[1], dtype=object)
+        return np.hstack((names, mapped)) if self._appends(A) else mapped
 
 
 class AffineNormalizer(AffineFeatureMap):
     """Supervised shift / scale from per-bin weighted medians and deviations, A = None: reference ``_affine_normalizer.py:25-117``
     (the n-proportional bin statistics run on the GPU, ``nls_bin_stats``)."""
 
-    def __init__(self, *, device=0):
+    def __init__(self, *, append_features=False, device=0):
+        self.append_features = append_features  # (A is None for a normaliser: nothing is ever appended, as upstream)
         self.device = device
 
     def fit(self, X, y, sample_weight=None, ctx=None):
@@ -107,7 +138,8 @@ class AffineNormalizer(AffineFeatureMap):
 class AffineSeparator(AffineFeatureMap):
     """(x - shift) diag(1/scale) A with supervised shift/scale/A: reference ``_affine_separator.py:54-210``."""
 
-    def __init__(self, *, rank_threshold=2e-2, edge_sample_size=384, edge_search_multiplier=4, random_state=42, device=0):
+    def __init__(self, *, append_features=False, rank_threshold=2e-2, edge_sample_size=384, edge_search_multiplier=4, random_state=42, device=0):
+        self.append_features = append_features
         self.rank_threshold = rank_threshold
         self.edge_sample_size = edge_sample_size
         self.edge_search_multiplier = edge_search_multiplier
@@ -180,6 +212,9 @@ class RandomFourierFeatures(BaseEstimator):
         afm = _as_own_affine_map(self.affine_feature_map)
         self.affine_feature_map_ = _fit_affine(AffineSeparator() if afm is None else clone(afm), X, y, sample_weight, ctx, _validated)
         shift, scale, A = _affine_params(self.affine_feature_map_)
+        if A is not None and getattr(self.affine_feature_map_, "append_features", False):
+            raise TypeError("an affine map with append_features=True cannot sit inside a random-feature map: the map folds (shift, scale, A) into its "
+                            "projection B = A Z (`_feature_maps.py:147-150`) and has no place for the appended columns")
         A = None if A is None else np.asarray(A, dtype=np.float64)
         d_in = A.shape[1] if A is not None else np.asarray(X).shape[1]
         orthogonal = self.orthogonal_default if self.orthogonal is None else bool(self.orthogonal)
@@ -247,10 +282,10 @@ def _as_own_affine_map(afm):
         return afm
     name, module = type(afm).__name__, type(afm).__module__
     if module.startswith("neo_ls_svm.") and name == "AffineSeparator":
-        keys = ("rank_threshold", "edge_sample_size", "edge_search_multiplier", "random_state")
+        keys = ("append_features", "rank_threshold", "edge_sample_size", "edge_search_multiplier", "random_state")
         return AffineSeparator(**{k: getattr(afm, k) for k in keys if hasattr(afm, k)})
     if module.startswith("neo_ls_svm.") and name == "AffineNormalizer":
-        return AffineNormalizer()
+        return AffineNormalizer(append_features=bool(getattr(afm, "append_features", False)))
     if callable(getattr(afm, "fit", None)):
         return afm  # checked for shift / scale / A once fitted (_fit_affine)
     raise TypeError(f"{name} is not an affine map: it has no fit(X, y, sample_weight)")

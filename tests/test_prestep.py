@@ -103,3 +103,37 @@ def test_weighted_median_toy():
     # a = (0, 1, 1), w = (2, 1, 1): the reference's definition gives 0.5 (_weighted_quantile.py:66-68)
     med = _prestep.weighted_median_columns(np.array([[0.0], [1.0], [1.0]]), np.array([2.0, 1.0, 1.0]))
     assert med.shape == (1, 1) and abs(med[0, 0] - 0.5) < 1e-15
+
+
+def test_affine_feature_map_surface_outside_the_hot_path():
+    """``append_features`` / ``inverse_transform`` / ``get_feature_names_out`` of the reference's ``AffineFeatureMap``
+    (``_affine_feature_map.py:26-38,90-136``), mirrored on the host: appended columns come first and invert exactly; without a matrix the map
+    inverts exactly; with one, through its pseudo-inverse; names as upstream spells them.  A random-feature map refuses an appending map."""
+    from neo_ls_svm_amd import AffineFeatureMap, AffineSeparator, RandomFourierFeatures
+
+    rng = np.random.default_rng(2)
+    X = rng.standard_normal((40, 5))
+    shift, scale = rng.standard_normal(5), rng.uniform(0.5, 2.0, 5)
+    plain = AffineFeatureMap(scale=scale, shift=shift).fit(X)
+    T = plain.transform(X)
+    assert np.allclose(T, (X - shift) / scale) and np.allclose(plain.inverse_transform(T), X, atol=1e-13)
+    assert list(plain.get_feature_names_out(list("abcde"))) == [f"{c}_shifted_scaled" for c in "abcde"]
+    A = rng.standard_normal((5, 7))  # wider than tall: full row rank, the pseudo-inverse undoes it
+    wide = AffineFeatureMap(scale=scale, shift=shift, A=A).fit(X)
+    Tw = wide.transform(X)
+    assert Tw.shape == (40, 7) and np.allclose(Tw, ((X - shift) / scale) @ A)
+    assert np.allclose(wide.inverse_transform(Tw), X, atol=1e-10)
+    assert list(wide.get_feature_names_out(list("abcde"))) == ["a,b,c,d,e_affine_map"] * 7
+    app = AffineFeatureMap(scale=scale, shift=shift, A=A, append_features=True).fit(X)
+    Ta = app.transform(X)
+    assert Ta.shape == (40, 12) and np.array_equal(Ta[:, :5], X) and np.allclose(Ta[:, 5:], Tw)
+    assert np.array_equal(app.inverse_transform(Ta), X)
+    assert list(app.get_feature_names_out(list("abcde"))) == list("abcde") + ["a,b,c,d,e_affine_map"] * 7
+    tall = AffineFeatureMap(scale=scale, shift=shift, A=A[:, :3]).fit(X)  # the memory-order switch of the reference (A.shape[1] < A.shape[0])
+    assert np.allclose(tall.transform(X), ((X - shift) / scale) @ A[:, :3])
+    # sklearn plumbing: the parameter round-trips through get_params / clone
+    from sklearn.base import clone
+
+    assert clone(AffineSeparator(append_features=True)).append_features is True
+    with pytest.raises(TypeError, match="append_features"):
+        RandomFourierFeatures(affine_feature_map=app, num_features=8).fit(X, rng.standard_normal(40))

@@ -76,6 +76,21 @@ def mode_fit(world):
             yo, _ = hp.primal_predict(Xq, shift, scale, B, beta=r1["beta"], ctx=grp)
             fac.close()
             assert rel(yf, y1) < 1e-11 and rel(sf, s1) < 1e-9 and rel(yo, y1) < 1e-11
+    # a rank whose whole row block has zero weight; a forced gamma index; the curve only (no re-solve); the generalised-EVD branch
+    # (a full complexity matrix: its Cholesky factor and the triangular solves are replicated on every rank)
+    X, y, s, shift, scale, B = problem(n=4000, d=10, D=96)
+    s0 = s.copy()
+    s0[: 4000 // max(world, 2)] = 0.0
+    for kw in ({"gamma_index": 300}, {"sweep_only": True}, {"complexity_matrix": hp.exact_complexity_matrix(hp.orf_frequencies(10, 96) * 0.4)}):
+        for sw in (s, s0):
+            a = hp.primal_fit(X, y, sw, shift, scale, B, False, ctx=solo, **kw)
+            b = hp.primal_fit(X, y, sw, shift, scale, B, False, ctx=grp, **kw)
+            assert a["opt"] == b["opt"] and rel(b["loo_errors_gammas"], a["loo_errors_gammas"]) < 1e-9, kw
+            if not kw.get("sweep_only"):
+                assert rel(b["beta"], a["beta"]) < 1e-7 and rel(b["loo_residuals"], a["loo_residuals"]) < 1e-7, kw
+                assert rel(b["loo_std"], a["loo_std"]) < 1e-7 and abs(b["loo_score"] - a["loo_score"]) < 1e-9, kw
+            else:
+                assert "beta" not in b and not b["finished"]
     # argument errors come back as ValueError, before any collective
     X, y, s, shift, scale, B = problem(n=world - 1) if world > 1 else problem(n=1)
     if world > 1:

@@ -12,7 +12,7 @@ for d in sorted(glob.glob(os.path.join(root, "pmcR2_*_[0-9]"))):
         for row in csv.DictReader(open(f)):
             k = row["Kernel_Name"].split("(")[0].replace("nls::", "").replace("void ", "")
             k = "k_featuremap" if k.startswith("k_featuremap") else k
-            if not any(k.startswith(p) for p in ("k_rotate3", "k_featuremap", "k_shift_pad", "k_gram3")):
+            if not any(k.startswith(p) for p in ("k_rotate3", "k_featuremap", "k_shift_pad", "k_gram3", "k_sweep")):
                 continue
             out[tag][k].setdefault(row["Counter_Name"], 0.0)
             out[tag][k][row["Counter_Name"]] += float(row["Counter_Value"])

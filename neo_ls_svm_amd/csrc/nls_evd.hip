@@ -179,13 +179,17 @@ static int apply_q_blocked(nls_ctx* ctx, const T* A, long lda, int n, const T* t
   using namespace trd;
   if (nrefl < 0) nrefl = n - off;
   if (nrefl <= 0 || ncols <= 0) return NLS_OK;
+  // reflectors per block: 512; 1024 from n = 6000 (round 5, real n = 10^4: 256: 57.9, 512: 45.9, 1024: 42.8, 2048: 48.6 ms; complex n = 4097: 18.2 / 15.2 / 14.9).
+  // NLS_BT_KB = 128 .. 2048 overrides (diagnostic).
+  int kbq = n >= 6000 ? 2 * KBQ : KBQ;
+  if (const char* e = std::getenv("NLS_BT_KB")) kbq = std::max(128, std::min(2048, std::atoi(e) / 32 * 32));
   T *Vw = nullptr, *S = nullptr, *W = nullptr;
-  NLSCHK(ws_get_t(ctx, "bt.V", (size_t)n * KBQ, &Vw));
-  NLSCHK(ws_get_t(ctx, "bt.S", (size_t)KBQ * KBQ, &S));
-  NLSCHK(ws_get_t(ctx, "bt.W", (size_t)KBQ * ncols, &W));
+  NLSCHK(ws_get_t(ctx, "bt.V", (size_t)n * kbq, &Vw));
+  NLSCHK(ws_get_t(ctx, "bt.S", (size_t)kbq * kbq, &S));
+  NLSCHK(ws_get_t(ctx, "bt.W", (size_t)kbq * ncols, &W));
   BLASCHK(ctx, rocblas_set_stream(ctx->blas, ctx->stream));
-  for (int j0 = ((nrefl - 1) / KBQ) * KBQ; j0 >= 0; j0 -= KBQ) {
-    const int kb = std::min(KBQ, nrefl - j0), r0 = j0 + off, m = n - r0;
+  for (int j0 = ((nrefl - 1) / kbq) * kbq; j0 >= 0; j0 -= kbq) {
+    const int kb = std::min(kbq, nrefl - j0), r0 = j0 + off, m = n - r0;
     hipLaunchKernelGGL(k_trd_copy_v<T>, dim3((unsigned)(((long)m * kb + 255) / 256)), dim3(256), 0, ctx->stream, A, lda, n, j0, kb, Vw, off);
     BLASCHK(ctx, bt_gemm(ctx->blas, bt_op_h(A), rocblas_operation_none, kb, kb, m, 1.0, Vw, m, Vw, m, 0.0, S, kb));
     hipLaunchKernelGGL(k_trd_tinv<T>, dim3((unsigned)((kb * kb + 255) / 256)), dim3(256), 0, ctx->stream, S, kb, tau, j0);

@@ -305,7 +305,9 @@ int nls_grid_select(const double* objective, const unsigned char* owned, int Sg,
  *                            before the eigendecomposition); row outputs land in the caller's n-vectors at the block's offset, the
  *                            replicated outputs (beta, L, lam, curves, score, timings) are rank 0's.  n >= ndev.
  *   nls_group_primal_fit_grid  the gamma x sigma grid with the SIGMAS dealt over the devices (every device holds all rows, no collective in
- *                            the data path; the tables are merged on the host); grid->rank / world / merge must be 0 / 1 / NULL.
+ *                            the data path; the tables are merged on the host); grid->rank / world / merge must be 0 / 1 / NULL.  Ranks > 0
+ *                            keep their incumbent's full result in host buffers of the group (4 n + 2 (D+1)^2 [+ 2 (D+1)] doubles each,
+ *                            allocated on first use and reused); the winner's is copied into the caller's buffers at the end.
  *   nls_group_primal_predict query rows sharded the same way; factor: a group factor (U^-1 resident on every member) or NULL with L.
  * The dual path does not shard (its n x n eigendecomposition): use nls_group_ctx(group, 0) with nls_dual_fit ("replicas only").
  * devices may name one device several times ONLY with a communication library that allows it (the test stand-in of tests/csrc/rccl_shim.cpp;

@@ -53,12 +53,35 @@ static int potrf_lower_real(nls_ctx* ctx, double* A, int n, long lda, rocblas_in
     return NLS_OK;
   };
   const int NBO = 2 * NB;
+  // Look-ahead (round 5): the update of the trailing matrix by an outer block is split - the next panel's 128 columns on the main stream, the rest
+  // on a side stream - so that the next diagonal block (ONE workgroup, 110 us) and its panel are factored beside the big update instead of after
+  // it.  The regions are disjoint (tile column 0 against tile columns >= 1 of the trailing matrix); the strip update of the panel after that
+  // waits for the side stream.  NLS_POTRF_LOOKAHEAD=0: everything on the main stream.
+  static const bool lookahead = [] { const char* e = std::getenv("NLS_POTRF_LOOKAHEAD"); return !(e && e[0] == '0'); }();
+  hipStream_t side = nullptr;
+  if (lookahead && n > 4 * NBO) {
+    if (!ctx->stream2) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+    side = ctx->stream2;
+    for (auto& e : ctx->la_ev)
+      if (!e) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  bool side_busy = false;  // the side stream holds an update the main stream has not waited for yet
+  auto join_side = [&]() -> int {
+    if (side_busy) {
+      HIPCHK(ctx, hipEventRecord(ctx->la_ev[1], side));
+      HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->la_ev[1], 0));
+      side_busy = false;
+    }
+    return NLS_OK;
+  };
   for (int K0 = 0; K0 < n; K0 += NBO) {
-    NLSCHK(panel(K0));
+    NLSCHK(panel(K0));  // (tile column 0 of the previous outer block's trailing update: main stream)
     const int ma = n - K0 - NB;  // rows (and columns) below panel a
+    bool block_event_on_side = false;
     if (ma > 0) {
       double* Pa = A + (long)(K0 + NB) + (long)K0 * lda;  // panel a's rows below its diagonal block
       const int nta = (ma + BM - 1) / BM;
+      NLSCHK(join_side());  // the strip below lies in the side stream's region of the previous outer block
       // the strip of the next 128 columns: tiles (R, 0)
       hipLaunchKernelGGL(k_potrf_syrk, dim3((unsigned)nta), dim3(Cfg4::NTHREADS), SMEM_REAL_D, ctx->stream, A + (long)(K0 + NB) + (long)(K0 + NB) * lda, lda, ma, Pa,
                          lda, NB / BK, 1);
@@ -66,14 +89,34 @@ static int potrf_lower_real(nls_ctx* ctx, double* A, int n, long lda, rocblas_in
       const int mb = n - K0 - NBO;  // rows below the outer block
       if (mb > 0) {
         const int ntb = (mb + BM - 1) / BM;
-        hipLaunchKernelGGL(k_potrf_syrk, dim3((unsigned)(ntb * (ntb + 1) / 2)), dim3(Cfg4::NTHREADS), SMEM_REAL_D, ctx->stream,
-                           A + (long)(K0 + NBO) + (long)(K0 + NBO) * lda, lda, mb, A + (long)(K0 + NBO) + (long)K0 * lda, lda, NBO / BK, ntb);
+        double* A22 = A + (long)(K0 + NBO) + (long)(K0 + NBO) * lda;
+        const double* Lp = A + (long)(K0 + NBO) + (long)K0 * lda;
+        if (side && ntb > 2) {
+          // tile column 0 (what the next diagonal block and panel need) here, tile columns >= 1 - the lower triangle of the sub-matrix one tile down
+          // and right, with the panel rows one tile down - on the side stream
+          hipLaunchKernelGGL(k_potrf_syrk, dim3((unsigned)ntb), dim3(Cfg4::NTHREADS), SMEM_REAL_D, ctx->stream, A22, lda, mb, Lp, lda, NBO / BK, 1);
+          HIPCHK(ctx, hipEventRecord(ctx->la_ev[0], ctx->stream));  // both panels of this outer block are final
+          HIPCHK(ctx, hipStreamWaitEvent(side, ctx->la_ev[0], 0));
+          const int nr = ntb - 1;
+          hipLaunchKernelGGL(k_potrf_syrk, dim3((unsigned)(nr * (nr + 1) / 2)), dim3(Cfg4::NTHREADS), SMEM_REAL_D, side, A22 + BM + (long)BM * lda, lda, mb - BM,
+                             Lp + BM, lda, NBO / BK, nr);
+          side_busy = true;
+          block_event_on_side = true;
+        } else {
+          hipLaunchKernelGGL(k_potrf_syrk, dim3((unsigned)(ntb * (ntb + 1) / 2)), dim3(Cfg4::NTHREADS), SMEM_REAL_D, ctx->stream, A22, lda, mb, Lp, lda,
+                             NBO / BK, ntb);
+        }
       }
       HIPCHK(ctx, hipGetLastError());
     }
     // event_cols > 0 (a multiple of 256): block column b of that width is final and no longer read once its last outer block's update has run
-    if (event_cols > 0 && ((K0 + NBO) % event_cols == 0 || K0 + NBO >= n)) HIPCHK(ctx, hipEventRecord(ctx->blk_ev[K0 / event_cols], ctx->stream));
+    // (on whichever stream reads its panels last)
+    if (event_cols > 0 && ((K0 + NBO) % event_cols == 0 || K0 + NBO >= n)) {
+      if (!block_event_on_side) NLSCHK(join_side());
+      HIPCHK(ctx, hipEventRecord(ctx->blk_ev[K0 / event_cols], block_event_on_side ? side : ctx->stream));
+    }
   }
+  NLSCHK(join_side());  // (what follows on the main stream reads the whole factor)
   if (rhs_run) {
     HIPCHK(ctx, hipMemcpyAsync(rhs_run, xsol, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
     if (carried) *carried = true;

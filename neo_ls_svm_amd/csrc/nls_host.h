@@ -59,6 +59,7 @@ struct nls_ctx {
   hipStream_t copy_lane[3] = {nullptr, nullptr, nullptr};  // further lanes of the pageable download (nls_dual.hip: helper threads)
   std::vector<hipEvent_t> blk_ev;     // one event per finished block column
   hipEvent_t side_ev[4] = {nullptr, nullptr, nullptr, nullptr};  // fork, potrf done, download done (timing of the side stream)
+  hipEvent_t la_ev[2] = {nullptr, nullptr};  // look-ahead of the real Cholesky factorisation (nls_dual.hip: potrf_lower_real): fork, join
   std::string err;
   std::map<std::string, DevBuf> ws;  // grow-only named workspace
   size_t ws_limit = 0;

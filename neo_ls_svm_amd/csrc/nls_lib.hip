@@ -239,6 +239,8 @@ extern "C" void nls_ctx_destroy(nls_ctx* ctx) {
   if (ctx->blas2) rocblas_destroy_handle(ctx->blas2);
   for (auto e : ctx->side_ev)
     if (e) (void)hipEventDestroy(e);
+  for (auto e : ctx->la_ev)
+    if (e) (void)hipEventDestroy(e);
   if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
   for (auto e : ctx->blk_ev)
     if (e) (void)hipEventDestroy(e);
@@ -1150,12 +1152,13 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
   bool side_copy = false, y_carried = false;
   double2* ysolve = nullptr;  // beta = cho_solve(L_, b): L y = b is carried through the factorisation, L^H beta = y follows the download
   if (a->L) {
-    if (!ctx->stream2) {
-      HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+    if (!ctx->stream2) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));  // (the dual path's look-ahead may have made it)
+    if (!ctx->blas2) {
       if (rocblas_create_handle(&ctx->blas2) != rocblas_status_success) return fail(ctx, NLS_ERR_HIP, "rocblas_create_handle (side stream) failed");
       BLASCHK(ctx, rocblas_set_stream(ctx->blas2, ctx->stream2));
-      for (auto& e : ctx->side_ev) HIPCHK(ctx, hipEventCreate(&e));
     }
+    for (auto& e : ctx->side_ev)
+      if (!e) HIPCHK(ctx, hipEventCreate(&e));
     NLSCHK(ws_get_t(ctx, "chol.info2", 4, &dinfo2));
     side = true;
     hipStream_t s2 = ctx->stream2;

@@ -246,7 +246,7 @@ static int sy2sb(nls_ctx* ctx, T* A, int n, long lda, T* tau1, int* dflag, int* 
   NLSCHK(ws_get_t(ctx, "sb.Wp", (size_t)parts_max * n * B, &Wp));
   NLSCHK(ws_get_t(ctx, "sb.ps", (size_t)1, &ps));
   const size_t mat = sb_mat_bytes<T, B>(B), tile = sb_mat_bytes<T, B>(64);
-  const size_t lds_chol = 2 * mat, lds_recon = 3 * mat, lds_apply = mat + tile, lds_finish = mat + tile, lds_reduce = 2 * tile, lds_x = tile + mat;
+  const size_t lds_chol = 2 * mat, lds_recon = 3 * mat, lds_apply = mat + tile, lds_finish = 2 * mat + tile, lds_reduce = 2 * tile, lds_x = tile + mat;
   NLSCHK(sb_lds_optin(ctx, k_sb_small_chol<T, B>, lds_chol, "k_sb_small_chol"));
   NLSCHK(sb_lds_optin(ctx, k_sb_small_recon<T, B>, lds_recon, "k_sb_small_recon"));
   NLSCHK(sb_lds_optin(ctx, k_sb_apply<T, B>, lds_apply, "k_sb_apply"));
@@ -256,7 +256,7 @@ static int sy2sb(nls_ctx* ctx, T* A, int n, long lda, T* tau1, int* dflag, int* 
   const size_t lds_her2k = her2k_lds_bytes<T, B>();
   NLSCHK(sb_lds_optin(ctx, k_sb_her2k<T, B>, lds_her2k, "k_sb_her2k"));
   hipStream_t st = ctx->stream;
-  const dim3 red_grid((B * B + 255) / 256);
+  const dim3 red_grid((4 * B * B + 255) / 256);  // (a quad per element)
   // well-conditioned panels take two passes instead of three (k_sb_small_chol); not in the rescue attempt; NLS_SB_ADAPTIVE=0: never
   const char* adaptive_env = std::getenv("NLS_SB_ADAPTIVE");
   const int adaptive = !(adaptive_env && adaptive_env[0] == '0') && !perturb ? 1 : 0;

@@ -28,6 +28,7 @@
 // copy with every panel perturbed by 1e-13 of its norm (k_sb_perturb) and, if that fails too, hands the copy to the one-stage panel.
 // All reductions run over per-block partials in a fixed order: bit-reproducible.
 #pragma once
+#include "nls_gemm.h"
 #include "nls_trd.h"
 
 namespace nls {
@@ -69,7 +70,7 @@ __device__ __forceinline__ bool finite_(double a) { return isfinite(a); }
 // columns cg + TPR q) with ONE barrier per elimination step (the pivot column / row travels through a double-buffered
 // LDS vector).  No explicit inverses: Q = P R^-1 is a row-wise back substitution with R in LDS (uniform reads).
 // ================================================================================================================
-constexpr int RW = 256;  // rows per workgroup of the panel kernels
+constexpr int RW = 64;  // rows per workgroup of the panel kernels: FOUR threads per row (thread t: row t / 4, columns t % 4 + 4 i)
 
 template <int B>
 struct Small {
@@ -88,22 +89,48 @@ struct PanelSmall {
   int skip2;       // the panel is well conditioned: its first pass ran unshifted and the second pass is skipped (CholeskyQR2)
 };
 
-// out[e] = sum_p part[p * count + e] in index order (bit-reproducible), 8 loads in flight per thread
+// Value of lane SRC of every quad, in all four lanes (DPP quad_perm [SRC, SRC, SRC, SRC]; whole quads must be active)
+template <int SRC>
+__device__ __forceinline__ double quad_bcast(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), SRC * 0x55, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), SRC * 0x55, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+template <int SRC>
+__device__ __forceinline__ Z quad_bcast(Z v) {
+  return {quad_bcast<SRC>(v.re), quad_bcast<SRC>(v.im)};
+}
+template <int CTRL>
+__device__ __forceinline__ double quad_perm(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ Z quad_perm(Z v) {
+  return {quad_perm<CTRL>(v.re), quad_perm<CTRL>(v.im)};
+}
+
+// out[e] = sum_p part[p * count + e] in a fixed order (bit-reproducible): the four lanes of a quad take the parts p = g, g + 4, ... of one
+// element (8 loads in flight each) and their sums are added as (s0 + s1) + (s2 + s3).  Grid: ceil(4 count / 256).
 template <class T>
 __global__ void __launch_bounds__(256) k_sb_reduce(const T* part, int nparts, int count, T* out) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= count) return;
+  const int e = (blockIdx.x * 256 + threadIdx.x) / 4, g = threadIdx.x % 4;
   T s = zero_<T>();
-  int p = 0;
-  for (; p + 8 <= nparts; p += 8) {
-    T v[8];
+  if (e < count) {  // uniform over a quad
+    int p = g;
+    for (; p + 28 < nparts; p += 32) {
+      T v[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) v[q] = part[(long)(p + q) * count + e];
+      for (int q = 0; q < 8; ++q) v[q] = part[(long)(p + 4 * q) * count + e];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) s = s + v[q];
+      for (int q = 0; q < 8; ++q) s = s + v[q];
+    }
+    for (; p < nparts; p += 4) s = s + part[(long)p * count + e];
   }
-  for (; p < nparts; ++p) s = s + part[(long)p * count + e];
-  out[e] = s;
+  s = s + quad_perm<0xB1>(s);  // lane ^ 1
+  s = s + quad_perm<0x4E>(s);  // lane ^ 2
+  if (g == 0 && e < count) out[e] = s;
 }
 
 // Gram of the rows held in a 64 x B LDS tile, accumulated into acc (thread (ti, tj): entries (ti + 16 x, tj + 16 y))
@@ -135,7 +162,7 @@ __device__ __forceinline__ void gram_store(const T (&acc)[B / 16][B / 16], T* ou
     for (int y = 0; y < TI; ++y) out[(ti + 16 * x) + B * (tj + 16 * y)] = acc[x][y];
 }
 
-// ---- panel Gram partials: Gp[block][i + B j] = sum over the block's 256 rows of conj(P[r][i]) P[r][j] ------------------
+// ---- panel Gram partials: Gp[block][i + B j] = sum over the block's RW rows of conj(P[r][i]) P[r][j] ------------------
 template <class T, int B>
 __global__ void __launch_bounds__(256) k_sb_gram(const T* P, long ldp, int m, int kb, T* Gp) {
   constexpr int TI = B / 16;
@@ -228,6 +255,37 @@ __device__ __attribute__((noinline)) void lds_row_solve_upper(T (*X)[B + 1], int
   row_solve_upper<T, B, UNIT>(x, R, dinv);
 #pragma unroll
   for (int c = 0; c < B; ++c) X[i][c] = x[c];
+}
+
+// q R = p for one row per QUAD: thread q4 of the quad holds the columns q4 + 4 i of its row (x[i], i < B / 4).  Rq: the upper triangular R
+// (identity outside the leading block, exact zeros below the diagonal) in LDS with the columns permuted to the owners' order,
+// Rq[j][(B / 4) q4 + i] = R[j][q4 + 4 i] - a thread's B / 4 entries of a row are one contiguous run.  Step j: the owner's x[j] / R[j][j] travels
+// through the quad (DPP), every thread updates its columns to the right of j.  A quarter of the thread-per-row form's multiply-adds and
+// LDS reads per thread, four times the threads per row: the row blocks of the panel kernels are 64 rows instead of 256.
+template <class T, int B>
+__device__ __forceinline__ void load_rq(T (*Rq)[B], const T* R /* R[r][c] at r + B c */) {
+  constexpr int CQ = B / 4;
+  for (int e = threadIdx.x; e < B * B; e += 256) {
+    const int r = e % B, c = e / B;
+    Rq[r][CQ * (c % 4) + c / 4] = R[e];
+  }
+}
+template <class T, int B, bool UNIT>
+__device__ __forceinline__ void quad_row_solve_upper(T (&x)[B / 4], T (*Rq)[B], const T* dinv, int q4) {
+  constexpr int CQ = B / 4;
+  static_for<B>([&](auto jc) {
+    constexpr int j = decltype(jc)::value, io = j / 4, sl = j % 4;
+    T r[CQ];
+#pragma unroll
+    for (int i = io; i < CQ; ++i) r[i] = Rq[j][CQ * q4 + i];
+    T t = x[io];
+    if (!UNIT) t = t * dinv[j];
+    const T xj = quad_bcast<sl>(t);
+    const T u = x[io] - xj * r[io];
+    x[io] = q4 == sl ? xj : (q4 > sl ? u : x[io]);  // column j itself: the solved value; its right neighbours in this group of four
+#pragma unroll
+    for (int i = io + 1; i < CQ; ++i) x[i] = x[i] - xj * r[i];
+  });
 }
 
 // ---- small kernel of passes 1 and 2:  G (+ shift) = R^H R;  ps->Rs = R;  Racc = R Racc -----------------------------------------
@@ -329,44 +387,40 @@ __global__ void __launch_bounds__(256) k_sb_small_chol(int kb, int m, int pass, 
   }
 }
 
-// ---- apply pass: rows of Q = rows of P solved against R (ps->Rs), written to dst; Gram partials of the result -----------------------
+// ---- apply pass: rows of Q = rows of P solved against R (ps->Rs), written to dst; Gram partial of the block's 64 result rows ----------
 template <class T, int B>
-__global__ void __launch_bounds__(256, 1) k_sb_apply(const T* src, long lds_, int m, int kb, const PanelSmall<T, B>* ps, T* dst, long ldd, T* Gp, int second) {
-  constexpr int TI = B / 16;
+__global__ void __launch_bounds__(256) k_sb_apply(const T* src, long lds_, int m, int kb, const PanelSmall<T, B>* ps, T* dst, long ldd, T* Gp, int second) {
+  constexpr int TI = B / 16, CQ = B / 4;
   if (second && ps->skip2) return;  // the second pass of a well-conditioned panel (k_sb_small_chol)
   size_t off = 0;
-  T(*Rs)[B + 1] = sb_carve<T, B + 1>(B, off);
+  T(*Rq)[B] = sb_carve<T, B>(B, off);
   T(*Ps)[B + 1] = sb_carve<T, B + 1>(64, off);
   __shared__ T dinv[B];
-  for (int e = threadIdx.x; e < B * B; e += 256) Rs[e % B][e / B] = ps->Rs[e];
+  load_rq<T, B>(Rq, ps->Rs);
   if (threadIdx.x < B) dinv[threadIdx.x] = inv_(ps->Rs[threadIdx.x + B * threadIdx.x]);
-  const long row = (long)blockIdx.x * RW + threadIdx.x;
-  T x[B];
+  const int rr = threadIdx.x / 4, q4 = threadIdx.x % 4;
+  const long row = (long)blockIdx.x * RW + rr;
+  T x[CQ];
 #pragma unroll
-  for (int c = 0; c < B; ++c) x[c] = (row < m && c < kb) ? src[row + (long)c * lds_] : zero_<T>();
-  __syncthreads();
-  row_solve_upper<T, B, false>(x, Rs, dinv);
-  if (row < m) {
-#pragma unroll
-    for (int c = 0; c < B; ++c)
-      if (c < kb) dst[row + (long)c * ldd] = x[c];
+  for (int i = 0; i < CQ; ++i) {
+    const int c = q4 + 4 * i;
+    x[i] = (row < m && c < kb) ? src[row + (long)c * lds_] : zero_<T>();
   }
+  __syncthreads();
+  quad_row_solve_upper<T, B, false>(x, Rq, dinv, q4);
+#pragma unroll
+  for (int i = 0; i < CQ; ++i) {
+    const int c = q4 + 4 * i;
+    if (row < m && c < kb) dst[row + (long)c * ldd] = x[i];
+    Ps[rr][c] = x[i];
+  }
+  __syncthreads();
   T acc[TI][TI];
 #pragma unroll
   for (int a = 0; a < TI; ++a)
 #pragma unroll
     for (int b = 0; b < TI; ++b) acc[a][b] = zero_<T>();
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int sub = 0; sub < RW / 64; ++sub) {
-    if ((long)blockIdx.x * RW + sub * 64 >= m) break;  // uniform
-    __syncthreads();
-    if (wave == sub) {
-#pragma unroll
-      for (int c = 0; c < B; ++c) Ps[lane][c] = x[c];
-    }
-    __syncthreads();
-    gram_tile_accumulate<T, B>(Ps, acc);
-  }
+  gram_tile_accumulate<T, B>(Ps, acc);
   gram_store<T, B>(acc, Gp + (long)blockIdx.x * B * B);
 }
 
@@ -517,67 +571,59 @@ __global__ void __launch_bounds__(256, 1) k_sb_small_recon(int kb, const T* Ytop
 
 // ---- finish: Y (explicit, m x kb) and Z = Y T into the panel buffers, Y's strictly-lower part into A below the band -----------------
 // Row r < kb of Y comes from Y1, rows >= kb are the rows of Q2 solved against M = U R3 (ps->Rs).  Yb / Zb have zh = B - kb zero rows on top;
-// Zr is Z once more, row-major with B columns.
+// Zr is Z once more, row-major with B columns.  64 rows per workgroup, four threads per row.
 template <class T, int B>
-__global__ void __launch_bounds__(256, 1) k_sb_finish(T* Yb, long ldy, int m, int kb, const PanelSmall<T, B>* ps, T* Zb, T* Zr, T* Apanel, long lda) {
+__global__ void __launch_bounds__(256) k_sb_finish(T* Yb, long ldy, int m, int kb, const PanelSmall<T, B>* ps, T* Zb, T* Zr, T* Apanel, long lda) {
+  constexpr int CQ = B / 4;
   size_t off = 0;
-  T(*Ms)[B + 1] = sb_carve<T, B + 1>(B, off);  // M, later T
+  T(*Mq)[B] = sb_carve<T, B>(B, off);
+  T(*Ts)[B + 1] = sb_carve<T, B + 1>(B, off);
   T(*Ps)[B + 1] = sb_carve<T, B + 1>(64, off);
   __shared__ T dinv[B];
   const int zh = B - kb;
-  for (int e = threadIdx.x; e < B * B; e += 256) Ms[e % B][e / B] = ps->Rs[e];
+  load_rq<T, B>(Mq, ps->Rs);
+  for (int e = threadIdx.x; e < B * B; e += 256) Ts[e % B][e / B] = ps->Tm[e];
   if (threadIdx.x < B) dinv[threadIdx.x] = inv_(ps->Rs[threadIdx.x + B * threadIdx.x]);
-  const long row = (long)blockIdx.x * RW + threadIdx.x;
-  T x[B];
-  if (row < kb) {
+  const int rr = threadIdx.x / 4, q4 = threadIdx.x % 4;
+  const long row = (long)blockIdx.x * RW + rr;
+  T x[CQ];
 #pragma unroll
-    for (int c = 0; c < B; ++c) x[c] = ps->Y1[row + B * c];
-  } else {
-#pragma unroll
-    for (int c = 0; c < B; ++c) x[c] = (row < m && c < kb) ? Yb[(row + zh) + (long)c * ldy] : zero_<T>();
+  for (int i = 0; i < CQ; ++i) {
+    const int c = q4 + 4 * i;
+    if (row < kb)
+      x[i] = ps->Y1[row + B * c];
+    else
+      x[i] = (row < m && c < kb) ? Yb[(row + zh) + (long)c * ldy] : zero_<T>();
   }
   __syncthreads();
-  if (row >= kb) row_solve_upper<T, B, false>(x, Ms, dinv);
+  if (row >= kb) quad_row_solve_upper<T, B, false>(x, Mq, dinv, q4);  // (uniform over a quad)
+#pragma unroll
+  for (int i = 0; i < CQ; ++i) {
+    const int c = q4 + 4 * i;
+    if (row < m && c < kb) {
+      Yb[(row + zh) + (long)c * ldy] = x[i];
+      if (row > c) Apanel[row + (long)c * lda] = x[i];  // below the unit diagonal of Y: below the band of A
+    }
+    Ps[rr][c] = c < kb ? x[i] : zero_<T>();
+  }
+  __syncthreads();
+  // Z = Y T
+  T z[CQ];
+#pragma unroll
+  for (int c = 0; c < CQ; ++c) z[c] = zero_<T>();
+#pragma unroll 2
+  for (int t = 0; t < B; ++t) {
+    const T y = Ps[rr][t];
+#pragma unroll
+    for (int c = 0; c < CQ; ++c) z[c] = z[c] + y * Ts[t][q4 + 4 * c];
+  }
   if (row < m) {
 #pragma unroll
-    for (int c = 0; c < B; ++c)
-      if (c < kb) {
-        Yb[(row + zh) + (long)c * ldy] = x[c];
-        if (row > c) Apanel[row + (long)c * lda] = x[c];  // below the unit diagonal of Y: below the band of A
+    for (int c = 0; c < CQ; ++c)
+      if (q4 + 4 * c < kb) {
+        Zb[(row + zh) + (long)(q4 + 4 * c) * ldy] = z[c];
+        Zr[(row + zh) * B + q4 + 4 * c] = z[c];  // row-major copy: the operand layout of k_sb_hemm
       }
-  }
-  __syncthreads();
-  for (int e = threadIdx.x; e < B * B; e += 256) Ms[e % B][e / B] = ps->Tm[e];
-  // Z = Y T through 64-row tiles: thread (row = tid / 4, quarter = tid % 4)
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  constexpr int CQ = B / 4;
-  for (int sub = 0; sub < RW / 64; ++sub) {
-    const long r0 = (long)blockIdx.x * RW + sub * 64;
-    if (r0 >= m) break;  // uniform
-    __syncthreads();
-    if (wave == sub) {
-#pragma unroll
-      for (int c = 0; c < B; ++c) Ps[lane][c] = (c < kb) ? x[c] : zero_<T>();
-    }
-    __syncthreads();
-    const int rr = threadIdx.x / 4, q4 = threadIdx.x % 4;
-    T z[CQ];
-#pragma unroll
-    for (int c = 0; c < CQ; ++c) z[c] = zero_<T>();
-#pragma unroll 2
-    for (int t = 0; t < B; ++t) {
-      const T y = Ps[rr][t];
-#pragma unroll
-      for (int c = 0; c < CQ; ++c) z[c] = z[c] + y * Ms[t][q4 + 4 * c];
-    }
-    if (r0 + rr < m) {
-#pragma unroll
-      for (int c = 0; c < CQ; ++c)
-        if (q4 + 4 * c < kb) {
-          Zb[(r0 + rr + zh) + (long)(q4 + 4 * c) * ldy] = z[c];
-          Zr[(long)(r0 + rr + zh) * B + q4 + 4 * c] = z[c];  // row-major copy: the operand layout of k_sb_hemm
-        }
-    }
   }
 }
 

@@ -246,7 +246,7 @@ static int sy2sb(nls_ctx* ctx, T* A, int n, long lda, T* tau1, int* dflag, int* 
   NLSCHK(ws_get_t(ctx, "sb.Wp", (size_t)parts_max * n * B, &Wp));
   NLSCHK(ws_get_t(ctx, "sb.ps", (size_t)1, &ps));
   const size_t mat = sb_mat_bytes<T, B>(B), tile = sb_mat_bytes<T, B>(64);
-  const size_t lds_chol = 2 * mat, lds_recon = 3 * mat, lds_apply = mat + tile, lds_finish = 2 * mat + tile, lds_reduce = 2 * tile, lds_x = tile + mat;
+  const size_t lds_chol = 2 * mat, lds_recon = 4 * mat, lds_apply = mat + tile, lds_finish = 2 * mat + tile, lds_reduce = 2 * tile, lds_x = tile + mat;
   NLSCHK(sb_lds_optin(ctx, k_sb_small_chol<T, B>, lds_chol, "k_sb_small_chol"));
   NLSCHK(sb_lds_optin(ctx, k_sb_small_recon<T, B>, lds_recon, "k_sb_small_recon"));
   NLSCHK(sb_lds_optin(ctx, k_sb_apply<T, B>, lds_apply, "k_sb_apply"));
@@ -260,6 +260,13 @@ static int sy2sb(nls_ctx* ctx, T* A, int n, long lda, T* tau1, int* dflag, int* 
   // well-conditioned panels take two passes instead of three (k_sb_small_chol); not in the rescue attempt; NLS_SB_ADAPTIVE=0: never
   const char* adaptive_env = std::getenv("NLS_SB_ADAPTIVE");
   const int adaptive = !(adaptive_env && adaptive_env[0] == '0') && !perturb ? 1 : 0;
+  // NLS_SB_STAMP=1 (diagnostic): the in-kernel time line of the first panel's k_sb_small_recon, printed when the reduction has been queued
+  static const bool want_stamps = [] { const char* m = std::getenv("NLS_SB_STAMP"); return m && m[0] == '1'; }();
+  long long* dstamps = nullptr;
+  if (want_stamps) {
+    NLSCHK(ws_get_t(ctx, "sb.stamps", (size_t)16, &dstamps));
+    HIPCHK(ctx, hipMemsetAsync(dstamps, 0, 16 * sizeof(long long), st));
+  }
   int j = 0;
   for (;;) {
     const int m = n - j - B;            // rows below the band in column j
@@ -287,7 +294,7 @@ static int sy2sb(nls_ctx* ctx, T* A, int n, long lda, T* tau1, int* dflag, int* 
     hipLaunchKernelGGL((k_sb_small_chol<T, B>), dim3(1), dim3(256), lds_chol, st, kb, m, 1, ps, dflag, adaptive);
     hipLaunchKernelGGL((k_sb_apply<T, B>), dim3(nch), dim3(256), lds_apply, st, Yb + zh, (long)n, m, kb, ps, Yb + zh, (long)n, Gp, 1);
     hipLaunchKernelGGL((k_sb_reduce<T>), red_grid, dim3(256), 0, st, Gp, nch, B * B, ps->G);
-    hipLaunchKernelGGL((k_sb_small_recon<T, B>), dim3(1), dim3(256), lds_recon, st, kb, Yb + zh, (long)n, ps, P, lda, tau1 + j, dflag);
+    hipLaunchKernelGGL((k_sb_small_recon<T, B>), dim3(1), dim3(256), lds_recon, st, kb, Yb + zh, (long)n, ps, P, lda, tau1 + j, dflag, j == 0 ? dstamps : nullptr);
     hipLaunchKernelGGL((k_sb_finish<T, B>), dim3(nch), dim3(256), lds_finish, st, Yb, (long)n, m, kb, ps, Zb, Zr, P, lda);
     HIPCHK(ctx, hipGetLastError());
     T* A22 = A + (long)(j + kb) + (long)(j + kb) * lda;
@@ -301,6 +308,14 @@ static int sy2sb(nls_ctx* ctx, T* A, int n, long lda, T* tau1, int* dflag, int* 
     hipLaunchKernelGGL((k_sb_her2k<T, B>), dim3(NT * (NT + 1) / 2), dim3(256), lds_her2k, st, A22, lda, mh, Wb, Yb, (long)n, kb);
     HIPCHK(ctx, hipGetLastError());
     j += kb;
+  }
+  if (want_stamps) {
+    long long h[16];
+    HIPCHK(ctx, hipMemcpyAsync(h, dstamps, sizeof(h), hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    std::fprintf(stderr, "[nls] k_sb_small_recon time line (us, 100 MHz clock; n = %d):", n);
+    for (int i = 1; i <= 9; ++i) std::fprintf(stderr, " %.2f", h[i] ? (double)(h[i] - h[0]) * 0.01 : 0.0);
+    std::fprintf(stderr, "\n");
   }
   *ncols_reduced = j;
   return NLS_OK;

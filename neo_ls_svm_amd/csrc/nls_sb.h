@@ -273,19 +273,120 @@ __device__ __forceinline__ void load_rq(T (*Rq)[B], const T* R /* R[r][c] at r +
 template <class T, int B, bool UNIT>
 __device__ __forceinline__ void quad_row_solve_upper(T (&x)[B / 4], T (*Rq)[B], const T* dinv, int q4) {
   constexpr int CQ = B / 4;
+  // Row j + 1 of R is fetched while row j is applied (the scheduling barriers keep the LDS reads ahead of the step's arithmetic: left alone,
+  // the compiler issues them where the previous step's registers come free and every step waits out an LDS round trip).
+  T rn[CQ];
+#pragma unroll
+  for (int i = 0; i < CQ; ++i) rn[i] = Rq[0][CQ * q4 + i];
+  T dn = UNIT ? T{} : dinv[0];
   static_for<B>([&](auto jc) {
     constexpr int j = decltype(jc)::value, io = j / 4, sl = j % 4;
     T r[CQ];
 #pragma unroll
-    for (int i = io; i < CQ; ++i) r[i] = Rq[j][CQ * q4 + i];
+    for (int i = io; i < CQ; ++i) r[i] = rn[i];
+    if constexpr (j + 1 < B) {
+#pragma unroll
+      for (int i = (j + 1) / 4; i < CQ; ++i) rn[i] = Rq[j + 1][CQ * q4 + i];
+    }
+    const T dj = dn;
+    if constexpr (!UNIT && j + 1 < B) dn = dinv[j + 1];
+    __builtin_amdgcn_sched_barrier(0);
     T t = x[io];
-    if (!UNIT) t = t * dinv[j];
+    if (!UNIT) t = t * dj;
     const T xj = quad_bcast<sl>(t);
     const T u = x[io] - xj * r[io];
     x[io] = q4 == sl ? xj : (q4 > sl ? u : x[io]);  // column j itself: the solved value; its right neighbours in this group of four
 #pragma unroll
     for (int i = io + 1; i < CQ; ++i) x[i] = x[i] - xj * r[i];
+    __builtin_amdgcn_sched_barrier(0);
   });
+}
+
+// ---- one-wave factorisations of a real B x B matrix, lane = column ---------------------------------------------------------------
+// The 256-thread forms above pay a workgroup barrier and an LDS round trip per elimination step (0.42 us per step of reg_cholesky, 0.54 per
+// step of the modified LU: in-kernel time line, NLS_SB_STAMP).  Here ONE wave keeps the matrix in registers - lane c holds column c, a[r] =
+// A[r][c]; lanes >= B mirror lanes < B and write nothing - and a step costs two v_readlane (the pivot column's entry r, a uniform value in
+// scalar registers) and one multiply-add per row: no LDS, no barrier, no division (v_rsq / v_rcp + Newton steps).  The pivot column is
+// scaled once at the end (its factor is folded into the other operand of the update), so the rounding differs from the classical order in
+// the last bits.
+__device__ __forceinline__ double rdlane(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ __forceinline__ double fast_rsqrt(double d) {  // d > 0, finite
+  const double y = __builtin_amdgcn_rsq(d);
+  const double e = fma(-(d * y), y, 1.0);
+  return fma(y * e, fma(0.375, e, 0.5), y);
+}
+__device__ __forceinline__ double fast_rcp(double d) {  // |d| >= 1 here
+  double y = __builtin_amdgcn_rcp(d);
+  double e = fma(-d, y, 1.0);
+  y = fma(y, e, y);
+  e = fma(-d, y, 1.0);
+  return fma(y, e, y);
+}
+// Cholesky of the leading k x k block of a symmetric matrix held IN FULL (both triangles are updated: the entry L[c][p] a lane needs is its
+// own a[p]).  Out: a[r] = L[r][c] for r >= c (r, c < k).  dmin / dmax: extreme diagonal entries of L.  false: a pivot <= 0 or not finite.
+template <int B>
+__device__ __forceinline__ bool wave_cholesky(double (&a)[B], int k, int lane, double& dmin, double& dmax) {
+  bool ok = true;
+  double myinv = 1.0, mysq = 1.0;
+  dmin = 1e300;
+  dmax = 0.0;
+  const int c = lane & (B - 1);
+  static_for<B>([&](auto pc) {
+    constexpr int p = decltype(pc)::value;
+    if (p < k) {  // uniform
+      double d = rdlane(a[p], p);
+      if (!(d > 0.0) || !isfinite(d)) {
+        ok = false;
+        d = 1.0;
+      }
+      const double inv = fast_rsqrt(d), sq = d * inv;
+      dmin = fmin(dmin, sq);
+      dmax = fmax(dmax, sq);
+      if (c == p) {
+        myinv = inv;
+        mysq = sq;
+      }
+      const double lc2 = a[p] * inv * inv;  // L[c][p] / sqrt(d)
+      if (c > p) {
+#pragma unroll
+        for (int r = p + 1; r < B; ++r) a[r] = fma(-rdlane(a[r], p), lc2, a[r]);
+      }
+    }
+  });
+#pragma unroll
+  for (int r = 0; r < B; ++r) a[r] = r == c ? mysq : a[r] * myinv;
+  return ok;
+}
+// Modified LU (Householder reconstruction) of Q - S in place: step p takes s = -sign(d) (d = the diagonal entry; -1 for d = 0), pivot d - s
+// (|pivot| = |d| + 1: no pivoting needed).  Out: a[r] = L[r][c] (r > c, unit diagonal implied), U[r][c] (r <= c, the pivot on the diagonal);
+// lane p holds its step's s in sd.
+template <int B>
+__device__ __forceinline__ void wave_modified_lu(double (&a)[B], int k, int lane, double& sd) {
+  double myipiv = 1.0;
+  sd = -1.0;
+  const int c = lane & (B - 1);
+  static_for<B>([&](auto pc) {
+    constexpr int p = decltype(pc)::value;
+    if (p < k) {  // uniform
+      const double d = rdlane(a[p], p);
+      const double s = d > 0.0 ? -1.0 : (d < 0.0 ? 1.0 : -1.0);
+      const double piv = d - s, ipiv = fast_rcp(piv);
+      if (c == p) {
+        myipiv = ipiv;
+        sd = s;
+        a[p] = piv;
+      }
+      const double rp = a[p] * ipiv;  // U[p][c] / pivot
+      if (c > p) {
+#pragma unroll
+        for (int r = p + 1; r < B; ++r) a[r] = fma(-rdlane(a[r], p), rp, a[r]);
+      }
+    }
+  });
+#pragma unroll
+  for (int r = 0; r < B; ++r) a[r] = r > c ? a[r] * myipiv : a[r];
 }
 
 // ---- small kernel of passes 1 and 2:  G (+ shift) = R^H R;  ps->Rs = R;  Racc = R Racc -----------------------------------------
@@ -293,9 +394,8 @@ __device__ __forceinline__ void quad_row_solve_upper(T (&x)[B / 4], T (*Rq)[B], 
 // order of 10^2 .. 10^3: one unshifted pass leaves an orthogonality error kappa^2 u <= 1e-10, which the last pass - k_sb_small_recon - removes:
 // CholeskyQR2) the second pass is skipped (ps->skip2; its kernels return at once).  Otherwise the shifted three-pass scheme runs as before.
 template <class T, int B>
-__global__ void __launch_bounds__(256) k_sb_small_chol(int kb, int m, int pass, PanelSmall<T, B>* ps, int* flag, int adaptive) {
+__device__ __forceinline__ void small_chol_generic(int kb, int m, int pass, PanelSmall<T, B>* ps, int* flag, int adaptive) {
   using S = Small<B>;
-  if (pass == 1 && ps->skip2) return;  // uniform
   size_t off = 0;
   T(*R)[B + 1] = sb_carve<T, B + 1>(B, off);
   T(*Ra)[B + 1] = sb_carve<T, B + 1>(B, off);
@@ -387,6 +487,80 @@ __global__ void __launch_bounds__(256) k_sb_small_chol(int kb, int m, int pass, 
   }
 }
 
+// Real B = 32: the factorisation on one wave (wave_cholesky); the other waves stage Racc meanwhile.
+template <int B>
+__device__ __forceinline__ void small_chol_wave(int kb, int m, int pass, PanelSmall<double, B>* ps, int* flag, int adaptive) {
+  using S = Small<B>;
+  size_t off = 0;
+  double(*R)[B + 1] = sb_carve<double, B + 1>(B, off);
+  double(*Ra)[B + 1] = sb_carve<double, B + 1>(B, off);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (wave == 0) {
+    const int c = lane & (B - 1);
+    double a[B];
+    auto load = [&]() {
+#pragma unroll
+      for (int r = 0; r < B; ++r) a[r] = ps->G[r + B * c];
+    };
+    load();
+    bool done = false;
+    double dmin, dmax;
+    if (pass == 0 && adaptive) {
+      const bool ok0 = wave_cholesky<B>(a, kb, lane, dmin, dmax);
+      done = ok0 && dmin > 1e-2 * dmax;
+      if (!done) load();
+    }
+    if (pass == 0 && lane == 0) ps->skip2 = done ? 1 : 0;
+    if (!done) {
+      if (pass == 0) {
+        double tr = (lane < B && c < kb) ? ps->G[c + B * c] : 0.0;
+        tr = wave_sum(tr);
+        const double shift = 11.0 * ((double)m * kb + (double)kb * (kb + 1)) * 1.1102230246251565e-16 * tr + 1e-300;
+#pragma unroll
+        for (int r = 0; r < B; ++r) a[r] += (r == c && c < kb) ? shift : 0.0;
+      }
+      const bool ok = wave_cholesky<B>(a, kb, lane, dmin, dmax);
+      if (!ok && lane == 0) flag[0] = 1;
+    }
+    // R = L^T (upper; identity outside the leading block): lane c writes row c
+    if (lane < B) {
+#pragma unroll
+      for (int r = 0; r < B; ++r) R[c][r] = (c < kb && r < kb) ? (r >= c ? a[r] : 0.0) : (r == c ? 1.0 : 0.0);
+    }
+  } else {
+    for (int e = threadIdx.x - 64; e < B * B; e += 192) {
+      const int r = e % B, c = e / B;
+      Ra[r][c] = pass == 0 ? (r == c ? 1.0 : 0.0) : ps->Racc[e];
+    }
+  }
+  __syncthreads();
+  const int r = threadIdx.x / S::TPR, cg = threadIdx.x % S::TPR;
+  double acc[S::CPT];
+#pragma unroll
+  for (int q = 0; q < S::CPT; ++q) acc[q] = 0.0;
+#pragma unroll 2
+  for (int t = 0; t < B; ++t) {
+    const double x = R[r][t];
+#pragma unroll
+    for (int q = 0; q < S::CPT; ++q) acc[q] = acc[q] + x * Ra[t][cg + S::TPR * q];
+  }
+#pragma unroll
+  for (int q = 0; q < S::CPT; ++q) {
+    const int c = cg + S::TPR * q;
+    ps->Racc[r + B * c] = acc[q];
+    ps->Rs[r + B * c] = R[r][c];
+  }
+}
+
+template <class T, int B>
+__global__ void __launch_bounds__(256) k_sb_small_chol(int kb, int m, int pass, PanelSmall<T, B>* ps, int* flag, int adaptive) {
+  if (pass == 1 && ps->skip2) return;  // uniform
+  if constexpr (sizeof(T) == 8 && B == 32)
+    small_chol_wave<B>(kb, m, pass, ps, flag, adaptive);
+  else
+    small_chol_generic<T, B>(kb, m, pass, ps, flag, adaptive);
+}
+
 // ---- apply pass: rows of Q = rows of P solved against R (ps->Rs), written to dst; Gram partial of the block's 64 result rows ----------
 template <class T, int B>
 __global__ void __launch_bounds__(256) k_sb_apply(const T* src, long lds_, int m, int kb, const PanelSmall<T, B>* ps, T* dst, long ldd, T* Gp, int second) {
@@ -429,16 +603,19 @@ __global__ void __launch_bounds__(256) k_sb_apply(const T* src, long lds_, int m
 // block become rows of Y by one solve against M), ps->Y1, ps->Tm, the kb x kb R factor S R3 R2 R1 written into the band block of A
 // (upper triangle; zeros below), tau1.
 template <class T, int B>
-__global__ void __launch_bounds__(256, 1) k_sb_small_recon(int kb, const T* Ytop, long ldy, PanelSmall<T, B>* ps, T* Aband, long lda, T* tau1, int* flag) {
+__global__ void __launch_bounds__(256, 1) k_sb_small_recon(int kb, const T* Ytop, long ldy, PanelSmall<T, B>* ps, T* Aband, long lda, T* tau1, int* flag, long long* stamps) {
   using S = Small<B>;
+  constexpr int CQ = B / 4;
   size_t off = 0;
   T(*R3)[B + 1] = sb_carve<T, B + 1>(B, off);   // R3, later U
   T(*X)[B + 1] = sb_carve<T, B + 1>(B, off);    // Racc, later Y1^H
-  T(*Q)[B + 1] = sb_carve<T, B + 1>(B, off);    // Qtop rows (after the solve), later -U S^-1 rows -> T
+  T(*Q)[B + 1] = sb_carve<T, B + 1>(B, off);    // U1 of the series, Qtop rows (after the solve), later -U S^-1 rows -> T
+  T(*Rq)[B] = sb_carve<T, B>(B, off);           // the triangular matrix of a quad row solve, columns in the owners' order
   __shared__ T col[2][B], Sd[B], dinv[B];
-  __shared__ int bad;
+  __shared__ int bad, coarse;
   const int r = threadIdx.x / S::TPR, cg = threadIdx.x % S::TPR;
-  if (threadIdx.x == 0) bad = 0;
+  if (threadIdx.x == 0) bad = 0, coarse = 0;
+  if (stamps && threadIdx.x == 0) stamps[0] = wall_clock64();
   T a[S::CPT];
 #pragma unroll
   for (int q = 0; q < S::CPT; ++q) a[q] = ps->G[r + B * (cg + S::TPR * q)];
@@ -454,22 +631,58 @@ __global__ void __launch_bounds__(256, 1) k_sb_small_recon(int kb, const T* Ytop
       }
     }
     if (!(dev < 1e-12)) bad = 1;
+    if (!(dev < 1e-16)) coarse = 1;
   }
   __syncthreads();
+  if (stamps && threadIdx.x == 0) stamps[1] = wall_clock64();
   bool ok = bad == 0;
-  ok = reg_cholesky<T, B>(a, kb, col) && ok;
-  if (!ok && threadIdx.x == 0) flag[0] = 1;
+  if (coarse) {  // uniform.  |G3 - I| >= 1e-8: the factorisation proper
+    ok = reg_cholesky<T, B>(a, kb, col) && ok;
 #pragma unroll
-  for (int q = 0; q < S::CPT; ++q) {
-    const int c = cg + S::TPR * q;
-    const bool in = r < kb && c < kb;
-    if (in && c <= r) R3[c][r] = conj_(a[q]);
-    if (in && c < r) R3[r][c] = zero_<T>();
-    if (!in) R3[r][c] = r == c ? one_<T>() : zero_<T>();
-    X[r][c] = ps->Racc[r + B * c];
+    for (int q = 0; q < S::CPT; ++q) {
+      const int c = cg + S::TPR * q;
+      const bool in = r < kb && c < kb;
+      if (in && c <= r) R3[c][r] = conj_(a[q]);
+      if (in && c < r) R3[r][c] = zero_<T>();
+      if (!in) R3[r][c] = r == c ? one_<T>() : zero_<T>();
+    }
+  } else {
+    // G3 = I + E with |E| < 1e-8 (the usual case: E is the rounding of the second pass): the Cholesky factor by its series, R3 = I + U1 + U2
+    // with U1 = striu(E) + diag(E) / 2 and U2 = -(striu(P) + diag(P) / 2), P = U1^H U1 - no elimination steps; the next term is of the
+    // order of |E|^3 < 1e-24.
+    T u1[S::CPT];
+#pragma unroll
+    for (int q = 0; q < S::CPT; ++q) {
+      const int c = cg + S::TPR * q;
+      const bool in = r < kb && c < kb;
+      u1[q] = !in ? zero_<T>() : (r < c ? a[q] : (r == c ? make_<T>(0.5 * (real_(a[q]) - 1.0), 0.0) : zero_<T>()));
+      Q[r][c] = u1[q];
+    }
+    __syncthreads();
+    T pr[S::CPT];
+#pragma unroll
+    for (int q = 0; q < S::CPT; ++q) pr[q] = zero_<T>();
+#pragma unroll 2
+    for (int t = 0; t < B; ++t) {
+      const T x = conj_(Q[t][r]);
+#pragma unroll
+      for (int q = 0; q < S::CPT; ++q) pr[q] = pr[q] + x * Q[t][cg + S::TPR * q];
+    }
+#pragma unroll
+    for (int q = 0; q < S::CPT; ++q) {
+      const int c = cg + S::TPR * q;
+      const T u2 = r < c ? neg_(pr[q]) : (r == c ? make_<T>(-0.5 * real_(pr[q]), 0.0) : zero_<T>());
+      R3[r][c] = (r == c ? one_<T>() : zero_<T>()) + u1[q] + u2;
+    }
+    __syncthreads();  // (Q is rewritten below)
   }
+  if (!ok && threadIdx.x == 0) flag[0] = 1;
+  if (stamps && threadIdx.x == 0) stamps[2] = wall_clock64();
+#pragma unroll
+  for (int q = 0; q < S::CPT; ++q) X[r][cg + S::TPR * q] = ps->Racc[r + B * (cg + S::TPR * q)];
   __syncthreads();
   if (threadIdx.x < B) dinv[threadIdx.x] = inv_(R3[threadIdx.x][threadIdx.x]);
+  for (int e = threadIdx.x; e < B * B; e += 256) Rq[e / B][CQ * ((e % B) % 4) + (e % B) / 4] = R3[e / B][e % B];
   // Rtot = R3 Racc (kept in registers: rtot[q] = Rtot[r][c])
   T rtot[S::CPT];
 #pragma unroll
@@ -481,45 +694,76 @@ __global__ void __launch_bounds__(256, 1) k_sb_small_recon(int kb, const T* Ytop
     for (int q = 0; q < S::CPT; ++q) rtot[q] = rtot[q] + x * X[t][cg + S::TPR * q];
   }
   __syncthreads();
-  // Qtop = Q2top R3^-1: thread i < B solves row i
-  for (int e = threadIdx.x; e < B * B; e += 256) {
-    const int i = e % B, c = e / B;
-    Q[i][c] = (i < kb && c < kb) ? Ytop[(long)i + (long)c * ldy] : zero_<T>();
+  if (stamps && threadIdx.x == 0) stamps[3] = wall_clock64();
+  // Qtop = Q2top R3^-1: a quad per row (threads < 4 B)
+  if (threadIdx.x < 4 * B) {
+    const int rr = threadIdx.x / 4, q4 = threadIdx.x % 4;
+    T x[CQ];
+#pragma unroll
+    for (int i = 0; i < CQ; ++i) {
+      const int c = q4 + 4 * i;
+      x[i] = (rr < kb && c < kb) ? Ytop[(long)rr + (long)c * ldy] : zero_<T>();
+    }
+    if (stamps) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (threadIdx.x == 0) stamps[7] = wall_clock64();
+    }
+    quad_row_solve_upper<T, B, false>(x, Rq, dinv, q4);
+    if (stamps && threadIdx.x == 0) stamps[9] = wall_clock64();
+#pragma unroll
+    for (int i = 0; i < CQ; ++i) Q[rr][q4 + 4 * i] = x[i];
   }
   __syncthreads();
-  if (threadIdx.x < B) lds_row_solve_upper<T, B, false>(Q, threadIdx.x, R3, dinv);
-  __syncthreads();
-  // Modified LU of Qtop - S, in place in the LDS matrix Q (a plain loop: two barriers per step; unrolled in registers it spills)
-  for (int p = 0; p < kb; ++p) {
-    const T d = Q[p][p];
-    const double ad = sqrt(abs2_(d));
-    const T s = ad > 0.0 ? (-1.0 / ad) * d : make_<T>(-1.0, 0.0);
-    const T piv = d - s;  // |piv| = |d| + 1: no pivoting needed
-    const T mult = r > p && r < kb ? Q[r][p] * inv_(piv) : zero_<T>();
-    T upd[S::CPT];
+  if (stamps && threadIdx.x == 0) stamps[4] = wall_clock64();
+  if constexpr (sizeof(T) == 8 && B == 32) {
+    // Modified LU of Qtop - S on one wave, the matrix in registers (wave_modified_lu)
+    if (threadIdx.x < 64) {
+      const int lane = threadIdx.x, c = lane & (B - 1);
+      double w[B], sd;
 #pragma unroll
-    for (int q = 0; q < S::CPT; ++q) {
-      const int c = cg + S::TPR * q;
-      upd[q] = (c > p && c < kb) ? mult * Q[p][c] : zero_<T>();
+      for (int i = 0; i < B; ++i) w[i] = Q[i][c];
+      wave_modified_lu<B>(w, kb, lane, sd);
+      if (lane < B) {
+#pragma unroll
+        for (int i = 0; i < B; ++i) Q[i][c] = w[i];
+        Sd[c] = sd;
+      }
     }
     __syncthreads();
-    if (r > p && r < kb) {
+  } else {
+    // Modified LU of Qtop - S, in place in the LDS matrix Q (a plain loop: two barriers per step; unrolled in registers it spills)
+    for (int p = 0; p < kb; ++p) {
+      const T d = Q[p][p];
+      const double ad = sqrt(abs2_(d));
+      const T s = ad > 0.0 ? (-1.0 / ad) * d : make_<T>(-1.0, 0.0);
+      const T piv = d - s;  // |piv| = |d| + 1: no pivoting needed
+      const T mult = r > p && r < kb ? Q[r][p] * inv_(piv) : zero_<T>();
+      T upd[S::CPT];
 #pragma unroll
       for (int q = 0; q < S::CPT; ++q) {
         const int c = cg + S::TPR * q;
-        if (c > p && c < kb) Q[r][c] = Q[r][c] - upd[q];
+        upd[q] = (c > p && c < kb) ? mult * Q[p][c] : zero_<T>();
       }
-      if (cg == p % S::TPR) Q[r][p] = mult;
+      __syncthreads();
+      if (r > p && r < kb) {
+#pragma unroll
+        for (int q = 0; q < S::CPT; ++q) {
+          const int c = cg + S::TPR * q;
+          if (c > p && c < kb) Q[r][c] = Q[r][c] - upd[q];
+        }
+        if (cg == p % S::TPR) Q[r][p] = mult;
+      }
+      if (threadIdx.x == 0) {
+        Q[p][p] = piv;
+        Sd[p] = s;
+      }
+      __syncthreads();
     }
-    if (threadIdx.x == 0) {
-      Q[p][p] = piv;
-      Sd[p] = s;
-    }
-    __syncthreads();
   }
 #pragma unroll
   for (int q = 0; q < S::CPT; ++q) a[q] = Q[r][cg + S::TPR * q];
   __syncthreads();
+  if (stamps && threadIdx.x == 0) stamps[5] = wall_clock64();
   // a now holds L (strict lower, unit diagonal implied) and U (upper incl. diagonal).
   // R factor of the Householder QR: diag(S) Rtot into the band block (upper triangle; zeros below: k_sb_finish puts Y there)
 #pragma unroll
@@ -527,7 +771,7 @@ __global__ void __launch_bounds__(256, 1) k_sb_small_recon(int kb, const T* Ytop
     const int c = cg + S::TPR * q;
     if (r < kb && c < kb) Aband[(long)r + (long)c * lda] = r <= c ? Sd[r] * rtot[q] : zero_<T>();
   }
-  // Y1 (unit lower) -> ps->Y1 and X := Y1^H (unit upper, identity outside);  Q := U -> later M = U R3
+  // Y1 (unit lower) -> ps->Y1 and X := Y1^H (unit upper, identity outside; Rq: its image for the quad solve);  Q := U -> later M = U R3
 #pragma unroll
   for (int q = 0; q < S::CPT; ++q) {
     const int c = cg + S::TPR * q;
@@ -535,6 +779,7 @@ __global__ void __launch_bounds__(256, 1) k_sb_small_recon(int kb, const T* Ytop
     const T y = in ? (r > c ? a[q] : (r == c ? one_<T>() : zero_<T>())) : (r == c ? one_<T>() : zero_<T>());
     ps->Y1[r + B * c] = y;
     X[c][r] = conj_(y);
+    Rq[c][CQ * (r % 4) + r / 4] = conj_(y);
     Q[r][c] = in ? (r <= c ? a[q] : zero_<T>()) : (r == c ? one_<T>() : zero_<T>());
   }
   __syncthreads();
@@ -552,21 +797,27 @@ __global__ void __launch_bounds__(256, 1) k_sb_small_recon(int kb, const T* Ytop
 #pragma unroll
     for (int q = 0; q < S::CPT; ++q) ps->Rs[r + B * (cg + S::TPR * q)] = acc[q];
   }
-  // T Y1^H = -U S^-1: thread i < B solves row i of T against the unit upper triangular X = Y1^H (right-hand sides in Q, in place)
+  if (stamps && threadIdx.x == 0) stamps[6] = wall_clock64();
+  // T Y1^H = -U S^-1: a quad per row of T solves against the unit upper triangular Y1^H (Rq)
   __syncthreads();
-  for (int e = threadIdx.x; e < B * B; e += 256) {
-    const int i = e % B, c = e / B;
-    Q[i][c] = (i < kb && c < kb && c >= i) ? neg_(Q[i][c] * conj_(Sd[c])) : zero_<T>();
+  if (threadIdx.x < 4 * B) {
+    const int rr = threadIdx.x / 4, q4 = threadIdx.x % 4;
+    T x[CQ];
+#pragma unroll
+    for (int i = 0; i < CQ; ++i) {
+      const int c = q4 + 4 * i;
+      x[i] = (rr < kb && c < kb && c >= rr) ? neg_(Q[rr][c] * conj_(Sd[c])) : zero_<T>();
+    }
+    quad_row_solve_upper<T, B, true>(x, Rq, dinv, q4);
+#pragma unroll
+    for (int i = 0; i < CQ; ++i) {
+      const int c = q4 + 4 * i;
+      const T t = (rr < kb && c < kb && c >= rr) ? x[i] : zero_<T>();
+      ps->Tm[rr + B * c] = t;
+      if (c == rr && rr < kb) tau1[rr] = t;
+    }
   }
-  __syncthreads();
-  if (threadIdx.x < B) lds_row_solve_upper<T, B, true>(Q, threadIdx.x, X, dinv);
-  __syncthreads();
-  for (int e = threadIdx.x; e < B * B; e += 256) {
-    const int i = e % B, c = e / B;
-    const T t = (i < kb && c < kb && c >= i) ? Q[i][c] : zero_<T>();
-    ps->Tm[i + B * c] = t;
-    if (c == i && i < kb) tau1[i] = t;
-  }
+  if (stamps && threadIdx.x == 0) stamps[8] = wall_clock64();
 }
 
 // ---- finish: Y (explicit, m x kb) and Z = Y T into the panel buffers, Y's strictly-lower part into A below the band -----------------

@@ -281,19 +281,19 @@ static int sy2sb(nls_ctx* ctx, T* A, int n, long lda, T* tau1, int* dflag, int* 
     T* P = A + (long)(j + B) + (long)j * lda;
     const int nch = (m + RW - 1) / RW;
     hipLaunchKernelGGL((k_sb_gram<T, B>), dim3(nch), dim3(256), 0, st, P, lda, m, kb, Gp);
-    hipLaunchKernelGGL((k_sb_reduce<T>), red_grid, dim3(256), 0, st, Gp, nch, B * B, ps->G);
+    hipLaunchKernelGGL((k_sb_reduce<T>), red_grid, dim3(256), 0, st, Gp, nch, B * B, ps->G, nullptr);
     if (perturb) {  // second attempt after a degenerate panel (nls_sb.h, k_sb_perturb)
       hipLaunchKernelGGL((k_sb_perturb<T>), dim3((unsigned)(((long)m * kb + 255) / 256)), dim3(256), 0, st, P, lda, m, kb, ps->G, B, (unsigned)j);
       hipLaunchKernelGGL((k_sb_gram<T, B>), dim3(nch), dim3(256), 0, st, P, lda, m, kb, Gp);
-      hipLaunchKernelGGL((k_sb_reduce<T>), red_grid, dim3(256), 0, st, Gp, nch, B * B, ps->G);
+      hipLaunchKernelGGL((k_sb_reduce<T>), red_grid, dim3(256), 0, st, Gp, nch, B * B, ps->G, nullptr);
     }
     hipLaunchKernelGGL((k_sb_small_chol<T, B>), dim3(1), dim3(256), lds_chol, st, kb, m, 0, ps, dflag, adaptive);
     hipLaunchKernelGGL((k_sb_apply<T, B>), dim3(nch), dim3(256), lds_apply, st, P, lda, m, kb, ps, Yb + zh, (long)n, Gp, 0);
-    hipLaunchKernelGGL((k_sb_reduce<T>), red_grid, dim3(256), 0, st, Gp, nch, B * B, ps->G);
-    // (second pass: returns at once for a well-conditioned panel - the reduction then re-adds the first pass's partials, unchanged)
+    hipLaunchKernelGGL((k_sb_reduce<T>), red_grid, dim3(256), 0, st, Gp, nch, B * B, ps->G, nullptr);
+    // (second pass: its three kernels return at once for a well-conditioned panel - ps->G still holds the first pass's Gram matrix)
     hipLaunchKernelGGL((k_sb_small_chol<T, B>), dim3(1), dim3(256), lds_chol, st, kb, m, 1, ps, dflag, adaptive);
     hipLaunchKernelGGL((k_sb_apply<T, B>), dim3(nch), dim3(256), lds_apply, st, Yb + zh, (long)n, m, kb, ps, Yb + zh, (long)n, Gp, 1);
-    hipLaunchKernelGGL((k_sb_reduce<T>), red_grid, dim3(256), 0, st, Gp, nch, B * B, ps->G);
+    hipLaunchKernelGGL((k_sb_reduce<T>), red_grid, dim3(256), 0, st, Gp, nch, B * B, ps->G, &ps->skip2);
     hipLaunchKernelGGL((k_sb_small_recon<T, B>), dim3(1), dim3(256), lds_recon, st, kb, Yb + zh, (long)n, ps, P, lda, tau1 + j, dflag, j == 0 ? dstamps : nullptr);
     hipLaunchKernelGGL((k_sb_finish<T, B>), dim3(nch), dim3(256), lds_finish, st, Yb, (long)n, m, kb, ps, Zb, Zr, P, lda);
     HIPCHK(ctx, hipGetLastError());
@@ -303,7 +303,7 @@ static int sy2sb(nls_ctx* ctx, T* A, int n, long lda, T* tau1, int* dflag, int* 
     const int parts = std::max(1, std::min({parts_max, (NT + 1) / 2, (8 * ctx->cus + NT - 1) / NT}));
     hipLaunchKernelGGL((k_sb_hemm<T, B>), dim3(NT, (parts + HemmCfg<T, B>::PPW - 1) / HemmCfg<T, B>::PPW), dim3(256), 0, st, A22, lda, mh, Zr, kb, parts, Wp);
     hipLaunchKernelGGL((k_sb_hemm_reduce<T, B>), dim3(nrb), dim3(256), lds_reduce, st, Wp, parts, mh, kb, Zb, Wb, (long)n, Mp);
-    hipLaunchKernelGGL((k_sb_reduce<T>), red_grid, dim3(256), 0, st, Mp, nrb, B * B, ps->G);
+    hipLaunchKernelGGL((k_sb_reduce<T>), red_grid, dim3(256), 0, st, Mp, nrb, B * B, ps->G, nullptr);
     hipLaunchKernelGGL((k_sb_x<T, B>), dim3(nrb), dim3(256), lds_x, st, Wb, Yb, (long)n, mh, kb, ps);
     hipLaunchKernelGGL((k_sb_her2k<T, B>), dim3(NT * (NT + 1) / 2), dim3(256), lds_her2k, st, A22, lda, mh, Wb, Yb, (long)n, kb);
     HIPCHK(ctx, hipGetLastError());

@@ -112,9 +112,10 @@ __device__ __forceinline__ Z quad_perm(Z v) {
 }
 
 // out[e] = sum_p part[p * count + e] in a fixed order (bit-reproducible): the four lanes of a quad take the parts p = g, g + 4, ... of one
-// element (8 loads in flight each) and their sums are added as (s0 + s1) + (s2 + s3).  Grid: ceil(4 count / 256).
+// element (8 loads in flight each) and their sums are added as (s0 + s1) + (s2 + s3).  Grid: ceil(4 count / 256).  skip: optional device word.
 template <class T>
-__global__ void __launch_bounds__(256) k_sb_reduce(const T* part, int nparts, int count, T* out) {
+__global__ void __launch_bounds__(256) k_sb_reduce(const T* part, int nparts, int count, T* out, const int* skip) {
+  if (skip && *skip) return;  // (the partials of a skipped pass are the previous pass's: out already holds their sum)
   const int e = (blockIdx.x * 256 + threadIdx.x) / 4, g = threadIdx.x % 4;
   T s = zero_<T>();
   if (e < count) {  // uniform over a quad
@@ -527,14 +528,20 @@ __device__ __forceinline__ void small_chol_wave(int kb, int m, int pass, PanelSm
 #pragma unroll
       for (int r = 0; r < B; ++r) R[c][r] = (c < kb && r < kb) ? (r >= c ? a[r] : 0.0) : (r == c ? 1.0 : 0.0);
     }
-  } else {
-    for (int e = threadIdx.x - 64; e < B * B; e += 192) {
-      const int r = e % B, c = e / B;
-      Ra[r][c] = pass == 0 ? (r == c ? 1.0 : 0.0) : ps->Racc[e];
-    }
+  } else if (pass != 0) {
+    for (int e = threadIdx.x - 64; e < B * B; e += 192) Ra[e % B][e / B] = ps->Racc[e];
   }
   __syncthreads();
   const int r = threadIdx.x / S::TPR, cg = threadIdx.x % S::TPR;
+  if (pass == 0) {  // Racc = R
+#pragma unroll
+    for (int q = 0; q < S::CPT; ++q) {
+      const int c = cg + S::TPR * q;
+      ps->Racc[r + B * c] = R[r][c];
+      ps->Rs[r + B * c] = R[r][c];
+    }
+    return;
+  }
   double acc[S::CPT];
 #pragma unroll
   for (int q = 0; q < S::CPT; ++q) acc[q] = 0.0;
@@ -1049,23 +1056,41 @@ __global__ void __launch_bounds__(256) k_sb_hemm_reduce(const T* Wp, int split, 
   T(*Ws)[B + 1] = sb_carve<T, B + 1>(RC, off);
   T(*Zs)[B + 1] = sb_carve<T, B + 1>(RC, off);
   const int r0 = blockIdx.x * RC;
-  for (int idx = threadIdx.x; idx < RC * B; idx += 256) {
-    const int c = idx % B, r = idx / B;  // partials are row-major
-    T s = zero_<T>();
-    if (r0 + r < mh && c < kb) {
-      const T* wp = Wp + ((long)r0 + r) * B + c;
-      const long pstride = (long)mh * B;
-      int p = 0;
-      for (; p + 8 <= split; p += 8) {  // eight loads in flight, added in the fixed order
-        T v[8];
+  {
+    // partials are row-major: thread t adds up the elements (row t / B + (256 / B) u, column t % B), u < RC B / 256, of every partial in the fixed
+    // order p = 0, 1, ...; four partials x all its elements are in flight at a time
+    constexpr int NU = RC * B / 256, RSTEP = 256 / B;
+    const int c = threadIdx.x % B, rb = threadIdx.x / B;
+    const long pstride = (long)mh * B;
+    const T* wp = Wp + ((long)r0 + rb) * B + c;
+    T s[NU];
+    bool valid[NU];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = wp[(p + u) * pstride];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) s = s + v[u];
-      }
-      for (; p < split; ++p) s = s + wp[p * pstride];
+    for (int u = 0; u < NU; ++u) {
+      s[u] = zero_<T>();
+      valid[u] = r0 + rb + RSTEP * u < mh && c < kb;
     }
-    Ws[r][c] = s;
+    int p = 0;
+    for (; p + 4 <= split; p += 4) {
+      T v[4][NU];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int u = 0; u < NU; ++u) v[q][u] = valid[u] ? wp[(p + q) * pstride + (long)u * RSTEP * B] : zero_<T>();
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int u = 0; u < NU; ++u) s[u] = s[u] + v[q][u];
+    }
+    for (; p < split; ++p) {
+      T v[NU];
+#pragma unroll
+      for (int u = 0; u < NU; ++u) v[u] = valid[u] ? wp[p * pstride + (long)u * RSTEP * B] : zero_<T>();
+#pragma unroll
+      for (int u = 0; u < NU; ++u) s[u] = s[u] + v[u];
+    }
+#pragma unroll
+    for (int u = 0; u < NU; ++u) Ws[rb + RSTEP * u][c] = s[u];
   }
   for (int idx = threadIdx.x; idx < RC * B; idx += 256) {
     const int r = idx % RC, c = idx / RC;

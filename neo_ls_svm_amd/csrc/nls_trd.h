@@ -97,7 +97,28 @@ __device__ __forceinline__ Larfg<T> larfg(T alpha, double xnorm2) {
     return h;
   }
   h.identity = false;
-  const double nrm = sqrt(ar * ar + ai * ai + xnorm2);
+  const double s2 = ar * ar + ai * ai + xnorm2;
+  if (s2 > 1e-280 && s2 < 1e280) {
+    // The reflector's scalars sit on the critical path of every column (one-stage) / stage (bulge chase): v_rsq_f64 / v_rcp_f64 with Newton
+    // steps (results within an ulp or two) instead of the IEEE sqrt and two divisions - a third of the dependent instructions.
+    const double y0 = __builtin_amdgcn_rsq(s2);
+    const double e0 = fma(-(s2 * y0), y0, 1.0);
+    const double y = fma(y0 * e0, fma(0.375, e0, 0.5), y0);  // 1 / sqrt(s2)
+    const double nrm = s2 * y;
+    h.beta = ar >= 0.0 ? -nrm : nrm;
+    const double ib = ar >= 0.0 ? -y : y;  // 1 / beta
+    h.tau = make_<T>((h.beta - ar) * ib, -ai * ib);
+    // 1 / (alpha - beta): |alpha - beta| >= |beta|, no cancellation (beta has the opposite sign of Re alpha)
+    const double dr = ar - h.beta, d2 = dr * dr + ai * ai;
+    double z = __builtin_amdgcn_rcp(d2);
+    double ez = fma(-d2, z, 1.0);
+    z = fma(z, ez, z);
+    ez = fma(-d2, z, 1.0);
+    z = fma(z, ez, z);
+    h.scale = make_<T>(dr * z, -ai * z);
+    return h;
+  }
+  const double nrm = sqrt(s2);
   h.beta = ar >= 0.0 ? -nrm : nrm;
   h.tau = make_<T>((h.beta - ar) / h.beta, -ai / h.beta);
   h.scale = inv_(alpha - make_<T>(h.beta, 0.0));

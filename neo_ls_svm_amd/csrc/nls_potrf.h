@@ -253,17 +253,30 @@ __global__ void __launch_bounds__(Cfg4::NTHREADS, 2) k_potrf_syrk(double* A, lon
   KMajorLoader<C4::NTHREADS, BM> la{Lp, ldl, (long)C * BM};
   KMajorLoader<C4::NTHREADS, BN> lb{Lp, ldl, (long)R * BN};
   mainloop_real<C4, true>(acc, la, lb, 0, ktiles, smem);
+  // read-modify-write of the tile: the 16 entries of an accumulator row block are LOADED together, then stored (written as A[..] -= acc the
+  // compiler must assume a store may feed the next load - the same array - and every entry pays its own memory round trip: 64 in a row)
 #pragma unroll
-  for (int mt = 0; mt < C4::MT; ++mt)
+  for (int mt = 0; mt < C4::MT; ++mt) {
+    double old[4][C4::NTL];
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
       const long cc = (long)C * BM + C4::acc_row(mt, reg);
 #pragma unroll
       for (int nt = 0; nt < C4::NTL; ++nt) {
         const long r = (long)R * BN + C4::acc_col(nt);
-        if (r < m && cc < m && r >= cc) A[r + cc * lda] -= acc[mt][nt][reg];
+        old[reg][nt] = (r < m && cc < m && r >= cc) ? A[r + cc * lda] : 0.0;
       }
     }
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const long cc = (long)C * BM + C4::acc_row(mt, reg);
+#pragma unroll
+      for (int nt = 0; nt < C4::NTL; ++nt) {
+        const long r = (long)R * BN + C4::acc_col(nt);
+        if (r < m && cc < m && r >= cc) A[r + cc * lda] = old[reg][nt] - acc[mt][nt][reg];
+      }
+    }
+  }
 }
 
 }  // namespace potrf

@@ -1157,16 +1157,12 @@ __global__ void __launch_bounds__(256) k_sb_x(T* Wb, const T* Yb, long ld, int m
 #pragma unroll
     for (int c = 0; c < CQ; ++c) acc[c] = acc[c] + a * Ms[t][q4 + 4 * c];
   }
-  if (r0 + r < mh) {
+  T wold[CQ];  // (loaded together, then stored: see her2k_tile)
 #pragma unroll
-    for (int c = 0; c < CQ; ++c) {
-      const int col = q4 + 4 * c;
-      if (col < kb) {
-        const long o = (long)(r0 + r) + (long)col * ld;
-        Wb[o] = Wb[o] - 0.5 * acc[c];
-      }
-    }
-  }
+  for (int c = 0; c < CQ; ++c) wold[c] = (r0 + r < mh && q4 + 4 * c < kb) ? Wb[(long)(r0 + r) + (long)(q4 + 4 * c) * ld] : zero_<T>();
+#pragma unroll
+  for (int c = 0; c < CQ; ++c)
+    if (r0 + r < mh && q4 + 4 * c < kb) Wb[(long)(r0 + r) + (long)(q4 + 4 * c) * ld] = wold[c] - 0.5 * acc[c];
 }
 
 // A22 -= X Y^H + Y X^H on the lower triangle, 64 x 64 tiles R >= C, on v_mfma_f64_16x16x4_f64.  The product is formed TRANSPOSED,
@@ -1234,6 +1230,18 @@ __device__ __forceinline__ void her2k_tile(T* A, long lda, int mh, const T* Xb, 
     }
   }
   // D[i][j]: lane = 16 (i % 4) + j, reg = i / 4:  column c0 + 16 w + 4 reg + lane / 16, row r0 + 16 jt + lane % 16
+  // (the tile's 16 entries per lane are loaded TOGETHER and then stored: entry by entry, every read-modify-write is its own memory round
+  // trip - the compiler keeps a store to A ahead of the next load from A)
+  T old[4][4];
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    const long cc = c0 + 16 * w + 4 * reg + kk;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+      const long r = r0 + 16 * jt + x;
+      old[reg][jt] = ((FULL || (r < mh && cc < mh)) && (!diag || r >= cc)) ? A[r + cc * lda] : zero_<T>();
+    }
+  }
 #pragma unroll
   for (int reg = 0; reg < 4; ++reg) {
     const long cc = c0 + 16 * w + 4 * reg + kk;
@@ -1242,7 +1250,7 @@ __device__ __forceinline__ void her2k_tile(T* A, long lda, int mh, const T* Xb, 
       const long r = r0 + 16 * jt + x;
       if ((FULL || (r < mh && cc < mh)) && (!diag || r >= cc)) {
         // D holds sum_k conj(P[cc][k]) Q[r][k] = (X Y^H + Y X^H)[r][cc]
-        T v = A[r + cc * lda] - make_<T>(acc[0][jt][reg], CX ? acc[1][jt][reg] : 0.0);
+        T v = old[reg][jt] - make_<T>(acc[0][jt][reg], CX ? acc[1][jt][reg] : 0.0);
         if (r == cc) v = make_<T>(real_(v), 0.0);
         A[r + cc * lda] = v;
       }

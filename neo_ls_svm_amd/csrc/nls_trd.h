@@ -808,13 +808,21 @@ __device__ __forceinline__ void trd_rank2k_body(T* A, long lda, const T* W, long
         for (int y = 0; y < 4; ++y) acc[x][y] = acc[x][y] + vr[x] * wc[y] + wr[x] * vc[y];
     }
   }
+  T old[4][4];  // (the 16 entries are loaded together, then stored: entry by entry every read-modify-write is its own memory round trip)
+#pragma unroll
+  for (int y = 0; y < 4; ++y)
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      const long r = r0 + tx + 16 * x, c = c0 + ty + 16 * y;
+      old[y][x] = (r < n && c < n && r >= c) ? A[r + c * lda] : make_<T>(0.0, 0.0);
+    }
 #pragma unroll
   for (int y = 0; y < 4; ++y)
 #pragma unroll
     for (int x = 0; x < 4; ++x) {
       const long r = r0 + tx + 16 * x, c = c0 + ty + 16 * y;
       if (r < n && c < n && r >= c) {
-        T v = A[r + c * lda] - acc[x][y];
+        T v = old[y][x] - acc[x][y];
         if (r == c) v = make_<T>(real_(v), 0.0);
         A[r + c * lda] = v;
       }

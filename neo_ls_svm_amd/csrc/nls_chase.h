@@ -90,27 +90,7 @@ struct ChaseLds {
   int pre_ok;
 };
 
-// Cross-lane sums on the DPP path (quad_perm / row_half_mirror / row_mirror inside a row of 16 lanes, v_readlane across rows): a
-// __shfl_xor goes through ds_bpermute (an LDS round trip per step and 32-bit half), which made the reductions half of a stage.
-template <int CTRL>
-__device__ __forceinline__ double dpp_mov(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
-  return __hiloint2double(hi, lo);
-}
-template <int CTRL>
-__device__ __forceinline__ Z dpp_mov(Z v) {
-  return {dpp_mov<CTRL>(v.re), dpp_mov<CTRL>(v.im)};
-}
-// sum over the 16 lanes of a DPP row, the same value in all of them
-template <class T>
-__device__ __forceinline__ T row16_sum(T v) {
-  v = v + dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]: lane ^ 1
-  v = v + dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]: lane ^ 2
-  v = v + dpp_mov<0x141>(v);  // row_half_mirror: the other quad of the 8
-  v = v + dpp_mov<0x140>(v);  // row_mirror: the other half of the 16
-  return v;
-}
+// (cross-lane sums on DPP: dpp_mov, row16_sum, wave_sum_dpp of nls_trd.h)
 template <int TPRV, class T>
 __device__ __forceinline__ T row_group_sum(T v) {  // sum over TPRV (4 or 8) adjacent lanes, the same value in all of them
   v = v + dpp_mov<0xB1>(v);
@@ -118,11 +98,6 @@ __device__ __forceinline__ T row_group_sum(T v) {  // sum over TPRV (4 or 8) adj
   if (TPRV == 8) v = v + dpp_mov<0x141>(v);
   return v;
 }
-__device__ __forceinline__ double wave_sum_dpp(double v) {
-  v = row16_sum(v);
-  return lane_bcast(v, 0) + lane_bcast(v, 16) + lane_bcast(v, 32) + lane_bcast(v, 48);
-}
-__device__ __forceinline__ Z wave_sum_dpp(Z v) { return {wave_sum_dpp(v.re), wave_sum_dpp(v.im)}; }
 
 // wait until done[sp] >= need (one lane polls; everybody leaves together).  Returns false on timeout / abort.
 __device__ __forceinline__ bool chase_wait(const unsigned* done, int sp, unsigned need, unsigned* ctl, int* abort_slot) {

@@ -60,11 +60,36 @@ __device__ __forceinline__ double lane_bcast(double v, int src) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
 }
 __device__ __forceinline__ Z lane_bcast(Z v, int src) { return {lane_bcast(v.re, src), lane_bcast(v.im, src)}; }
+// Cross-lane sums on the DPP path (quad_perm / row_half_mirror / row_mirror inside a row of 16 lanes, v_readlane across rows): a
+// __shfl_xor goes through ds_bpermute (an LDS round trip per step and 32-bit half).  Whole rows of 16 lanes must be active.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ Z dpp_mov(Z v) {
+  return {dpp_mov<CTRL>(v.re), dpp_mov<CTRL>(v.im)};
+}
+// sum over the 16 lanes of a DPP row, the same value in all of them
+template <class T>
+__device__ __forceinline__ T row16_sum(T v) {
+  v = v + dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]: lane ^ 1
+  v = v + dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]: lane ^ 2
+  v = v + dpp_mov<0x141>(v);  // row_half_mirror: the other quad of the 8
+  v = v + dpp_mov<0x140>(v);  // row_mirror: the other half of the 16
+  return v;
+}
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+  v = row16_sum(v);
+  return lane_bcast(v, 0) + lane_bcast(v, 16) + lane_bcast(v, 32) + lane_bcast(v, 48);
+}
+__device__ __forceinline__ Z wave_sum_dpp(Z v) { return {wave_sum_dpp(v.re), wave_sum_dpp(v.im)}; }
+// sum over the wave, the same value in every lane (round 5: on DPP; the whole wave must be active)
 template <class T>
 __device__ __forceinline__ T wave_sum(T v) {
-#pragma unroll
-  for (int m = 32; m > 0; m >>= 1) v = v + shfl_xor_(v, m);
-  return v;
+  return wave_sum_dpp(v);
 }
 
 constexpr int NB = 32;    // panel width
@@ -73,9 +98,8 @@ constexpr int TPR = 16;   // threads per row in the row kernels (they split the 
 constexpr int ROWT = 16;  // rows per block of the row kernels (256 threads)
 template <class T>
 __device__ __forceinline__ T row_sum(T v) {  // sum over the TPR consecutive lanes of one row, same value in all of them
-#pragma unroll
-  for (int m = 1; m < TPR; m <<= 1) v = v + shfl_xor_(v, m);
-  return v;
+  static_assert(TPR == 16, "a row of the row kernels is a DPP row");
+  return row16_sum(v);
 }
 
 // larfg scalars from alpha = x[j+1] and xnorm^2 = |x[j+2:]|^2  (zlarfg / dlarfg)

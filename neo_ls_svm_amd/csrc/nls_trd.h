@@ -292,21 +292,48 @@ constexpr int GW = 8;         // columns per butterfly group (8 keeps the kernel
 // Column sums of v[0..8) over the 64 lanes by halving: after the step with mask m a lane keeps half of its values
 // (which half: its bit m) summed with its partner's - 7 exchanges, then 3 plain steps, instead of 8 x 6.
 // Result for column 4 b5 + 2 b4 + b3 (bits of the lane index) in v[0] of the lanes with (lane & 7) == 0.
+// The exchanges stay on the vector ALU (round 5; a __shfl_xor is two ds_bpermute round trips per double): v_permlane32_swap / v_permlane16_swap
+// (gfx950) across the rows of 16 lanes, DPP inside a row.  xchg<M>(v): the value of the lane's partner - lane ^ M for M = 32, 16, 8, 2, 1; for
+// M = 4 the partner is lane ^ 7 (row_half_mirror), which serves a plain sum over groups of 8 just as well.
+template <int M>
+__device__ __forceinline__ unsigned xchg32(unsigned x, int lane) {
+  if constexpr (M == 32) {
+    const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);  // r[0]: the lower half's values in both halves, r[1]: the upper's
+    return (lane & 32) ? r[0] : r[1];
+  } else if constexpr (M == 16) {
+    const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);  // r[0]: the even rows' values in both rows of a pair, r[1]: the odd rows'
+    return (lane & 16) ? r[0] : r[1];
+  } else {
+    constexpr int CTRL = M == 8 ? 0x128 /* row_ror:8 */ : (M == 4 ? 0x141 /* row_half_mirror */ : (M == 2 ? 0x4E : 0xB1));
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xf, 0xf, false);
+  }
+}
+template <int M>
+__device__ __forceinline__ double xchg(double v, int lane) {
+  return __hiloint2double((int)xchg32<M>((unsigned)__double2hiint(v), lane), (int)xchg32<M>((unsigned)__double2loint(v), lane));
+}
+template <int M>
+__device__ __forceinline__ Z xchg(Z v, int lane) {
+  return {xchg<M>(v.re, lane), xchg<M>(v.im, lane)};
+}
+template <int H, int M, class T>
+__device__ __forceinline__ void butterfly_level(T (&v)[GW], int lane) {
+  const bool hi = lane & M;
+#pragma unroll
+  for (int k = 0; k < H; ++k) {
+    const T send = sel_(hi, v[k], v[k + H]);
+    const T keep = sel_(hi, v[k + H], v[k]);
+    v[k] = keep + xchg<M>(send, lane);
+  }
+}
 template <class T>
 __device__ __forceinline__ void butterfly8(T (&v)[GW], int lane) {
-#pragma unroll
-  for (int h = 4, m = 32; h >= 1; h >>= 1, m >>= 1) {
-    const bool hi = lane & m;
-#pragma unroll
-    for (int k = 0; k < h; ++k) {
-      const T send = sel_(hi, v[k], v[k + h]);
-      const T keep = sel_(hi, v[k + h], v[k]);
-      v[k] = keep + shfl_xor_(send, m);
-    }
-  }
-  v[0] = v[0] + shfl_xor_(v[0], 4);
-  v[0] = v[0] + shfl_xor_(v[0], 2);
-  v[0] = v[0] + shfl_xor_(v[0], 1);
+  butterfly_level<4, 32>(v, lane);
+  butterfly_level<2, 16>(v, lane);
+  butterfly_level<1, 8>(v, lane);
+  v[0] = v[0] + xchg<4>(v[0], lane);
+  v[0] = v[0] + xchg<2>(v[0], lane);
+  v[0] = v[0] + xchg<1>(v[0], lane);
 }
 __device__ __forceinline__ int butterfly_col(int lane) { return ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1); }
 

@@ -42,9 +42,19 @@ __global__ void __launch_bounds__(256) k_potrf_leaf(double* A, long lda, int w, 
   double(*Ls)[LDL] = reinterpret_cast<double(*)[LDL]>(potrf_smem);  // Ls[r][c], lower part valid
   __shared__ double dinv[NB];                                       // 1 / L[k][k]: the solves multiply
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int idx = tid; idx < NB * NB; idx += 256) {
-    const int r = idx % NB, c = idx / NB;
-    Ls[r][c] = (r < w && c < w && r >= c) ? A[r + (long)c * lda] : (r == c ? 1.0 : 0.0);
+  // (sixteen entries per thread requested together: a load and an LDS store per loop trip is one memory round trip per trip, 64 in a row)
+  for (int i0 = 0; i0 < NB * NB / 256; i0 += 16) {
+    double bv[16];
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int idx = tid + 256 * (i0 + it), r = idx % NB, c = idx / NB;
+      bv[it] = (r < w && c < w && r >= c) ? A[r + (long)c * lda] : (r == c ? 1.0 : 0.0);
+    }
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int idx = tid + 256 * (i0 + it);
+      Ls[idx % NB][idx / NB] = bv[it];
+    }
   }
   __syncthreads();
   for (int kb = 0; kb < NB; kb += SBK) {
@@ -63,7 +73,7 @@ __global__ void __launch_bounds__(256) k_potrf_leaf(double* A, long lda, int w, 
           if (bad == 0) bad = kb + k + 1;
           d = 1.0;
         }
-        const double sq = sqrt(d), inv = 1.0 / sq;
+        const double inv = sb::fast_rsqrt(d), sq = d * inv;  // (v_rsq_f64 + a Newton step instead of sqrt and a division on the critical path)
         if (lane == 0) dinv[kb + k] = inv;
         const double l = r == k ? sq : a[k] * inv;
         a[k] = l;

@@ -70,6 +70,25 @@ __device__ __forceinline__ bool finite_(double a) { return isfinite(a); }
 // columns cg + TPR q) with ONE barrier per elimination step (the pivot column / row travels through a double-buffered
 // LDS vector).  No explicit inverses: Q = P R^-1 is a row-wise back substitution with R in LDS (uniform reads).
 // ================================================================================================================
+// Cooperative copy of COUNT items by the 256 threads of a workgroup (item e = threadIdx.x + 256 it): ALL of a thread's loads are issued
+// before its first store.  Written as `for (e = threadIdx.x; e < COUNT; e += 256) dst(e) = src(e)` the loop is not unrolled (its trip count
+// hangs on threadIdx.x) and every iteration pays its own memory round trip - 4 to 8 in a row at the head of every small kernel of a panel.
+template <int COUNT, class LOAD, class STORE>
+__device__ __forceinline__ void block_copy(LOAD&& load, STORE&& store) {
+  constexpr int NIT = (COUNT + 255) / 256;
+  decltype(load(0)) v[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int e = (int)threadIdx.x + 256 * it;
+    if (COUNT % 256 == 0 || e < COUNT) v[it] = load(e);
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int e = (int)threadIdx.x + 256 * it;
+    if (COUNT % 256 == 0 || e < COUNT) store(e, v[it]);
+  }
+}
+
 constexpr int RW = 64;  // rows per workgroup of the panel kernels: FOUR threads per row (thread t: row t / 4, columns t % 4 + 4 i)
 
 template <int B>
@@ -177,10 +196,8 @@ __global__ void __launch_bounds__(256) k_sb_gram(const T* P, long ldp, int m, in
     const int r0 = blockIdx.x * RW + sub * 64;
     if (r0 >= m) break;  // uniform
     __syncthreads();
-    for (int idx = threadIdx.x; idx < 64 * B; idx += 256) {
-      const int r = idx % 64, c = idx / 64;
-      Ps[r][c] = (r0 + r < m && c < kb) ? P[(long)(r0 + r) + (long)c * ldp] : zero_<T>();
-    }
+    block_copy<64 * B>([&](int idx) { return (r0 + idx % 64 < m && idx / 64 < kb) ? P[(long)(r0 + idx % 64) + (long)(idx / 64) * ldp] : zero_<T>(); },
+                       [&](int idx, T v) { Ps[idx % 64][idx / 64] = v; });
     __syncthreads();
     gram_tile_accumulate<T, B>(Ps, acc);
   }
@@ -266,10 +283,7 @@ __device__ __attribute__((noinline)) void lds_row_solve_upper(T (*X)[B + 1], int
 template <class T, int B>
 __device__ __forceinline__ void load_rq(T (*Rq)[B], const T* R /* R[r][c] at r + B c */) {
   constexpr int CQ = B / 4;
-  for (int e = threadIdx.x; e < B * B; e += 256) {
-    const int r = e % B, c = e / B;
-    Rq[r][CQ * (c % 4) + c / 4] = R[e];
-  }
+  block_copy<B * B>([&](int e) { return R[e]; }, [&](int e, T v) { Rq[e % B][CQ * ((e / B) % 4) + (e / B) / 4] = v; });
 }
 template <class T, int B, bool UNIT>
 __device__ __forceinline__ void quad_row_solve_upper(T (&x)[B / 4], T (*Rq)[B], const T* dinv, int q4) {
@@ -840,7 +854,7 @@ __global__ void __launch_bounds__(256) k_sb_finish(T* Yb, long ldy, int m, int k
   __shared__ T dinv[B];
   const int zh = B - kb;
   load_rq<T, B>(Mq, ps->Rs);
-  for (int e = threadIdx.x; e < B * B; e += 256) Ts[e % B][e / B] = ps->Tm[e];
+  block_copy<B * B>([&](int e) { return ps->Tm[e]; }, [&](int e, T v) { Ts[e % B][e / B] = v; });
   if (threadIdx.x < B) dinv[threadIdx.x] = inv_(ps->Rs[threadIdx.x + B * threadIdx.x]);
   const int rr = threadIdx.x / 4, q4 = threadIdx.x % 4;
   const long row = (long)blockIdx.x * RW + rr;
@@ -1092,10 +1106,8 @@ __global__ void __launch_bounds__(256) k_sb_hemm_reduce(const T* Wp, int split, 
 #pragma unroll
     for (int u = 0; u < NU; ++u) Ws[rb + RSTEP * u][c] = s[u];
   }
-  for (int idx = threadIdx.x; idx < RC * B; idx += 256) {
-    const int r = idx % RC, c = idx / RC;
-    Zs[r][c] = (r0 + r < mh && c < kb) ? Zb[(long)(r0 + r) + (long)c * ld] : zero_<T>();
-  }
+  block_copy<RC * B>([&](int idx) { return (r0 + idx % RC < mh && idx / RC < kb) ? Zb[(long)(r0 + idx % RC) + (long)(idx / RC) * ld] : zero_<T>(); },
+                     [&](int idx, T v) { Zs[idx % RC][idx / RC] = v; });
   __syncthreads();
   for (int idx = threadIdx.x; idx < RC * B; idx += 256) {
     const int r = idx % RC, c = idx / RC;
@@ -1134,17 +1146,17 @@ __global__ void __launch_bounds__(256) k_sb_x(T* Wb, const T* Yb, long ld, int m
   T(*Ys)[B + 1] = sb_carve<T, B + 1>(RC, off);
   T(*Ms)[B + 1] = sb_carve<T, B + 1>(B, off);
   const int r0 = blockIdx.x * RC;
-  for (int idx = threadIdx.x; idx < RC * B; idx += 256) {
-    const int r = idx % RC, c = idx / RC;
-    Ys[r][c] = (r0 + r < mh && c < kb) ? Yb[(long)(r0 + r) + (long)c * ld] : zero_<T>();
-  }
+  block_copy<RC * B>([&](int idx) { return (r0 + idx % RC < mh && idx / RC < kb) ? Yb[(long)(r0 + idx % RC) + (long)(idx / RC) * ld] : zero_<T>(); },
+                     [&](int idx, T v) { Ys[idx % RC][idx / RC] = v; });
   // M = Z^H A22 Z is Hermitian; the reduced sum (ps->G) is symmetrised here (rounding makes its two triangles differ in the last bit)
-  for (int e = threadIdx.x; e < B * B; e += 256) {
-    const int i = e % B, j = e / B;
-    T v = 0.5 * (ps->G[i + B * j] + conj_(ps->G[j + B * i]));
-    if (i == j) v = make_<T>(real_(v), 0.0);
-    Ms[i][j] = v;
-  }
+  block_copy<B * B>(
+      [&](int e) {
+        const int i = e % B, j = e / B;
+        T v = 0.5 * (ps->G[i + B * j] + conj_(ps->G[j + B * i]));
+        if (i == j) v = make_<T>(real_(v), 0.0);
+        return v;
+      },
+      [&](int e, T v) { Ms[e % B][e / B] = v; });
   __syncthreads();
   constexpr int CQ = B / 4;
   const int r = threadIdx.x / 4, q4 = threadIdx.x % 4;
@@ -1183,12 +1195,10 @@ __device__ __forceinline__ void her2k_tile(T* A, long lda, int mh, const T* Xb, 
   constexpr int KS = B / 4;
   T(*Xs)[H2LD] = reinterpret_cast<T(*)[H2LD]>(sb_smem);
   T(*Ys)[H2LD] = Xs + B;
-  for (int idx = threadIdx.x; idx < B * 64; idx += 256) {
-    const int row = idx % 64, k = idx / 64;
-    const bool in = k < kb && (FULL || r0 + row < mh);
-    Xs[k][row] = in ? Xb[r0 + row + (long)k * ld] : zero_<T>();
-    Ys[k][row] = in ? Yb[r0 + row + (long)k * ld] : zero_<T>();
-  }
+  block_copy<B * 64>([&](int idx) { return (idx / 64 < kb && (FULL || r0 + idx % 64 < mh)) ? Xb[r0 + idx % 64 + (long)(idx / 64) * ld] : zero_<T>(); },
+                     [&](int idx, T v) { Xs[idx / 64][idx % 64] = v; });
+  block_copy<B * 64>([&](int idx) { return (idx / 64 < kb && (FULL || r0 + idx % 64 < mh)) ? Yb[r0 + idx % 64 + (long)(idx / 64) * ld] : zero_<T>(); },
+                     [&](int idx, T v) { Ys[idx / 64][idx % 64] = v; });
   const int x = lane & 15, kk = lane >> 4;
   const long c = c0 + 16 * w + x;  // A operand: column c of the tile
   T a[2][KS];

@@ -25,13 +25,36 @@ __global__ void __launch_bounds__(256) k_trsv_fwd_block(const double* __restrict
   for (int p = 0; p < np; ++p) {
     const int k0 = K0 + p * PB, w = min(PB, K0 + W - k0);
     // row k0 + c of the panel: sum over the block's earlier columns t in [K0, k0)
+    // (four products in flight per thread, the block's entries requested together: one load per loop trip is one memory round trip per trip)
     double s = 0.0;
-    if (c < w)
-      for (int t = K0 + g; t < k0; t += 8) s += L[(long)(k0 + c) + (long)t * ldl] * y[t];
+    if (c < w) {
+      double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      int t = K0 + g;
+      for (; t + 24 < k0; t += 32) {
+        const double l0 = L[(long)(k0 + c) + (long)t * ldl], l1 = L[(long)(k0 + c) + (long)(t + 8) * ldl];
+        const double l2 = L[(long)(k0 + c) + (long)(t + 16) * ldl], l3 = L[(long)(k0 + c) + (long)(t + 24) * ldl];
+        const double y0 = y[t], y1 = y[t + 8], y2 = y[t + 16], y3 = y[t + 24];
+        s += l0 * y0;
+        s1 += l1 * y1;
+        s2 += l2 * y2;
+        s3 += l3 * y3;
+      }
+      for (; t < k0; t += 8) s += L[(long)(k0 + c) + (long)t * ldl] * y[t];
+      s = (s + s1) + (s2 + s3);
+    }
     part[g][c] = s;
-    for (int idx = tid; idx < PB * PB; idx += 256) {
-      const int rr = idx % PB, cc = idx / PB;
-      blk[rr][cc] = (rr < w && cc < w && rr >= cc) ? L[(long)(k0 + rr) + (long)(k0 + cc) * ldl] : (rr == cc ? 1.0 : 0.0);
+    {
+      double bv[PB * PB / 256];
+#pragma unroll
+      for (int it = 0; it < PB * PB / 256; ++it) {
+        const int idx = tid + 256 * it, rr = idx % PB, cc = idx / PB;
+        bv[it] = (rr < w && cc < w && rr >= cc) ? L[(long)(k0 + rr) + (long)(k0 + cc) * ldl] : (rr == cc ? 1.0 : 0.0);
+      }
+#pragma unroll
+      for (int it = 0; it < PB * PB / 256; ++it) {
+        const int idx = tid + 256 * it;
+        blk[idx % PB][idx / PB] = bv[it];
+      }
     }
     __syncthreads();
     if (tid < 64) {
@@ -40,8 +63,9 @@ __global__ void __launch_bounds__(256) k_trsv_fwd_block(const double* __restrict
         acc = y[k0 + c];
         for (int q = 0; q < 8; ++q) acc -= part[q][c];
       }
+      const double rd = 1.0 / blk[tid & (PB - 1)][tid & (PB - 1)];  // (one division per unknown, all at once, instead of one per step of the chain)
       for (int t = 0; t < PB; ++t) {
-        if (tid == t) sol[t] = acc / blk[t][t];
+        if (tid == t) sol[t] = acc * rd;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (tid > t && tid < PB) acc -= blk[tid][t] * sol[t];
@@ -72,7 +96,21 @@ __global__ void __launch_bounds__(256) k_trsv_bwd_outer_sum(const double* __rest
   __shared__ double red[4];
   const int c = K0 + blockIdx.x;
   double s = 0.0;
-  for (int r = K0 + W + threadIdx.x; r < n; r += 256) s += L[(long)r + (long)c * ldl] * y[r];
+  {
+    const double* col = L + (long)c * ldl;
+    double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int r = K0 + W + threadIdx.x;
+    for (; r + 768 < n; r += 1024) {  // four products in flight per thread
+      const double l0 = col[r], l1 = col[r + 256], l2 = col[r + 512], l3 = col[r + 768];
+      const double y0 = y[r], y1 = y[r + 256], y2 = y[r + 512], y3 = y[r + 768];
+      s += l0 * y0;
+      s1 += l1 * y1;
+      s2 += l2 * y2;
+      s3 += l3 * y3;
+    }
+    for (; r < n; r += 256) s += col[r] * y[r];
+    s = (s + s1) + (s2 + s3);
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
@@ -91,12 +129,34 @@ __global__ void __launch_bounds__(256) k_trsv_bwd_block(const double* __restrict
   for (int p = np - 1; p >= 0; --p) {
     const int k0 = K0 + p * PB, w = min(PB, bend - k0), rend = k0 + w;
     double s = 0.0;
-    if (c < w)
-      for (int r = rend + g; r < bend; r += 8) s += L[(long)r + (long)(k0 + c) * ldl] * y[r];
+    if (c < w) {
+      double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      int r = rend + g;
+      for (; r + 24 < bend; r += 32) {
+        const double* col = L + (long)(k0 + c) * ldl;
+        const double l0 = col[r], l1 = col[r + 8], l2 = col[r + 16], l3 = col[r + 24];
+        const double y0 = y[r], y1 = y[r + 8], y2 = y[r + 16], y3 = y[r + 24];
+        s += l0 * y0;
+        s1 += l1 * y1;
+        s2 += l2 * y2;
+        s3 += l3 * y3;
+      }
+      for (; r < bend; r += 8) s += L[(long)r + (long)(k0 + c) * ldl] * y[r];
+      s = (s + s1) + (s2 + s3);
+    }
     part[g][c] = s;
-    for (int idx = tid; idx < PB * PB; idx += 256) {
-      const int rr = idx % PB, cc = idx / PB;
-      blk[rr][cc] = (rr < w && cc < w && rr >= cc) ? L[(long)(k0 + rr) + (long)(k0 + cc) * ldl] : (rr == cc ? 1.0 : 0.0);
+    {
+      double bv[PB * PB / 256];
+#pragma unroll
+      for (int it = 0; it < PB * PB / 256; ++it) {
+        const int idx = tid + 256 * it, rr = idx % PB, cc = idx / PB;
+        bv[it] = (rr < w && cc < w && rr >= cc) ? L[(long)(k0 + rr) + (long)(k0 + cc) * ldl] : (rr == cc ? 1.0 : 0.0);
+      }
+#pragma unroll
+      for (int it = 0; it < PB * PB / 256; ++it) {
+        const int idx = tid + 256 * it;
+        blk[idx % PB][idx / PB] = bv[it];
+      }
     }
     __syncthreads();
     if (tid < 64) {
@@ -106,8 +166,9 @@ __global__ void __launch_bounds__(256) k_trsv_bwd_block(const double* __restrict
         if (sums) acc -= sums[k0 - K0 + c];
         for (int q = 0; q < 8; ++q) acc -= part[q][c];
       }
+      const double rd = 1.0 / blk[tid & (PB - 1)][tid & (PB - 1)];
       for (int t = PB - 1; t >= 0; --t) {
-        if (tid == t) sol[t] = acc / blk[t][t];
+        if (tid == t) sol[t] = acc * rd;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (tid < t) acc -= blk[t][tid] * sol[t];

@@ -66,15 +66,36 @@ __global__ void __launch_bounds__(ZP_THREADS) k_zpotrf_panel(double2* __restrict
   const bool st = stamps != nullptr && blockIdx.x == 0;
   if (st && ftid == 0) stamps[0] = wall_clock64();
   // ---- this thread's row of the panel: loads in flight while the block is factored ----
-  if (rowthr)
-    for (int c = 0; c < NBZ; ++c) xs[c][tid] = (live && c < w) ? A21[r + (long)c * lda] : make_double2(0.0, 0.0);
+  // (sixteen columns are requested together and then stored: written as one predicated load and LDS store per column the loop is compiled into
+  // load - wait - store, 32 dependent memory round trips: the 10 us this prologue took in the round-5 time line)
+  if (rowthr) {
+#pragma unroll
+    for (int c0 = 0; c0 < NBZ; c0 += 16) {
+      double2 xr[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) xr[c] = (live && c0 + c < w) ? A21[r + (long)(c0 + c) * lda] : make_double2(0.0, 0.0);
+#pragma unroll
+      for (int c = 0; c < 16; ++c) xs[c0 + c][tid] = xr[c];
+    }
+  }
   // ---- the diagonal block (rows / columns k0 .. k0 + w of A), identity-padded to 32 x 32 ----
-  for (int idx = ftid; idx < NBZ * NBZ; idx += ZP_THREADS) {
-    const int rr = idx % NBZ, c = idx / NBZ;
-    double2 v = make_double2(rr == c ? 1.0 : 0.0, 0.0);
-    if (rr < w && c < w && rr >= c) v = A[rr + (long)c * lda];
-    Lr[rr][c] = v.x;
-    Li[rr][c] = rr == c ? 0.0 : v.y;  // the diagonal of a Hermitian matrix is real (LAPACK ignores its imaginary part too)
+  {
+    constexpr int NIT = (NBZ * NBZ + ZP_THREADS - 1) / ZP_THREADS;
+    double2 dv4[NIT];  // (all of a thread's entries requested together, then stored)
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = ftid + it * ZP_THREADS, rr = idx % NBZ, c = idx / NBZ;
+      dv4[it] = make_double2(rr == c ? 1.0 : 0.0, 0.0);
+      if (idx < NBZ * NBZ && rr < w && c < w && rr >= c) dv4[it] = A[rr + (long)c * lda];
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = ftid + it * ZP_THREADS, rr = idx % NBZ, c = idx / NBZ;
+      if (idx < NBZ * NBZ) {
+        Lr[rr][c] = dv4[it].x;
+        Li[rr][c] = rr == c ? 0.0 : dv4[it].y;  // the diagonal of a Hermitian matrix is real (LAPACK ignores its imaginary part too)
+      }
+    }
   }
   __syncthreads();
   if (st && ftid == 0) stamps[1] = wall_clock64();  // diagonal block in LDS
@@ -112,7 +133,7 @@ __global__ void __launch_bounds__(ZP_THREADS) k_zpotrf_panel(double2* __restrict
         if (bad == 0) bad = k + 1;
         d = 1.0;
       }
-      const double inv = 1.0 / sqrt(d);
+      const double inv = sb::fast_rsqrt(d);  // (v_rsq_f64 + one Newton step of third order: within an ulp or two of 1 / sqrt(d), a third of the dependent instructions)
       const double lr = from_half(ao_r[qk] * inv, hk), li = from_half(ao_i[qk] * inv, hk);
       // column k is final: publish it (rows above the diagonal hold garbage that nobody reads), then the count
       dv[k] = inv;
@@ -303,10 +324,29 @@ __global__ void __launch_bounds__(256) k_ztrsv_outer_sum(const double2* __restri
   __shared__ double2 red[4];
   const int c = K0 + blockIdx.x;
   double sr = 0.0, si = 0.0;
-  for (int r = K0 + W + threadIdx.x; r < n; r += 256) {
-    const double2 l = Lc[(long)r + (long)c * lda], b = y[r];
-    sr += l.x * b.x - l.y * b.y;
-    si += l.x * b.y + l.y * b.x;
+  {
+    const double2* col = Lc + (long)c * lda;
+    double sr1 = 0.0, si1 = 0.0;
+    int r = K0 + W + threadIdx.x;
+    for (; r + 768 < n; r += 1024) {  // four products in flight per thread
+      const double2 l0 = col[r], l1 = col[r + 256], l2 = col[r + 512], l3 = col[r + 768];
+      const double2 b0 = y[r], b1 = y[r + 256], b2 = y[r + 512], b3 = y[r + 768];
+      sr += l0.x * b0.x - l0.y * b0.y;
+      si += l0.x * b0.y + l0.y * b0.x;
+      sr1 += l1.x * b1.x - l1.y * b1.y;
+      si1 += l1.x * b1.y + l1.y * b1.x;
+      sr += l2.x * b2.x - l2.y * b2.y;
+      si += l2.x * b2.y + l2.y * b2.x;
+      sr1 += l3.x * b3.x - l3.y * b3.y;
+      si1 += l3.x * b3.y + l3.y * b3.x;
+    }
+    for (; r < n; r += 256) {
+      const double2 l = col[r], b = y[r];
+      sr += l.x * b.x - l.y * b.y;
+      si += l.x * b.y + l.y * b.x;
+    }
+    sr += sr1;
+    si += si1;
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -326,17 +366,45 @@ __global__ void __launch_bounds__(256) k_ztrsv_block(const double2* __restrict__
   const int bend = K0 + W, np = (W + NBZ - 1) / NBZ;
   for (int p = np - 1; p >= 0; --p) {
     const int k0 = K0 + p * NBZ, w = min(NBZ, bend - k0), rend = k0 + w;
+    // (four products in flight per thread and the block's entries requested together: one load per loop trip is one memory round trip per trip)
     double sr = 0.0, si = 0.0;
-    if (c < w)
-      for (int r = rend + g; r < bend; r += 8) {
-        const double2 l = Lc[(long)r + (long)(k0 + c) * lda], b = y[r];
+    if (c < w) {
+      const double2* col = Lc + (long)(k0 + c) * lda;
+      double sr1 = 0.0, si1 = 0.0;
+      int r = rend + g;
+      for (; r + 24 < bend; r += 32) {
+        const double2 l0 = col[r], l1 = col[r + 8], l2 = col[r + 16], l3 = col[r + 24];
+        const double2 b0 = y[r], b1 = y[r + 8], b2 = y[r + 16], b3 = y[r + 24];
+        sr += l0.x * b0.x - l0.y * b0.y;
+        si += l0.x * b0.y + l0.y * b0.x;
+        sr1 += l1.x * b1.x - l1.y * b1.y;
+        si1 += l1.x * b1.y + l1.y * b1.x;
+        sr += l2.x * b2.x - l2.y * b2.y;
+        si += l2.x * b2.y + l2.y * b2.x;
+        sr1 += l3.x * b3.x - l3.y * b3.y;
+        si1 += l3.x * b3.y + l3.y * b3.x;
+      }
+      for (; r < bend; r += 8) {
+        const double2 l = col[r], b = y[r];
         sr += l.x * b.x - l.y * b.y;
         si += l.x * b.y + l.y * b.x;
       }
+      sr += sr1;
+      si += si1;
+    }
     part[g][c] = make_double2(sr, si);
-    for (int idx = tid; idx < NBZ * NBZ; idx += 256) {
-      const int rr = idx % NBZ, cc = idx / NBZ;
-      blk[rr][cc] = (rr < w && cc < w && rr >= cc) ? Lc[(long)(k0 + rr) + (long)(k0 + cc) * lda] : make_double2(rr == cc ? 1.0 : 0.0, 0.0);
+    {
+      double2 bv[NBZ * NBZ / 256];
+#pragma unroll
+      for (int it = 0; it < NBZ * NBZ / 256; ++it) {
+        const int idx = tid + 256 * it, rr = idx % NBZ, cc = idx / NBZ;
+        bv[it] = (rr < w && cc < w && rr >= cc) ? Lc[(long)(k0 + rr) + (long)(k0 + cc) * lda] : make_double2(rr == cc ? 1.0 : 0.0, 0.0);
+      }
+#pragma unroll
+      for (int it = 0; it < NBZ * NBZ / 256; ++it) {
+        const int idx = tid + 256 * it;
+        blk[idx % NBZ][idx / NBZ] = bv[it];
+      }
     }
     __syncthreads();
     if (tid < 64) {  // wave 0: lane cc holds its unknown's right-hand side; 32 steps of backward substitution across the lanes
@@ -353,11 +421,9 @@ __global__ void __launch_bounds__(256) k_ztrsv_block(const double2* __restrict__
           acc.y -= part[q][cc].y;
         }
       }
+      const double dinv = 1.0 / blk[cc][cc].x;  // the diagonal of a Cholesky factor is real; (one division per unknown, all at once, not one per step)
       for (int t = NBZ - 1; t >= 0; --t) {
-        if (tid == t) {
-          const double dinv = 1.0 / blk[t][t].x;  // the diagonal of a Cholesky factor is real
-          sol[t] = make_double2(acc.x * dinv, acc.y * dinv);
-        }
+        if (tid == t) sol[t] = make_double2(acc.x * dinv, acc.y * dinv);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (tid < t) {  // unknown cc < t: take Lc[t][cc] beta[t] off

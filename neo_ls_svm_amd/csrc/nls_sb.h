@@ -953,8 +953,10 @@ struct HemmSlice {
   T a[HemmCfg<T, B>::RT][4], z[B / 16][4];
 };
 // FULL: the tile and the row block lie inside the matrix (no bounds tests).  r0: first row of this wave's slab.
-template <class T, int B, bool FULL>
-__device__ __forceinline__ void hemm_load(HemmSlice<T, B>& f, const T* A, long lda, int mh, const T* Zr, int I, long r0, int t, int q, int lane) {
+// KIND: 0 tile left of the diagonal (stored as is), 1 below it (read transposed), 2 the diagonal tile (stored half, mirrored).  The kind is
+// uniform over the slice and decided ONCE (hemm_load_any): tested per element it put a ladder of scalar branches in front of every load.
+template <class T, int B, bool FULL, int KIND>
+__device__ __forceinline__ void hemm_load(HemmSlice<T, B>& f, const T* A, long lda, int mh, const T* Zr, long r0, int t, int q, int lane) {
   constexpr int RT = HemmCfg<T, B>::RT;
   const int x = lane & 15, kk = lane >> 4;
   const long k0 = (long)t * HT + 16 * q + 4 * kk;  // first of this lane's four k
@@ -966,9 +968,9 @@ __device__ __forceinline__ void hemm_load(HemmSlice<T, B>& f, const T* A, long l
       const long k = k0 + e;
       T v = zero_<T>();
       if (FULL || (r < mh && k < mh)) {
-        if (t < I) {
+        if constexpr (KIND == 0) {
           v = A[r + k * lda];
-        } else if (t > I) {
+        } else if constexpr (KIND == 1) {
           v = conj_(A[k + r * lda]);
         } else {  // diagonal tile: the stored half, mirrored
           v = r >= k ? A[r + k * lda] : conj_(A[k + r * lda]);
@@ -986,10 +988,23 @@ __device__ __forceinline__ void hemm_load(HemmSlice<T, B>& f, const T* A, long l
 // bounds tests only for the tiles that touch the end of the matrix (uniform choice)
 template <class T, int B>
 __device__ __forceinline__ void hemm_load_any(HemmSlice<T, B>& f, const T* A, long lda, int mh, const T* Zr, int I, long r0, int t, int q, int lane) {
-  if ((long)(max(I, t) + 1) * HT <= mh)
-    hemm_load<T, B, true>(f, A, lda, mh, Zr, I, r0, t, q, lane);
-  else
-    hemm_load<T, B, false>(f, A, lda, mh, Zr, I, r0, t, q, lane);
+  const bool full = (long)(max(I, t) + 1) * HT <= mh;
+  if (t < I) {
+    if (full)
+      hemm_load<T, B, true, 0>(f, A, lda, mh, Zr, r0, t, q, lane);
+    else
+      hemm_load<T, B, false, 0>(f, A, lda, mh, Zr, r0, t, q, lane);
+  } else if (t > I) {
+    if (full)
+      hemm_load<T, B, true, 1>(f, A, lda, mh, Zr, r0, t, q, lane);
+    else
+      hemm_load<T, B, false, 1>(f, A, lda, mh, Zr, r0, t, q, lane);
+  } else {
+    if (full)
+      hemm_load<T, B, true, 2>(f, A, lda, mh, Zr, r0, t, q, lane);
+    else
+      hemm_load<T, B, false, 2>(f, A, lda, mh, Zr, r0, t, q, lane);
+  }
 }
 template <int B, int RT, int JT>
 __device__ __forceinline__ void hemm_mac(hv4d (&acc)[2][RT][JT], const HemmSlice<double, B>& f) {
@@ -1189,15 +1204,16 @@ template <class T, int B>
 constexpr size_t her2k_lds_bytes() {
   return 2 * (size_t)B * H2LD * sizeof(T);
 }
-template <class T, int B, bool FULL>
-__device__ __forceinline__ void her2k_tile(T* A, long lda, int mh, const T* Xb, const T* Yb, long ld, int kb, long r0, long c0, bool diag, int w, int lane) {
+// FULL: the tile lies inside the matrix; FULLK: the panel has all its B columns (kb == B) - no predicates on the loads then
+template <class T, int B, bool FULL, bool FULLK, bool DIAG>
+__device__ __forceinline__ void her2k_tile(T* A, long lda, int mh, const T* Xb, const T* Yb, long ld, int kb, long r0, long c0, int w, int lane) {
   constexpr bool CX = sizeof(T) == 16;
   constexpr int KS = B / 4;
   T(*Xs)[H2LD] = reinterpret_cast<T(*)[H2LD]>(sb_smem);
   T(*Ys)[H2LD] = Xs + B;
-  block_copy<B * 64>([&](int idx) { return (idx / 64 < kb && (FULL || r0 + idx % 64 < mh)) ? Xb[r0 + idx % 64 + (long)(idx / 64) * ld] : zero_<T>(); },
+  block_copy<B * 64>([&](int idx) { return ((FULLK || idx / 64 < kb) && (FULL || r0 + idx % 64 < mh)) ? Xb[r0 + idx % 64 + (long)(idx / 64) * ld] : zero_<T>(); },
                      [&](int idx, T v) { Xs[idx / 64][idx % 64] = v; });
-  block_copy<B * 64>([&](int idx) { return (idx / 64 < kb && (FULL || r0 + idx % 64 < mh)) ? Yb[r0 + idx % 64 + (long)(idx / 64) * ld] : zero_<T>(); },
+  block_copy<B * 64>([&](int idx) { return ((FULLK || idx / 64 < kb) && (FULL || r0 + idx % 64 < mh)) ? Yb[r0 + idx % 64 + (long)(idx / 64) * ld] : zero_<T>(); },
                      [&](int idx, T v) { Ys[idx / 64][idx % 64] = v; });
   const int x = lane & 15, kk = lane >> 4;
   const long c = c0 + 16 * w + x;  // A operand: column c of the tile
@@ -1208,7 +1224,7 @@ __device__ __forceinline__ void her2k_tile(T* A, long lda, int mh, const T* Xb, 
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const int k = 4 * ks + kk;
-      a[half][ks] = (k < kb && (FULL || c < mh)) ? conj_(Pa[c + (long)k * ld]) : zero_<T>();
+      a[half][ks] = ((FULLK || k < kb) && (FULL || c < mh)) ? conj_(Pa[c + (long)k * ld]) : zero_<T>();
     }
   }
   __syncthreads();
@@ -1249,7 +1265,7 @@ __device__ __forceinline__ void her2k_tile(T* A, long lda, int mh, const T* Xb, 
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) {
       const long r = r0 + 16 * jt + x;
-      old[reg][jt] = ((FULL || (r < mh && cc < mh)) && (!diag || r >= cc)) ? A[r + cc * lda] : zero_<T>();
+      old[reg][jt] = ((FULL || (r < mh && cc < mh)) && (!DIAG || r >= cc)) ? A[r + cc * lda] : zero_<T>();
     }
   }
 #pragma unroll
@@ -1258,7 +1274,7 @@ __device__ __forceinline__ void her2k_tile(T* A, long lda, int mh, const T* Xb, 
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) {
       const long r = r0 + 16 * jt + x;
-      if ((FULL || (r < mh && cc < mh)) && (!diag || r >= cc)) {
+      if ((FULL || (r < mh && cc < mh)) && (!DIAG || r >= cc)) {
         // D holds sum_k conj(P[cc][k]) Q[r][k] = (X Y^H + Y X^H)[r][cc]
         T v = old[reg][jt] - make_<T>(acc[0][jt][reg], CX ? acc[1][jt][reg] : 0.0);
         if (r == cc) v = make_<T>(real_(v), 0.0);
@@ -1277,10 +1293,16 @@ __global__ void __launch_bounds__(256) k_sb_her2k(T* A, long lda, int mh, const 
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const long r0 = (long)R * UT, c0 = (long)C * UT;
-  if (r0 + UT <= mh)  // c0 <= r0
-    her2k_tile<T, B, true>(A, lda, mh, Xb, Yb, ld, kb, r0, c0, R == C, w, lane);
+  if (r0 + UT <= mh && kb == B && R != C)  // c0 <= r0: the common tile - inside the matrix, off the diagonal, a full panel: no predicates at all
+    her2k_tile<T, B, true, true, false>(A, lda, mh, Xb, Yb, ld, kb, r0, c0, w, lane);
+  else if (r0 + UT <= mh && R != C)
+    her2k_tile<T, B, true, false, false>(A, lda, mh, Xb, Yb, ld, kb, r0, c0, w, lane);
+  else if (r0 + UT <= mh)
+    her2k_tile<T, B, true, false, true>(A, lda, mh, Xb, Yb, ld, kb, r0, c0, w, lane);
+  else if (R != C)
+    her2k_tile<T, B, false, false, false>(A, lda, mh, Xb, Yb, ld, kb, r0, c0, w, lane);
   else
-    her2k_tile<T, B, false>(A, lda, mh, Xb, Yb, ld, kb, r0, c0, R == C, w, lane);
+    her2k_tile<T, B, false, false, true>(A, lda, mh, Xb, Yb, ld, kb, r0, c0, w, lane);
 }
 
 // ---- dense (lower, bandwidth B) -> band storage AB[(i - j) + j * ldab], rows 0 .. 2B (the rows beyond B: room for the bulges, zero) ----

@@ -11,6 +11,7 @@
 #include "nls_gemm.h"
 #include "nls_gemm3m.h"
 #include "nls_sincos.h"
+#include "nls_trd.h"
 
 namespace nls {
 
@@ -131,12 +132,22 @@ __global__ void __launch_bounds__(Cfg4::NTHREADS, 1) k_featuremap(FeatureMapPara
       // Plane tile without padded columns (every tile when D is a multiple of 128): no per-element column test, one address
       // per accumulator row and plane, the four column groups at immediate offsets.
       const long cbase = col0 + C::acc_col(0);
+      // The row scales are fetched for all 16 accumulator rows BEFORE the first store: a load between the stores makes the wave wait for
+      // vmcnt(0) - on this chip the counter the stores use too - i.e. drain its eight stores sixteen times per tile (round 5).
+      double fs[C::MT][4];
 #pragma unroll
       for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const long row = row0 + C::acc_row(mt, r);
-          const double f = row < p.rows ? p.inv_sqrt_D * (p.rowscale ? p.rowscale[row] : 1.0) : 0.0;
+          fs[mt][r] = row < p.rows ? p.inv_sqrt_D * (p.rowscale ? p.rowscale[row] : 1.0) : 0.0;
+        }
+#pragma unroll
+      for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const long row = row0 + C::acc_row(mt, r);
+          const double f = fs[mt][r];
           double* pc = p.Fc + row * p.Kf + cbase;
           double* ps = p.Fs + row * p.Kf + cbase;
 #pragma unroll
@@ -150,6 +161,14 @@ __global__ void __launch_bounds__(Cfg4::NTHREADS, 1) k_featuremap(FeatureMapPara
       return;
     }
   }
+  double rsv[C::MT][4];  // (fetched before the first store: see above)
+#pragma unroll
+  for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long row = row0 + C::acc_row(mt, r);
+      rsv[mt][r] = row < p.rows ? (p.rowscale ? p.rowscale[row] : 1.0) : 0.0;
+    }
   auto epilogue = [&](auto fastc) {
     constexpr bool FAST = decltype(fastc)::value;
 #pragma unroll
@@ -158,7 +177,7 @@ __global__ void __launch_bounds__(Cfg4::NTHREADS, 1) k_featuremap(FeatureMapPara
       for (int r = 0; r < 4; ++r) {
         const long row = row0 + C::acc_row(mt, r);
         const bool live = row < p.rows;
-        const double rs = live ? (p.rowscale ? p.rowscale[row] : 1.0) : 0.0;
+        const double rs = rsv[mt][r];
         const double f = p.inv_sqrt_D * rs;
 #pragma unroll
         for (int nt = 0; nt < C::NTL; ++nt) {
@@ -237,8 +256,7 @@ __global__ void __launch_bounds__(Cfg4::NTHREADS, 1) k_featuremap_gemv(FeatureMa
           else sincos(acc[mt][nt][r], &sv, &cv);
           sum += cv * br[nt] + sv * bi[nt];
         }
-#pragma unroll
-        for (int m = 1; m < 16; m <<= 1) sum += __shfl_xor(sum, m, 64);
+        sum = trd::row16_sum(sum);  // (the 16 lanes of a row group are a DPP row: four vector instructions instead of four LDS round trips)
         if ((threadIdx.x & 15) == 0) out[row0 + C::acc_row(mt, r)] = sum;
       }
   };

@@ -264,29 +264,38 @@ __global__ void __launch_bounds__(Cfg4::NTHREADS, 2) k_potrf_syrk(double* A, lon
   KMajorLoader<C4::NTHREADS, BN> lb{Lp, ldl, (long)R * BN};
   mainloop_real<C4, true>(acc, la, lb, 0, ktiles, smem);
   // read-modify-write of the tile: the 16 entries of an accumulator row block are LOADED together, then stored (written as A[..] -= acc the
-  // compiler must assume a store may feed the next load - the same array - and every entry pays its own memory round trip: 64 in a row)
+  // compiler must assume a store may feed the next load - the same array - and every entry pays its own memory round trip: 64 in a row).
+  // A tile inside the matrix and off the diagonal - nearly all of them - takes the copy of the loop without per-entry tests (each test is a
+  // scalar branch in front of its load / store).
+  auto rmw = [&](auto plainc) {
+    constexpr bool PLAIN = decltype(plainc)::value;
 #pragma unroll
-  for (int mt = 0; mt < C4::MT; ++mt) {
-    double old[4][C4::NTL];
+    for (int mt = 0; mt < C4::MT; ++mt) {
+      double old[4][C4::NTL];
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const long cc = (long)C * BM + C4::acc_row(mt, reg);
+      for (int reg = 0; reg < 4; ++reg) {
+        const long cc = (long)C * BM + C4::acc_row(mt, reg);
 #pragma unroll
-      for (int nt = 0; nt < C4::NTL; ++nt) {
-        const long r = (long)R * BN + C4::acc_col(nt);
-        old[reg][nt] = (r < m && cc < m && r >= cc) ? A[r + cc * lda] : 0.0;
+        for (int nt = 0; nt < C4::NTL; ++nt) {
+          const long r = (long)R * BN + C4::acc_col(nt);
+          old[reg][nt] = (PLAIN || (r < m && cc < m && r >= cc)) ? A[r + cc * lda] : 0.0;
+        }
+      }
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const long cc = (long)C * BM + C4::acc_row(mt, reg);
+#pragma unroll
+        for (int nt = 0; nt < C4::NTL; ++nt) {
+          const long r = (long)R * BN + C4::acc_col(nt);
+          if (PLAIN || (r < m && cc < m && r >= cc)) A[r + cc * lda] = old[reg][nt] - acc[mt][nt][reg];
+        }
       }
     }
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const long cc = (long)C * BM + C4::acc_row(mt, reg);
-#pragma unroll
-      for (int nt = 0; nt < C4::NTL; ++nt) {
-        const long r = (long)R * BN + C4::acc_col(nt);
-        if (r < m && cc < m && r >= cc) A[r + cc * lda] = old[reg][nt] - acc[mt][nt][reg];
-      }
-    }
-  }
+  };
+  if (R != C && ((long)R + 1) * BN <= m)  // (C < R: the columns are inside too)
+    rmw(std::true_type{});
+  else
+    rmw(std::false_type{});
 }
 
 }  // namespace potrf

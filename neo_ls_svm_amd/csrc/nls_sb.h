@@ -1093,31 +1093,37 @@ __global__ void __launch_bounds__(256) k_sb_hemm_reduce(const T* Wp, int split, 
     const long pstride = (long)mh * B;
     const T* wp = Wp + ((long)r0 + rb) * B + c;
     T s[NU];
-    bool valid[NU];
 #pragma unroll
-    for (int u = 0; u < NU; ++u) {
-      s[u] = zero_<T>();
-      valid[u] = r0 + rb + RSTEP * u < mh && c < kb;
-    }
-    int p = 0;
-    for (; p + 4 <= split; p += 4) {
-      T v[4][NU];
+    for (int u = 0; u < NU; ++u) s[u] = zero_<T>();
+    auto add_up = [&](auto plainc) {  // PLAIN: the whole row block lies inside the matrix and the panel is full - no test in front of the loads
+      constexpr bool PLAIN = decltype(plainc)::value;
+      bool valid[NU];
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
+      for (int u = 0; u < NU; ++u) valid[u] = PLAIN || (r0 + rb + RSTEP * u < mh && c < kb);
+      int p = 0;
+      for (; p + 4 <= split; p += 4) {
+        T v[4][NU];
 #pragma unroll
-        for (int u = 0; u < NU; ++u) v[q][u] = valid[u] ? wp[(p + q) * pstride + (long)u * RSTEP * B] : zero_<T>();
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
+          for (int u = 0; u < NU; ++u) v[q][u] = valid[u] ? wp[(p + q) * pstride + (long)u * RSTEP * B] : zero_<T>();
 #pragma unroll
-        for (int u = 0; u < NU; ++u) s[u] = s[u] + v[q][u];
-    }
-    for (; p < split; ++p) {
-      T v[NU];
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-      for (int u = 0; u < NU; ++u) v[u] = valid[u] ? wp[p * pstride + (long)u * RSTEP * B] : zero_<T>();
+          for (int u = 0; u < NU; ++u) s[u] = s[u] + v[q][u];
+      }
+      for (; p < split; ++p) {
+        T v[NU];
 #pragma unroll
-      for (int u = 0; u < NU; ++u) s[u] = s[u] + v[u];
-    }
+        for (int u = 0; u < NU; ++u) v[u] = valid[u] ? wp[p * pstride + (long)u * RSTEP * B] : zero_<T>();
+#pragma unroll
+        for (int u = 0; u < NU; ++u) s[u] = s[u] + v[u];
+      }
+    };
+    if (r0 + RC <= mh && kb == B)
+      add_up(std::true_type{});
+    else
+      add_up(std::false_type{});
 #pragma unroll
     for (int u = 0; u < NU; ++u) Ws[rb + RSTEP * u][c] = s[u];
   }

@@ -288,29 +288,37 @@ __global__ void __launch_bounds__(Cfg4::NTHREADS, 2) k_zpotrf_herk(double2* A, l
   KMajorLoader<C4::NTHREADS, BN> lb{part == 0 ? S1 : S3, ldp, (long)R * BN};
   mainloop_real<C4, true>(acc, la, lb, 0, ktiles, smem);
   double* Ad = reinterpret_cast<double*>(A) + part;
-  // read-modify-write: 16 entries loaded together, then stored (A[..] -= acc entry by entry is one memory round trip per entry: nls_potrf.h)
+  // read-modify-write: 16 entries loaded together, then stored (A[..] -= acc entry by entry is one memory round trip per entry: nls_potrf.h);
+  // tiles inside the matrix and off the diagonal without per-entry tests
+  auto rmw = [&](auto plainc) {
+    constexpr bool PLAIN = decltype(plainc)::value;
 #pragma unroll
-  for (int mt = 0; mt < C4::MT; ++mt) {
-    double old[4][C4::NTL];
+    for (int mt = 0; mt < C4::MT; ++mt) {
+      double old[4][C4::NTL];
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const long cc = (long)C * BM + C4::acc_row(mt, reg);
+      for (int reg = 0; reg < 4; ++reg) {
+        const long cc = (long)C * BM + C4::acc_row(mt, reg);
 #pragma unroll
-      for (int nt = 0; nt < C4::NTL; ++nt) {
-        const long r = (long)R * BN + C4::acc_col(nt);
-        old[reg][nt] = (r < m && cc < ncols && (part == 0 ? r >= cc : r > cc)) ? Ad[2 * (r + cc * lda)] : 0.0;
+        for (int nt = 0; nt < C4::NTL; ++nt) {
+          const long r = (long)R * BN + C4::acc_col(nt);
+          old[reg][nt] = (PLAIN || (r < m && cc < ncols && (part == 0 ? r >= cc : r > cc))) ? Ad[2 * (r + cc * lda)] : 0.0;
+        }
+      }
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const long cc = (long)C * BM + C4::acc_row(mt, reg);
+#pragma unroll
+        for (int nt = 0; nt < C4::NTL; ++nt) {
+          const long r = (long)R * BN + C4::acc_col(nt);
+          if (PLAIN || (r < m && cc < ncols && (part == 0 ? r >= cc : r > cc))) Ad[2 * (r + cc * lda)] = old[reg][nt] - acc[mt][nt][reg];
+        }
       }
     }
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const long cc = (long)C * BM + C4::acc_row(mt, reg);
-#pragma unroll
-      for (int nt = 0; nt < C4::NTL; ++nt) {
-        const long r = (long)R * BN + C4::acc_col(nt);
-        if (r < m && cc < ncols && (part == 0 ? r >= cc : r > cc)) Ad[2 * (r + cc * lda)] = old[reg][nt] - acc[mt][nt][reg];
-      }
-    }
-  }
+  };
+  if (R != C && ((long)R + 1) * BN <= m && ((long)C + 1) * BM <= ncols)
+    rmw(std::true_type{});
+  else
+    rmw(std::false_type{});
 }
 
 // beta of L^H beta = y, in place in y, where the array holds Lc = conj(L) (column-major lower: what the download's conjugation leaves behind,

@@ -57,7 +57,8 @@ static int potrf_lower_real(nls_ctx* ctx, double* A, int n, long lda, rocblas_in
   // on a side stream - so that the next diagonal block (ONE workgroup, 110 us) and its panel are factored beside the big update instead of after
   // it.  The regions are disjoint (tile column 0 against tile columns >= 1 of the trailing matrix); the strip update of the panel after that
   // waits for the side stream.  NLS_POTRF_LOOKAHEAD=0: everything on the main stream.
-  static const bool lookahead = [] { const char* e = std::getenv("NLS_POTRF_LOOKAHEAD"); return !(e && e[0] == '0'); }();
+  const char* la_env = std::getenv("NLS_POTRF_LOOKAHEAD");  // (read per call: tests switch it)
+  const bool lookahead = !(la_env && la_env[0] == '0');
   hipStream_t side = nullptr;
   if (lookahead && n > 4 * NBO) {
     if (!ctx->stream2) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));

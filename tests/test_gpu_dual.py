@@ -94,6 +94,22 @@ def test_own_cholesky_factorisation_matches_numpy(n, cplx, hp):
         assert np.all(np.diag(L).imag == 0.0) and np.all(np.diag(L).real > 0.0)
 
 
+@pytest.mark.parametrize("n", [1025, 1537, 2600])
+def test_real_cholesky_lookahead_is_bit_identical(n, hp, monkeypatch):
+    """The real factorisation's look-ahead (the next diagonal block and panel factored on a side stream beside the trailing update,
+    csrc/nls_dual.hip: potrf_lower_real; active from n > 1024) only reorders independent work: the factor is the same bit for bit with
+    NLS_POTRF_LOOKAHEAD=0, and repeated calls agree."""
+    rng = np.random.default_rng(n)
+    M = rng.standard_normal((n, n + 3))
+    A = M @ M.T / n + 0.5 * np.eye(n)
+    L1 = hp.cholesky(A)
+    L2 = hp.cholesky(A)
+    monkeypatch.setenv("NLS_POTRF_LOOKAHEAD", "0")
+    L0 = hp.cholesky(A)
+    assert np.array_equal(L1, L0) and np.array_equal(L2, L0)
+    assert np.max(np.abs(L0 @ L0.T - A)) <= 1e-13 * n * np.max(np.abs(A))
+
+
 @pytest.mark.parametrize("cplx", [False, True])
 def test_own_cholesky_reports_the_first_bad_pivot(cplx, hp):
     """LAPACK semantics: info = 1-based index of the first non-positive pivot -> LinAlgError."""

@@ -267,6 +267,8 @@ static int sy2sb(nls_ctx* ctx, T* A, int n, long lda, T* tau1, int* dflag, int* 
     NLSCHK(ws_get_t(ctx, "sb.stamps", (size_t)16, &dstamps));
     HIPCHK(ctx, hipMemsetAsync(dstamps, 0, 16 * sizeof(long long), st));
   }
+  const char* series_env = std::getenv("NLS_SB_SERIES");  // 0: the third pass's Cholesky factor always by elimination (test of that branch)
+  const int series = !(series_env && series_env[0] == '0') ? 1 : 0;
   int j = 0;
   for (;;) {
     const int m = n - j - B;            // rows below the band in column j
@@ -294,7 +296,7 @@ static int sy2sb(nls_ctx* ctx, T* A, int n, long lda, T* tau1, int* dflag, int* 
     hipLaunchKernelGGL((k_sb_small_chol<T, B>), dim3(1), dim3(256), lds_chol, st, kb, m, 1, ps, dflag, adaptive);
     hipLaunchKernelGGL((k_sb_apply<T, B>), dim3(nch), dim3(256), lds_apply, st, Yb + zh, (long)n, m, kb, ps, Yb + zh, (long)n, Gp, 1);
     hipLaunchKernelGGL((k_sb_reduce<T>), red_grid, dim3(256), 0, st, Gp, nch, B * B, ps->G, &ps->skip2);
-    hipLaunchKernelGGL((k_sb_small_recon<T, B>), dim3(1), dim3(256), lds_recon, st, kb, Yb + zh, (long)n, ps, P, lda, tau1 + j, dflag, j == 0 ? dstamps : nullptr);
+    hipLaunchKernelGGL((k_sb_small_recon<T, B>), dim3(1), dim3(256), lds_recon, st, kb, Yb + zh, (long)n, ps, P, lda, tau1 + j, dflag, j == 0 ? dstamps : nullptr, series);
     hipLaunchKernelGGL((k_sb_finish<T, B>), dim3(nch), dim3(256), lds_finish, st, Yb, (long)n, m, kb, ps, Zb, Zr, P, lda);
     HIPCHK(ctx, hipGetLastError());
     T* A22 = A + (long)(j + kb) + (long)(j + kb) * lda;

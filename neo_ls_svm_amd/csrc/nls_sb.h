@@ -624,7 +624,7 @@ __global__ void __launch_bounds__(256) k_sb_apply(const T* src, long lds_, int m
 // block become rows of Y by one solve against M), ps->Y1, ps->Tm, the kb x kb R factor S R3 R2 R1 written into the band block of A
 // (upper triangle; zeros below), tau1.
 template <class T, int B>
-__global__ void __launch_bounds__(256, 1) k_sb_small_recon(int kb, const T* Ytop, long ldy, PanelSmall<T, B>* ps, T* Aband, long lda, T* tau1, int* flag, long long* stamps) {
+__global__ void __launch_bounds__(256, 1) k_sb_small_recon(int kb, const T* Ytop, long ldy, PanelSmall<T, B>* ps, T* Aband, long lda, T* tau1, int* flag, long long* stamps, int series) {
   using S = Small<B>;
   constexpr int CQ = B / 4;
   size_t off = 0;
@@ -652,7 +652,7 @@ __global__ void __launch_bounds__(256, 1) k_sb_small_recon(int kb, const T* Ytop
       }
     }
     if (!(dev < 1e-12)) bad = 1;
-    if (!(dev < 1e-16)) coarse = 1;
+    if (!series || !(dev < 1e-16)) coarse = 1;  // (series = 0, NLS_SB_SERIES=0: always the factorisation proper - the test of that branch)
   }
   __syncthreads();
   if (stamps && threadIdx.x == 0) stamps[1] = wall_clock64();

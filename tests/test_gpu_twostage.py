@@ -151,6 +151,25 @@ def test_three_pass_panels_equal_the_adaptive_two_pass_ones(cplx, hp, monkeypatc
         assert np.max(np.abs(Q.conj().T @ Q - np.eye(n))) <= 1e-13 * n
 
 
+@pytest.mark.parametrize("cplx", [False, True])
+def test_third_pass_factor_by_series_equals_the_elimination(cplx, hp, monkeypatch):
+    """The reconstruction kernel takes the Cholesky factor of the third Gram matrix G3 = I + E from its series when |E| < 1e-8 (always, in
+    practice) and by elimination otherwise; NLS_SB_SERIES=0 forces the elimination: same decomposition to rounding, with two and with three passes."""
+    monkeypatch.setenv("NLS_EVD", "twostage")
+    n = 700
+    A = _herm(n, cplx, 5)
+    lam0 = np.linalg.eigvalsh(A)
+    scale = np.max(np.abs(lam0))
+    for adaptive in ("1", "0"):
+        monkeypatch.setenv("NLS_SB_ADAPTIVE", adaptive)
+        for series in ("1", "0"):
+            monkeypatch.setenv("NLS_SB_SERIES", series)
+            lam, Q = hp.eigh(A)
+            assert np.max(np.abs(lam - lam0)) <= 1e-13 * n * scale
+            assert np.max(np.abs(A @ Q - Q * lam[None, :])) <= 1e-13 * n * scale
+            assert np.max(np.abs(Q.conj().T @ Q - np.eye(n))) <= 1e-13 * n
+
+
 def test_fits_through_the_two_stage_reduction_match_the_reference(hp, monkeypatch):
     """The primal and the dual fit with every eigendecomposition forced through the two-stage path: same parity bar as the default."""
     monkeypatch.setenv("NLS_EVD", "twostage")

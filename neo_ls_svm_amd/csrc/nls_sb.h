@@ -23,6 +23,14 @@
 // (the block is a product of kb elementary reflectors, so the blocked back-transformation of nls_evd.hip rebuilds its
 // T^-1 = striu(Y^H Y) + diag(1 / tau) from Y and tau1 alone).
 //
+// How the panel's kernels are laid out (round 5: a panel is a chain of a dozen dependent launches whose cost is latency, not work):
+//   * the row kernels (k_sb_gram / k_sb_apply / k_sb_finish) take 64 rows per workgroup with FOUR threads per row - a quad shares a row's
+//     triangular solve (quad_row_solve_upper: the solved entry travels on DPP) - so a panel of 10^4 rows is 157 workgroups, not 40;
+//   * the 32 x 32 factorisations of the real path run on ONE wave with the matrix in registers, lane = column (wave_cholesky,
+//     wave_modified_lu: v_readlane broadcasts, v_rsq / v_rcp + Newton steps, no LDS, no barrier); the third pass's Cholesky factor comes from
+//     its series (G3 = I + E, |E| < 1e-8), the elimination only otherwise (NLS_SB_SERIES=0 forces it);
+//   * every cooperative copy requests all of a thread's items before its first store (block_copy), every read-modify-write loads its entries
+//     in a batch, and the tile kind / bounds case of the big products is decided per tile, not per load (tools/isa_scan.py).
 // Failure: a Cholesky pivot <= 0 / NaN or a second-pass Gram matrix further than 1e-6 from I (kappa(P) beyond ~1e15:
 // exactly dependent or zero panel columns, e.g. a diagonal matrix) raises flag[0]; the driver then repeats the reduction on the saved
 // copy with every panel perturbed by 1e-13 of its norm (k_sb_perturb) and, if that fails too, hands the copy to the one-stage panel.
@@ -64,11 +72,12 @@ __device__ __forceinline__ bool finite_(Z a) { return isfinite(a.re) && isfinite
 __device__ __forceinline__ bool finite_(double a) { return isfinite(a); }
 
 // ================================================================================================================
-// Panel kernels.  Rows are handled 256 per workgroup (thread = row for the triangular solves), Gram matrices are
-// accumulated over four 64-row LDS tiles per workgroup, partial Gram matrices are summed by an element-parallel kernel
-// (k_sb_reduce) in a fixed order, and the B x B factorisations keep their matrix in registers (thread (r, cg) owns row r,
-// columns cg + TPR q) with ONE barrier per elimination step (the pivot column / row travels through a double-buffered
-// LDS vector).  No explicit inverses: Q = P R^-1 is a row-wise back substitution with R in LDS (uniform reads).
+// Panel kernels.  Rows are handled 64 per workgroup (a quad of threads per row for the triangular solves), Gram matrices are
+// accumulated over one 64-row LDS tile per workgroup, partial Gram matrices are summed by an element-parallel kernel
+// (k_sb_reduce) in a fixed order.  The B x B factorisations: one wave, lane = column, for the real B = 32 path (wave_cholesky,
+// wave_modified_lu); the generic form (complex, other band widths) keeps the matrix in registers across the workgroup (thread (r, cg)
+// owns row r, columns cg + TPR q) with ONE barrier per elimination step (the pivot column / row travels through a double-buffered
+// LDS vector).  No explicit inverses: Q = P R^-1 is a row-wise back substitution with R in LDS.
 // ================================================================================================================
 // Cooperative copy of COUNT items by the 256 threads of a workgroup (item e = threadIdx.x + 256 it): ALL of a thread's loads are issued
 // before its first store.  Written as `for (e = threadIdx.x; e < COUNT; e += 256) dst(e) = src(e)` the loop is not unrolled (its trip count

@@ -187,14 +187,29 @@ static int apply_q_blocked(nls_ctx* ctx, const T* A, long lda, int n, const T* t
   NLSCHK(ws_get_t(ctx, "bt.V", (size_t)n * kbq, &Vw));
   NLSCHK(ws_get_t(ctx, "bt.S", (size_t)kbq * kbq, &S));
   NLSCHK(ws_get_t(ctx, "bt.W", (size_t)kbq * ncols, &W));
+  // V^H stored explicitly (k_trd_transpose_v) makes the two products with it no-transpose GEMMs.  Measured (round 5, tools/gpu_r05_v.sh): complex
+  // n = 4097: 15.15 -> 13.0 ms per back-transformation; real n = 10^4: 42.6-43.9 -> 45.7-46.0 ms (the real transposed-operand kernel is the
+  // better one there).  Default: complex only; NLS_BT_VT=0 / 1 overrides.
+  T* Vt = nullptr;
+  bool want_vt = sizeof(T) == 16;
+  if (const char* e = std::getenv("NLS_BT_VT")) want_vt = e[0] == '1';
+  if (want_vt) NLSCHK(ws_get_t(ctx, "bt.Vt", (size_t)n * kbq, &Vt));
   BLASCHK(ctx, rocblas_set_stream(ctx->blas, ctx->stream));
   for (int j0 = ((nrefl - 1) / kbq) * kbq; j0 >= 0; j0 -= kbq) {
     const int kb = std::min(kbq, nrefl - j0), r0 = j0 + off, m = n - r0;
     hipLaunchKernelGGL(k_trd_copy_v<T>, dim3((unsigned)(((long)m * kb + 255) / 256)), dim3(256), 0, ctx->stream, A, lda, n, j0, kb, Vw, off);
-    BLASCHK(ctx, bt_gemm(ctx->blas, bt_op_h(A), rocblas_operation_none, kb, kb, m, 1.0, Vw, m, Vw, m, 0.0, S, kb));
+    if (Vt) {  // V^H explicitly: both products with it are no-transpose GEMMs
+      hipLaunchKernelGGL(k_trd_transpose_v<T>, dim3((unsigned)((m + 31) / 32), (unsigned)((kb + 31) / 32)), dim3(32, 8), 0, ctx->stream, Vw, (long)m, kb, Vt);
+      BLASCHK(ctx, bt_gemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, kb, kb, m, 1.0, Vt, kb, Vw, m, 0.0, S, kb));
+    } else {
+      BLASCHK(ctx, bt_gemm(ctx->blas, bt_op_h(A), rocblas_operation_none, kb, kb, m, 1.0, Vw, m, Vw, m, 0.0, S, kb));
+    }
     hipLaunchKernelGGL(k_trd_tinv<T>, dim3((unsigned)((kb * kb + 255) / 256)), dim3(256), 0, ctx->stream, S, kb, tau, j0);
     HIPCHK(ctx, hipGetLastError());
-    BLASCHK(ctx, bt_gemm(ctx->blas, bt_op_h(A), rocblas_operation_none, kb, ncols, m, 1.0, Vw, m, C + r0, ldc, 0.0, W, kb));
+    if (Vt)
+      BLASCHK(ctx, bt_gemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, kb, ncols, m, 1.0, Vt, kb, C + r0, ldc, 0.0, W, kb));
+    else
+      BLASCHK(ctx, bt_gemm(ctx->blas, bt_op_h(A), rocblas_operation_none, kb, ncols, m, 1.0, Vw, m, C + r0, ldc, 0.0, W, kb));
     BLASCHK(ctx, bt_trsm(ctx->blas, kb, ncols, S, kb, W, kb));
     BLASCHK(ctx, bt_gemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, m, ncols, kb, -1.0, Vw, m, W, kb, 1.0, C + r0, ldc));
   }

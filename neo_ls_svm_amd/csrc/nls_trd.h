@@ -908,6 +908,28 @@ __global__ void k_trd_copy_v(const T* A, long lda, int n, int j0, int kb, T* Vw,
   const int p = (int)(idx / m);
   Vw[idx] = q < p ? make_<T>(0.0, 0.0) : (q == p ? make_<T>(1.0, 0.0) : A[(j0 + off + q) + (long)(j0 + p) * lda]);
 }
+// Vt = Vw^H (kb x m, column-major, leading dimension kb): with it both products with V^H are plain (no-transpose) GEMMs - the library's
+// transposed-operand kernels run W = V^H C at 0.67 of the matrix pipe, its plain ones at 0.87 (round 5).  32 x 32 tiles through LDS: both
+// sides of the transposition move whole 256-byte runs.  grid (ceil(m / 32), ceil(kb / 32)), block (32, 8).
+template <class T>
+__global__ void __launch_bounds__(256) k_trd_transpose_v(const T* Vw, long m, int kb, T* Vt) {
+  __shared__ T tile[32][33];
+  const long q0 = (long)blockIdx.x * 32;
+  const int p0 = blockIdx.y * 32;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int p = p0 + threadIdx.y + 8 * i;
+    const long q = q0 + threadIdx.x;
+    tile[threadIdx.y + 8 * i][threadIdx.x] = (q < m && p < kb) ? Vw[q + (long)p * m] : make_<T>(0.0, 0.0);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long q = q0 + threadIdx.y + 8 * i;
+    const int p = p0 + threadIdx.x;
+    if (q < m && p < kb) Vt[p + q * (long)kb] = conj_(tile[threadIdx.x][threadIdx.y + 8 * i]);
+  }
+}
 // S (kb x kb, = V^H V) -> T^-1 = striu(S) + diag(1 / tau); tau = 0 (H = I) gets a huge diagonal, i.e. a zero row of X
 template <class T>
 __global__ void k_trd_tinv(T* S, int kb, const T* tau, int j0) {

@@ -151,7 +151,7 @@ int nls_rotate_only(nls_ctx* ctx, const double* X, int64_t n, int d, const doubl
  *   environment selects rocSOLVER's zheevd / dsyevd for every eigendecomposition of the library. */
 int nls_tridiag_only(nls_ctx* ctx, void* A, int n, int is_complex, double* d, double* e, void* tau);
 int nls_eigh_only(nls_ctx* ctx, void* A, int n, int is_complex, double* lam);
-/* The eigendecompositions above take a TWO-STAGE reduction for large real matrices (n >= 6000; dense -> band of width bw -> tridiagonal, two
+/* The eigendecompositions above take a TWO-STAGE reduction for large real matrices (n >= 4500; dense -> band of width bw -> tridiagonal, two
  * back-transformations; csrc/nls_sb.h, nls_chase.h, nls_q2.h) and the one-stage panel otherwise (complex matrices always): NLS_EVD=twostage /
  * onestage forces / forbids it, NLS_TWOSTAGE_MIN moves the size rule (both arithmetics), NLS_SB_BW = 32 / 64 the band width of real matrices
  * (default 32; complex: 32).  nls_twostage_stage runs ONE stage of it on host data (tests, profiling):

@@ -541,6 +541,8 @@ static int evd_bw(bool cplx) {
 //   real:    n = 4000: 139 against 128 ms one-stage, n = 5000: 135 against ~150, n = 6500: ~200 against ~250, n = 8000: 281 against 330, n = 10^4: 478 against 587
 //            -> two-stage from n = 6000 (the one-stage panel streams the trailing matrix from HBM once per column as soon as its lower
 //            triangle outgrows the 256 MB Infinity Cache);
+//            round 5 (band reduction 117 -> 75 ms at 10^4; eigh incl. copies, tools/gpu_r05_cross.sh): n = 3000: 111 against 70 one-stage,
+//            4000: 111 against 116, 5000: 163 against 178, 6000: 222 against 251 -> two-stage from n = 4500;
 //   complex: n = 4097: 171 against 143, n = 1025: 27 against 18.5 -> one-stage.
 // NLS_EVD=twostage forces it (n >= 4), NLS_EVD=onestage forbids it, NLS_TWOSTAGE_MIN = n moves the size rule (both arithmetics).
 static bool evd_use_two_stage(int n, bool cplx) {
@@ -548,7 +550,7 @@ static bool evd_use_two_stage(int n, bool cplx) {
   if (m && std::string(m) == "twostage") return n >= 4;
   if (m && std::string(m) == "onestage") return false;
   if (const char* e = std::getenv("NLS_TWOSTAGE_MIN")) return n >= std::max(4, std::atoi(e));
-  return !cplx && n >= 6000;
+  return !cplx && n >= 4500;
 }
 
 static bool evd_rocsolver_backtransform() {  // NLS_EVD_UNMTR=rocsolver: zunmtr / dormtr instead of apply_q_blocked (diagnostic)

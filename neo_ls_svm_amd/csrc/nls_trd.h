@@ -181,8 +181,19 @@ struct Args {
 template <class T>
 __device__ __forceinline__ T sum_partials(const T* p, int cnt, T* slot) {
   if (threadIdx.x < 64) {
+    // (eight partials per lane requested together - at n = 4097 there are 257: one load per loop trip was five dependent round trips at the
+    // head of EVERY block of the matrix-vector kernel; the order of the additions is still fixed)
     T s = make_<T>(0.0, 0.0);
-    for (int b = threadIdx.x; b < cnt; b += 64) s = s + p[b];
+    for (int b0 = 0; b0 < cnt; b0 += 512) {
+      T v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int b = b0 + 64 * u + (int)threadIdx.x;
+        v[u] = b < cnt ? p[b] : make_<T>(0.0, 0.0);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s = s + v[u];
+    }
     s = wave_sum(s);
     if (threadIdx.x == 0) *slot = s;
   }
@@ -566,31 +577,69 @@ __device__ __forceinline__ void trd_hemv2_body(const Args<T>& a, int S0, int nti
   const int n = a.n, j = a.j, i = a.j - a.j0;
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  PrevScalars<T> ps;
-  ps.mu = ps.alpha2 = make_<T>(0.0, 0.0);
-  if (i > 0) ps = prev_scalars(a, &slot);
-  // x[q] of column j for q > j (0 above): first column of a panel straight from A, else base + mu v_{j-1}
-  auto xval = [&](long q) -> T {
-    if (q <= j || q >= n) return make_<T>(0.0, 0.0);
-    return i > 0 ? a.bvec[q] + ps.mu * a.A[q + (long)(j - 1) * a.lda] : a.A[q + (long)j * a.lda];
+  // x[q] of column j for q > j (0 above) is base + mu v_{j-1} (first column of a panel: A[q][j] itself).  Its two parts are REQUESTED before
+  // mu is known - and so are the block's matrix entries: mu comes out of a reduction over the previous column's partials, a barrier and two
+  // more loads, three dependent round trips that used to stand in front of every block's own loads (round 5).
+  struct XRaw {
+    T base, v;
   };
-  if (bid < ntiles) {
+  auto xraw = [&](long q) -> XRaw {
+    XRaw x{make_<T>(0.0, 0.0), make_<T>(0.0, 0.0)};
+    if (q <= j || q >= n) return x;
+    if (i > 0) {
+      x.base = a.bvec[q];
+      x.v = a.A[q + (long)(j - 1) * a.lda];
+    } else {
+      x.base = a.A[q + (long)j * a.lda];
+    }
+    return x;
+  };
+  const bool tile = bid < ntiles;
+  int R = 0, C = 0;
+  long r = 0;
+  T av[2 * GW];
+  XRaw xr_raw{make_<T>(0.0, 0.0), make_<T>(0.0, 0.0)}, xc_raw = xr_raw;
+  // dot block: rows j + 64 b + lane (row j itself included: it carries d[j])
+  const int b = bid - ntiles;
+  bool inrange = false;
+  T xbase = make_<T>(0.0, 0.0), wt = make_<T>(0.0, 0.0), vprev = make_<T>(0.0, 0.0);
+  if (tile) {
     // Odd columns walk the tiles backwards: a trailing matrix larger than the 256 MB Infinity Cache (real n = 10^4: 400 MB of
     // lower triangle) then starts each column on the tiles the previous column touched last, which are still resident.
     int t = (a.boustrophedon && (a.j & 1)) ? ntiles - 1 - bid : bid, Rr = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
     while ((Rr + 1) * (Rr + 2) / 2 <= t) ++Rr;
     while (Rr * (Rr + 1) / 2 > t) --Rr;
-    const int R = S0 + Rr, C = S0 + (t - Rr * (Rr + 1) / 2);
-    const long r = (long)R * RT + lane;
-    T av[2 * GW];
+    R = S0 + Rr;
+    C = S0 + (t - Rr * (Rr + 1) / 2);
+    r = (long)R * RT + lane;
 #pragma unroll
     for (int cc = 0; cc < 2 * GW; ++cc) {
       const long c = (long)C * TS + 2 * GW * w + cc;
       av[cc] = make_<T>(0.0, 0.0);
       if (r < n && c < n && r >= c) av[cc] = a.A[r + c * a.lda];
     }
-    const T xr = xval(r);
-    const T xcol = xval((long)C * TS + 2 * GW * w + (lane & 15));
+    xr_raw = xraw(r);
+    xc_raw = xraw((long)C * TS + 2 * GW * w + (lane & 15));
+  } else {
+    r = (long)j + (long)b * RD + lane;
+    inrange = r < n;
+    if (inrange) {
+      if (i > 0) {
+        vprev = a.A[r + (long)(j - 1) * a.lda];
+        wt = a.wtmp_prev[r];
+        xbase = a.bvec[r];
+      } else {
+        xbase = a.A[r + (long)j * a.lda];
+      }
+    }
+  }
+  PrevScalars<T> ps;
+  ps.mu = ps.alpha2 = make_<T>(0.0, 0.0);
+  if (i > 0) ps = prev_scalars(a, &slot);
+  if (tile) {
+    // tile (R, C) of RT x TS = 64 x 64; lane = row, wave w = columns 16 w .. 16 w + 15 (all 16 loads in flight at once)
+    const T xr = xr_raw.base + ps.mu * xr_raw.v;
+    const T xcol = xc_raw.base + ps.mu * xc_raw.v;
     T low = make_<T>(0.0, 0.0);
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
@@ -614,20 +663,8 @@ __device__ __forceinline__ void trd_hemv2_body(const Args<T>& a, int S0, int nti
     __syncthreads();
     if (w == 0 && r < n) a.ylow[(long)C * n + r] = ((sh[0][lane] + sh[1][lane]) + sh[2][lane]) + sh[3][lane];
   } else {
-    // dot block b: rows j + 64 b + lane (row j itself included: it carries d[j]); wave w: panel columns p = w, w + 4, ...
-    const int b = bid - ntiles;
-    const long r = (long)j + (long)b * RD + lane;
-    const bool inrange = r < n;
-    T xfull = make_<T>(0.0, 0.0), wt = make_<T>(0.0, 0.0), vprev = make_<T>(0.0, 0.0);
-    if (inrange) {
-      if (i > 0) {
-        vprev = a.A[r + (long)(j - 1) * a.lda];
-        wt = a.wtmp_prev[r];
-        xfull = a.bvec[r] + ps.mu * vprev;
-      } else {
-        xfull = a.A[r + (long)j * a.lda];
-      }
-    }
+    // dot block b; wave w: panel columns p = w, w + 4, ...
+    const T xfull = inrange ? (i > 0 ? xbase + ps.mu * vprev : xbase) : make_<T>(0.0, 0.0);
     const bool live = inrange && r > j;
     const T xr = live ? xfull : make_<T>(0.0, 0.0);
     const T wlast = wt + ps.alpha2 * vprev;  // final W[r][i - 1]

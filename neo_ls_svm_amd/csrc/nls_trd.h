@@ -452,8 +452,15 @@ __global__ void __launch_bounds__(ROWT * TPR) k_trd_finish(Args<T> a, int S0, in
   T zp = make_<T>(0.0, 0.0);  // thread (slot = t % 64, part = t / 64) sums the dot partials b = part, part + 4, ...
   {
     const int slot = threadIdx.x % (2 * NB), part = threadIdx.x / (2 * NB);
-    if (slot % NB < i)
-      for (int b = part; b < a.ndot; b += 4) zp = zp + a.zpart[(long)b * 2 * NB + slot];
+    if (slot % NB < i) {  // (four partials requested together: one load per loop trip is one round trip per trip)
+      int b = part;
+      for (; b + 12 < a.ndot; b += 16) {
+        const T z0 = a.zpart[(long)b * 2 * NB + slot], z1 = a.zpart[(long)(b + 4) * 2 * NB + slot];
+        const T z2 = a.zpart[(long)(b + 8) * 2 * NB + slot], z3 = a.zpart[(long)(b + 12) * 2 * NB + slot];
+        zp = (((zp + z0) + z1) + z2) + z3;
+      }
+      for (; b < a.ndot; b += 4) zp = zp + a.zpart[(long)b * 2 * NB + slot];
+    }
   }
   T zrow = make_<T>(0.0, 0.0);  // row j + 1 of W (slots < NB) and of V
   if (threadIdx.x < 2 * NB && threadIdx.x % NB < i) {
@@ -728,8 +735,15 @@ __device__ __forceinline__ void trd_finish2_body(const Args<T>& a, int S0, int N
   T zp = make_<T>(0.0, 0.0);
   {
     const int slot = threadIdx.x % (2 * NB), part = threadIdx.x / (2 * NB);
-    if (slot % NB < i)
-      for (int b = part; b < a.ndot; b += 4) zp = zp + a.zpart[(long)b * 2 * NB + slot];
+    if (slot % NB < i) {  // (four partials requested together: one load per loop trip is one round trip per trip)
+      int b = part;
+      for (; b + 12 < a.ndot; b += 16) {
+        const T z0 = a.zpart[(long)b * 2 * NB + slot], z1 = a.zpart[(long)(b + 4) * 2 * NB + slot];
+        const T z2 = a.zpart[(long)(b + 8) * 2 * NB + slot], z3 = a.zpart[(long)(b + 12) * 2 * NB + slot];
+        zp = (((zp + z0) + z1) + z2) + z3;
+      }
+      for (; b < a.ndot; b += 4) zp = zp + a.zpart[(long)b * 2 * NB + slot];
+    }
   }
   T zrow = make_<T>(0.0, 0.0);  // row j + 1 of W (slots < NB) and of V
   if (threadIdx.x < 2 * NB && threadIdx.x % NB < i) {

@@ -610,6 +610,7 @@ __device__ __forceinline__ void trd_hemv2_body(const Args<T>& a, int S0, int nti
   const int b = bid - ntiles;
   bool inrange = false;
   T xbase = make_<T>(0.0, 0.0), wt = make_<T>(0.0, 0.0), vprev = make_<T>(0.0, 0.0);
+  T mw[GW], mv[GW];  // (dot block) this wave's panel columns of W and V at row r
   if (tile) {
     // Odd columns walk the tiles backwards: a trailing matrix larger than the 256 MB Infinity Cache (real n = 10^4: 400 MB of
     // lower triangle) then starts each column on the tiles the previous column touched last, which are still resident.
@@ -637,6 +638,15 @@ __device__ __forceinline__ void trd_hemv2_body(const Args<T>& a, int S0, int nti
         xbase = a.bvec[r];
       } else {
         xbase = a.A[r + (long)j * a.lda];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < GW; ++k) {
+      const int p = w + 4 * k;
+      mw[k] = mv[k] = make_<T>(0.0, 0.0);
+      if (inrange && r > j && p < i) {
+        if (p != i - 1) mw[k] = a.W[r + (long)p * n];  // (column i - 1 of W is finished below, from wtmp and alpha2)
+        mv[k] = a.A[r + (long)(a.j0 + p) * a.lda];
       }
     }
   }
@@ -675,16 +685,9 @@ __device__ __forceinline__ void trd_hemv2_body(const Args<T>& a, int S0, int nti
     const bool live = inrange && r > j;
     const T xr = live ? xfull : make_<T>(0.0, 0.0);
     const T wlast = wt + ps.alpha2 * vprev;  // final W[r][i - 1]
-    T mw[GW], mv[GW];
 #pragma unroll
-    for (int k = 0; k < GW; ++k) {
-      const int p = w + 4 * k;
-      mw[k] = mv[k] = make_<T>(0.0, 0.0);
-      if (live && p < i) {
-        mw[k] = p == i - 1 ? wlast : a.W[r + (long)p * n];
-        mv[k] = a.A[r + (long)(a.j0 + p) * a.lda];
-      }
-    }
+    for (int k = 0; k < GW; ++k)
+      if (live && w + 4 * k == i - 1) mw[k] = wlast;
     if (w == 0 && inrange) {
       if (r == j) {
         const double dj = real_(xfull);

@@ -731,23 +731,7 @@ __device__ __forceinline__ void trd_finish2_body(const Args<T>& a, int S0, int N
   const long r = (long)bid * ROWT + rl;
   const bool live = r < n && r >= j + 1;
   // ---- loads
-  double pn = 0.0;
-  if (threadIdx.x < 64)
-    for (int b = threadIdx.x; b < a.ndot; b += 64) pn += a.pnorm[b];  // |x[j+2:]|^2 partials of the dot blocks
   const T alpha = a.xvec[j + 1];
-  T zp = make_<T>(0.0, 0.0);
-  {
-    const int slot = threadIdx.x % (2 * NB), part = threadIdx.x / (2 * NB);
-    if (slot % NB < i) {  // (four partials requested together: one load per loop trip is one round trip per trip)
-      int b = part;
-      for (; b + 12 < a.ndot; b += 16) {
-        const T z0 = a.zpart[(long)b * 2 * NB + slot], z1 = a.zpart[(long)(b + 4) * 2 * NB + slot];
-        const T z2 = a.zpart[(long)(b + 8) * 2 * NB + slot], z3 = a.zpart[(long)(b + 12) * 2 * NB + slot];
-        zp = (((zp + z0) + z1) + z2) + z3;
-      }
-      for (; b < a.ndot; b += 4) zp = zp + a.zpart[(long)b * 2 * NB + slot];
-    }
-  }
   T zrow = make_<T>(0.0, 0.0);  // row j + 1 of W (slots < NB) and of V
   if (threadIdx.x < 2 * NB && threadIdx.x % NB < i) {
     const int p = threadIdx.x % NB;
@@ -757,6 +741,16 @@ __device__ __forceinline__ void trd_finish2_body(const Args<T>& a, int S0, int N
 #pragma unroll
   for (int k = 0; k < PPT; ++k) vv[k] = ww[k] = make_<T>(0.0, 0.0);
   if (live) {
+    xr = a.xvec[r];
+    t0 = a.A[r + (long)(j + 1) * a.lda];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+      const int p = q + TPR * k;
+      if (p < i) {
+        vv[k] = a.A[r + (long)(a.j0 + p) * a.lda];
+        ww[k] = a.W[r + (long)p * n];
+      }
+    }
     T y1 = make_<T>(0.0, 0.0), y2 = y1, y3 = y1;
     const int Clast = (int)(r / TS);
     for (int C = S0 + q; C <= Clast; C += 4 * TPR) {
@@ -772,14 +766,21 @@ __device__ __forceinline__ void trd_finish2_body(const Args<T>& a, int S0, int N
       if (R + 3 * TPR < NS) y3 = y3 + a.yup[(long)(R + 3 * TPR) * n + r];
     }
     y = (y + y1) + (y2 + y3);
-    xr = a.xvec[r];
-    t0 = a.A[r + (long)(j + 1) * a.lda];
+  }
+  // (the loops below wait for their loads trip by trip: they come LAST, with everything else already in flight)
+  double pn = 0.0;
+  if (threadIdx.x < 64)
+    for (int b = threadIdx.x; b < a.ndot; b += 64) pn += a.pnorm[b];  // |x[j+2:]|^2 partials of the dot blocks
+  T zp = make_<T>(0.0, 0.0);
+  {
+    const int slot = threadIdx.x % (2 * NB), part = threadIdx.x / (2 * NB);
+    if (slot % NB < i) {  // (eight partials requested together: one load per loop trip is one round trip per trip)
+      for (int b0 = part; b0 < a.ndot; b0 += 32) {
+        T z[8];
 #pragma unroll
-    for (int k = 0; k < PPT; ++k) {
-      const int p = q + TPR * k;
-      if (p < i) {
-        vv[k] = a.A[r + (long)(a.j0 + p) * a.lda];
-        ww[k] = a.W[r + (long)p * n];
+        for (int u = 0; u < 8; ++u) z[u] = b0 + 4 * u < a.ndot ? a.zpart[(long)(b0 + 4 * u) * 2 * NB + slot] : make_<T>(0.0, 0.0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) zp = zp + z[u];
       }
     }
   }

@@ -569,11 +569,12 @@ struct PrevScalars {
 // mu and alpha2 of the previous column (i > 0), every thread of the block gets them; slot: one T of shared memory
 template <class T>
 __device__ __forceinline__ PrevScalars<T> prev_scalars(const Args<T>& a, T* slot) {
+  const T tauv = a.tau[a.j - 1], wj = a.wtmp_prev[a.j];  // (requested before the reduction's barrier, not after it)
   const T s = sum_partials(a.spart_prev, a.nrowblocks, slot);
-  const T ts = a.tau[a.j - 1] * s;
+  const T ts = tauv * s;
   PrevScalars<T> ps;
   ps.alpha2 = (-0.5) * ts;
-  ps.mu = make_<T>(real_(ts), 0.0) - conj_(a.wtmp_prev[a.j]);
+  ps.mu = make_<T>(real_(ts), 0.0) - conj_(wj);
   return ps;
 }
 

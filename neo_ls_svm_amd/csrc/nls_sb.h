@@ -600,8 +600,7 @@ __global__ void __launch_bounds__(256) k_sb_apply(const T* src, long lds_, int m
   T(*Rq)[B] = sb_carve<T, B>(B, off);
   T(*Ps)[B + 1] = sb_carve<T, B + 1>(64, off);
   __shared__ T dinv[B];
-  load_rq<T, B>(Rq, ps->Rs);
-  if (threadIdx.x < B) dinv[threadIdx.x] = inv_(ps->Rs[threadIdx.x + B * threadIdx.x]);
+  // (the rows and the diagonal are requested BEFORE the triangular matrix is staged: three groups of loads, one round trip)
   const int rr = threadIdx.x / 4, q4 = threadIdx.x % 4;
   const long row = (long)blockIdx.x * RW + rr;
   T x[CQ];
@@ -610,6 +609,9 @@ __global__ void __launch_bounds__(256) k_sb_apply(const T* src, long lds_, int m
     const int c = q4 + 4 * i;
     x[i] = (row < m && c < kb) ? src[row + (long)c * lds_] : zero_<T>();
   }
+  const T dg = threadIdx.x < B ? ps->Rs[threadIdx.x + B * threadIdx.x] : one_<T>();
+  load_rq<T, B>(Rq, ps->Rs);
+  if (threadIdx.x < B) dinv[threadIdx.x] = inv_(dg);
   __syncthreads();
   quad_row_solve_upper<T, B, false>(x, Rq, dinv, q4);
 #pragma unroll
@@ -649,6 +651,15 @@ __global__ void __launch_bounds__(256, 1) k_sb_small_recon(int kb, const T* Ytop
   T a[S::CPT];
 #pragma unroll
   for (int q = 0; q < S::CPT; ++q) a[q] = ps->G[r + B * (cg + S::TPR * q)];
+  // (the kernel's other two inputs - the accumulated R factor and the top block of Q2 - are requested now, not where they are used)
+  T racc[S::CPT], ytop[CQ];
+#pragma unroll
+  for (int q = 0; q < S::CPT; ++q) racc[q] = ps->Racc[r + B * (cg + S::TPR * q)];
+#pragma unroll
+  for (int i = 0; i < CQ; ++i) {
+    const int rr = threadIdx.x / 4, c = threadIdx.x % 4 + 4 * i;
+    ytop[i] = (threadIdx.x < 4 * B && rr < kb && c < kb) ? Ytop[(long)rr + (long)c * ldy] : zero_<T>();
+  }
   __syncthreads();
   {  // orthogonality after the second pass: |G3 - I| < 1e-6, else the third pass cannot finish the job
     double dev = 0.0;
@@ -709,7 +720,7 @@ __global__ void __launch_bounds__(256, 1) k_sb_small_recon(int kb, const T* Ytop
   if (!ok && threadIdx.x == 0) flag[0] = 1;
   if (stamps && threadIdx.x == 0) stamps[2] = wall_clock64();
 #pragma unroll
-  for (int q = 0; q < S::CPT; ++q) X[r][cg + S::TPR * q] = ps->Racc[r + B * (cg + S::TPR * q)];
+  for (int q = 0; q < S::CPT; ++q) X[r][cg + S::TPR * q] = racc[q];
   __syncthreads();
   if (threadIdx.x < B) dinv[threadIdx.x] = inv_(R3[threadIdx.x][threadIdx.x]);
   for (int e = threadIdx.x; e < B * B; e += 256) Rq[e / B][CQ * ((e % B) % 4) + (e % B) / 4] = R3[e / B][e % B];
@@ -730,10 +741,7 @@ __global__ void __launch_bounds__(256, 1) k_sb_small_recon(int kb, const T* Ytop
     const int rr = threadIdx.x / 4, q4 = threadIdx.x % 4;
     T x[CQ];
 #pragma unroll
-    for (int i = 0; i < CQ; ++i) {
-      const int c = q4 + 4 * i;
-      x[i] = (rr < kb && c < kb) ? Ytop[(long)rr + (long)c * ldy] : zero_<T>();
-    }
+    for (int i = 0; i < CQ; ++i) x[i] = ytop[i];
     if (stamps) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (threadIdx.x == 0) stamps[7] = wall_clock64();
@@ -862,9 +870,7 @@ __global__ void __launch_bounds__(256) k_sb_finish(T* Yb, long ldy, int m, int k
   T(*Ps)[B + 1] = sb_carve<T, B + 1>(64, off);
   __shared__ T dinv[B];
   const int zh = B - kb;
-  load_rq<T, B>(Mq, ps->Rs);
-  block_copy<B * B>([&](int e) { return ps->Tm[e]; }, [&](int e, T v) { Ts[e % B][e / B] = v; });
-  if (threadIdx.x < B) dinv[threadIdx.x] = inv_(ps->Rs[threadIdx.x + B * threadIdx.x]);
+  // (rows and diagonal requested before the two matrices are staged: one round trip instead of four)
   const int rr = threadIdx.x / 4, q4 = threadIdx.x % 4;
   const long row = (long)blockIdx.x * RW + rr;
   T x[CQ];
@@ -876,6 +882,22 @@ __global__ void __launch_bounds__(256) k_sb_finish(T* Yb, long ldy, int m, int k
     else
       x[i] = (row < m && c < kb) ? Yb[(row + zh) + (long)c * ldy] : zero_<T>();
   }
+  const T dg = threadIdx.x < B ? ps->Rs[threadIdx.x + B * threadIdx.x] : one_<T>();
+  {
+    T mv[B * B / 256], tv[B * B / 256];
+#pragma unroll
+    for (int it = 0; it < B * B / 256; ++it) {
+      mv[it] = ps->Rs[threadIdx.x + 256 * it];
+      tv[it] = ps->Tm[threadIdx.x + 256 * it];
+    }
+#pragma unroll
+    for (int it = 0; it < B * B / 256; ++it) {
+      const int e = threadIdx.x + 256 * it;
+      Mq[e % B][CQ * ((e / B) % 4) + (e / B) / 4] = mv[it];
+      Ts[e % B][e / B] = tv[it];
+    }
+  }
+  if (threadIdx.x < B) dinv[threadIdx.x] = inv_(dg);
   __syncthreads();
   if (row >= kb) quad_row_solve_upper<T, B, false>(x, Mq, dinv, q4);  // (uniform over a quad)
 #pragma unroll
@@ -1094,6 +1116,13 @@ __global__ void __launch_bounds__(256) k_sb_hemm_reduce(const T* Wp, int split, 
   T(*Ws)[B + 1] = sb_carve<T, B + 1>(RC, off);
   T(*Zs)[B + 1] = sb_carve<T, B + 1>(RC, off);
   const int r0 = blockIdx.x * RC;
+  // (the block's rows of Z are requested before the partial sums are walked - that loop waits trip by trip)
+  T zv[RC * B / 256];
+#pragma unroll
+  for (int it = 0; it < RC * B / 256; ++it) {
+    const int idx = threadIdx.x + 256 * it;
+    zv[it] = (r0 + idx % RC < mh && idx / RC < kb) ? Zb[(long)(r0 + idx % RC) + (long)(idx / RC) * ld] : zero_<T>();
+  }
   {
     // partials are row-major: thread t adds up the elements (row t / B + (256 / B) u, column t % B), u < RC B / 256, of every partial in the fixed
     // order p = 0, 1, ...; four partials x all its elements are in flight at a time
@@ -1136,8 +1165,11 @@ __global__ void __launch_bounds__(256) k_sb_hemm_reduce(const T* Wp, int split, 
 #pragma unroll
     for (int u = 0; u < NU; ++u) Ws[rb + RSTEP * u][c] = s[u];
   }
-  block_copy<RC * B>([&](int idx) { return (r0 + idx % RC < mh && idx / RC < kb) ? Zb[(long)(r0 + idx % RC) + (long)(idx / RC) * ld] : zero_<T>(); },
-                     [&](int idx, T v) { Zs[idx % RC][idx / RC] = v; });
+#pragma unroll
+  for (int it = 0; it < RC * B / 256; ++it) {
+    const int idx = threadIdx.x + 256 * it;
+    Zs[idx % RC][idx / RC] = zv[it];
+  }
   __syncthreads();
   for (int idx = threadIdx.x; idx < RC * B; idx += 256) {
     const int r = idx % RC, c = idx / RC;
@@ -1176,20 +1208,39 @@ __global__ void __launch_bounds__(256) k_sb_x(T* Wb, const T* Yb, long ld, int m
   T(*Ys)[B + 1] = sb_carve<T, B + 1>(RC, off);
   T(*Ms)[B + 1] = sb_carve<T, B + 1>(B, off);
   const int r0 = blockIdx.x * RC;
-  block_copy<RC * B>([&](int idx) { return (r0 + idx % RC < mh && idx / RC < kb) ? Yb[(long)(r0 + idx % RC) + (long)(idx / RC) * ld] : zero_<T>(); },
-                     [&](int idx, T v) { Ys[idx % RC][idx / RC] = v; });
-  // M = Z^H A22 Z is Hermitian; the reduced sum (ps->G) is symmetrised here (rounding makes its two triangles differ in the last bit)
-  block_copy<B * B>(
-      [&](int e) {
-        const int i = e % B, j = e / B;
-        T v = 0.5 * (ps->G[i + B * j] + conj_(ps->G[j + B * i]));
-        if (i == j) v = make_<T>(real_(v), 0.0);
-        return v;
-      },
-      [&](int e, T v) { Ms[e % B][e / B] = v; });
-  __syncthreads();
   constexpr int CQ = B / 4;
   const int r = threadIdx.x / 4, q4 = threadIdx.x % 4;
+  // Everything the block reads - its rows of W (updated in place at the end), its rows of Y, M - is requested up front: one round trip.
+  T wold[CQ];
+#pragma unroll
+  for (int c = 0; c < CQ; ++c) wold[c] = (r0 + r < mh && q4 + 4 * c < kb) ? Wb[(long)(r0 + r) + (long)(q4 + 4 * c) * ld] : zero_<T>();
+  constexpr int NY = RC * B / 256, NM = B * B / 256;
+  T yv[NY], g1[NM], g2[NM];
+#pragma unroll
+  for (int it = 0; it < NY; ++it) {
+    const int idx = threadIdx.x + 256 * it;
+    yv[it] = (r0 + idx % RC < mh && idx / RC < kb) ? Yb[(long)(r0 + idx % RC) + (long)(idx / RC) * ld] : zero_<T>();
+  }
+#pragma unroll
+  for (int it = 0; it < NM; ++it) {
+    const int e = threadIdx.x + 256 * it, i = e % B, j = e / B;
+    g1[it] = ps->G[i + B * j];
+    g2[it] = ps->G[j + B * i];
+  }
+#pragma unroll
+  for (int it = 0; it < NY; ++it) {
+    const int idx = threadIdx.x + 256 * it;
+    Ys[idx % RC][idx / RC] = yv[it];
+  }
+  // M = Z^H A22 Z is Hermitian; the reduced sum (ps->G) is symmetrised here (rounding makes its two triangles differ in the last bit)
+#pragma unroll
+  for (int it = 0; it < NM; ++it) {
+    const int e = threadIdx.x + 256 * it, i = e % B, j = e / B;
+    T v = 0.5 * (g1[it] + conj_(g2[it]));
+    if (i == j) v = make_<T>(real_(v), 0.0);
+    Ms[i][j] = v;
+  }
+  __syncthreads();
   T acc[CQ];
 #pragma unroll
   for (int c = 0; c < CQ; ++c) acc[c] = zero_<T>();
@@ -1199,9 +1250,6 @@ __global__ void __launch_bounds__(256) k_sb_x(T* Wb, const T* Yb, long ld, int m
 #pragma unroll
     for (int c = 0; c < CQ; ++c) acc[c] = acc[c] + a * Ms[t][q4 + 4 * c];
   }
-  T wold[CQ];  // (loaded together, then stored: see her2k_tile)
-#pragma unroll
-  for (int c = 0; c < CQ; ++c) wold[c] = (r0 + r < mh && q4 + 4 * c < kb) ? Wb[(long)(r0 + r) + (long)(q4 + 4 * c) * ld] : zero_<T>();
 #pragma unroll
   for (int c = 0; c < CQ; ++c)
     if (r0 + r < mh && q4 + 4 * c < kb) Wb[(long)(r0 + r) + (long)(q4 + 4 * c) * ld] = wold[c] - 0.5 * acc[c];

@@ -881,23 +881,51 @@ __device__ __forceinline__ void trd_rank2k_body(T* A, long lda, const T* W, long
   const int C = t - R * (R + 1) / 2;
   const int tx = threadIdx.x % 16, ty = threadIdx.x / 16;
   const long r0 = (long)jend + (long)R * UT, c0 = (long)jend + (long)C * UT;
+  // A workgroup lives for a handful of memory round trips: the tile's own entries - needed last - are requested first, and the operand panels
+  // of slice k0 + UK while slice k0 is multiplied (round 5: every slice and the read-modify-write used to wait for their own loads in turn).
+  constexpr bool EARLY = sizeof(T) == 8;  // (complex: the 64 extra registers would halve the occupancy - its entries are requested after the loop)
+  T old[4][4];
+  auto fetch_old = [&]() {
+#pragma unroll
+    for (int y = 0; y < 4; ++y)
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        const long r = r0 + tx + 16 * x, c = c0 + ty + 16 * y;
+        old[y][x] = (r < n && c < n && r >= c) ? A[r + c * lda] : make_<T>(0.0, 0.0);
+      }
+  };
+  if constexpr (EARLY) fetch_old();
+  constexpr int NIT = UK * UT / 256;
+  T sv[NIT][4];  // staged operands of one slice: V / W at the tile's rows, conj V / conj W at its columns
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int row = threadIdx.x % UT, k = threadIdx.x / UT + (256 / UT) * it;
+      const bool kin = k0 + k < nb;
+      const long rr = r0 + row, cc = c0 + row;
+      sv[it][0] = kin && rr < n ? A[rr + (long)(j0 + k0 + k) * lda] : make_<T>(0.0, 0.0);
+      sv[it][1] = kin && rr < n ? W[rr + (long)(k0 + k) * ldw] : make_<T>(0.0, 0.0);
+      sv[it][2] = kin && cc < n ? conj_(A[cc + (long)(j0 + k0 + k) * lda]) : make_<T>(0.0, 0.0);
+      sv[it][3] = kin && cc < n ? conj_(W[cc + (long)(k0 + k) * ldw]) : make_<T>(0.0, 0.0);
+    }
+  };
   T acc[4][4];
 #pragma unroll
   for (int x = 0; x < 4; ++x)
 #pragma unroll
     for (int y = 0; y < 4; ++y) acc[x][y] = make_<T>(0.0, 0.0);
+  fetch(0);
   for (int k0 = 0; k0 < nb; k0 += UK) {
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < UK * UT / 256; ++it) {
+    for (int it = 0; it < NIT; ++it) {
       const int row = threadIdx.x % UT, k = threadIdx.x / UT + (256 / UT) * it;
-      const bool kin = k0 + k < nb;
-      const long rr = r0 + row, cc = c0 + row;
-      Vr[k][row] = kin && rr < n ? A[rr + (long)(j0 + k0 + k) * lda] : make_<T>(0.0, 0.0);
-      Wr[k][row] = kin && rr < n ? W[rr + (long)(k0 + k) * ldw] : make_<T>(0.0, 0.0);
-      Vc[k][row] = kin && cc < n ? conj_(A[cc + (long)(j0 + k0 + k) * lda]) : make_<T>(0.0, 0.0);
-      Wc[k][row] = kin && cc < n ? conj_(W[cc + (long)(k0 + k) * ldw]) : make_<T>(0.0, 0.0);
+      Vr[k][row] = sv[it][0];
+      Wr[k][row] = sv[it][1];
+      Vc[k][row] = sv[it][2];
+      Wc[k][row] = sv[it][3];
     }
+    if (k0 + UK < nb) fetch(k0 + UK);  // (uniform)
     __syncthreads();
 #pragma unroll 4
     for (int k = 0; k < UK; ++k) {
@@ -915,14 +943,7 @@ __device__ __forceinline__ void trd_rank2k_body(T* A, long lda, const T* W, long
         for (int y = 0; y < 4; ++y) acc[x][y] = acc[x][y] + vr[x] * wc[y] + wr[x] * vc[y];
     }
   }
-  T old[4][4];  // (the 16 entries are loaded together, then stored: entry by entry every read-modify-write is its own memory round trip)
-#pragma unroll
-  for (int y = 0; y < 4; ++y)
-#pragma unroll
-    for (int x = 0; x < 4; ++x) {
-      const long r = r0 + tx + 16 * x, c = c0 + ty + 16 * y;
-      old[y][x] = (r < n && c < n && r >= c) ? A[r + c * lda] : make_<T>(0.0, 0.0);
-    }
+  if constexpr (!EARLY) fetch_old();
 #pragma unroll
   for (int y = 0; y < 4; ++y)
 #pragma unroll

@@ -66,6 +66,16 @@ __global__ void __launch_bounds__(ZP_THREADS) k_zpotrf_panel(double2* __restrict
   const bool st = stamps != nullptr && blockIdx.x == 0;
   if (st && ftid == 0) stamps[0] = wall_clock64();
   // ---- this thread's row of the panel: loads in flight while the block is factored ----
+  // ---- the diagonal block (rows / columns k0 .. k0 + w of A), identity-padded to 32 x 32: requested first, stored last - its round trip
+  // runs beside the row panel's ----
+  constexpr int NIT = (NBZ * NBZ + ZP_THREADS - 1) / ZP_THREADS;
+  double2 dv4[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int idx = ftid + it * ZP_THREADS, rr = idx % NBZ, c = idx / NBZ;
+    dv4[it] = make_double2(rr == c ? 1.0 : 0.0, 0.0);
+    if (idx < NBZ * NBZ && rr < w && c < w && rr >= c) dv4[it] = A[rr + (long)c * lda];
+  }
   // (sixteen columns are requested together and then stored: written as one predicated load and LDS store per column the loop is compiled into
   // load - wait - store, 32 dependent memory round trips: the 10 us this prologue took in the round-5 time line)
   if (rowthr) {
@@ -78,23 +88,12 @@ __global__ void __launch_bounds__(ZP_THREADS) k_zpotrf_panel(double2* __restrict
       for (int c = 0; c < 16; ++c) xs[c0 + c][tid] = xr[c];
     }
   }
-  // ---- the diagonal block (rows / columns k0 .. k0 + w of A), identity-padded to 32 x 32 ----
-  {
-    constexpr int NIT = (NBZ * NBZ + ZP_THREADS - 1) / ZP_THREADS;
-    double2 dv4[NIT];  // (all of a thread's entries requested together, then stored)
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int idx = ftid + it * ZP_THREADS, rr = idx % NBZ, c = idx / NBZ;
-      dv4[it] = make_double2(rr == c ? 1.0 : 0.0, 0.0);
-      if (idx < NBZ * NBZ && rr < w && c < w && rr >= c) dv4[it] = A[rr + (long)c * lda];
-    }
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int idx = ftid + it * ZP_THREADS, rr = idx % NBZ, c = idx / NBZ;
-      if (idx < NBZ * NBZ) {
-        Lr[rr][c] = dv4[it].x;
-        Li[rr][c] = rr == c ? 0.0 : dv4[it].y;  // the diagonal of a Hermitian matrix is real (LAPACK ignores its imaginary part too)
-      }
+  for (int it = 0; it < NIT; ++it) {
+    const int idx = ftid + it * ZP_THREADS, rr = idx % NBZ, c = idx / NBZ;
+    if (idx < NBZ * NBZ) {
+      Lr[rr][c] = dv4[it].x;
+      Li[rr][c] = rr == c ? 0.0 : dv4[it].y;  // the diagonal of a Hermitian matrix is real (LAPACK ignores its imaginary part too)
     }
   }
   __syncthreads();

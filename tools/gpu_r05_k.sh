@@ -1,4 +1,5 @@
 # Round 5, GPU pass K: compute-unit masks (probe), then the band reduction's look-ahead on masked streams: two-stage tests, config 4 with
+# (NLS_SB_LOOKAHEAD exists only with profiles/r05_rejected/band_lookahead.diff.txt applied: the look-ahead was measured and removed)
 # the look-ahead off / on masked streams / on plain streams / other side-set sizes.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out

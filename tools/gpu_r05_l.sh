@@ -1,4 +1,5 @@
 # Round 5, GPU pass L: kernel trace of a config-4 fit with the band look-ahead: do the chain and the update overlap?
+# (NLS_SB_LOOKAHEAD exists only with profiles/r05_rejected/band_lookahead.diff.txt applied: the look-ahead was measured and removed)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 rm -rf /tmp/trL

@@ -1,4 +1,5 @@
 # Round 5, GPU pass M: panel kernels of the band reduction with 64-row blocks / four threads per row: tests, config 4 (look-ahead off / on),
+# (NLS_SB_LOOKAHEAD exists only with profiles/r05_rejected/band_lookahead.diff.txt applied: the look-ahead was measured and removed)
 # kernel stats of one run.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out

@@ -1,5 +1,7 @@
 // Host side of libneolssvm_hip.so: context, workspace, stage orchestration of the primal path and the C ABI of
 // include/neolssvm_hip.h.  Device code lives in nls_gemm.h / nls_gemm3m.h / nls_kernels.h; the dual path is nls_dual.hip.
+#include <mutex>
+
 #include "nls_host.h"
 #include "nls_kernels.h"
 #include "nls_dual_kernels.h"
@@ -172,7 +174,10 @@ extern "C" int nls_ctx_create(int device, nls_ctx** out) {
     return bail("hipStreamCreate", hipGetErrorString(e));
   // (rocBLAS's real GEMMs through hipBLASLt - Q1 of the two-stage eigendecomposition 43 -> 37.5 ms at n = 1e4; takes effect only if rocBLAS has
   // not read its environment yet: a C host exports ROCBLAS_USE_HIPBLASLT=1 itself; never overrides the caller's choice)
-  setenv("ROCBLAS_USE_HIPBLASLT", "1", 0);
+  {
+    static std::once_flag once;  // (contexts of a group are created on several host threads at once; setenv is not re-entrant)
+    std::call_once(once, [] { setenv("ROCBLAS_USE_HIPBLASLT", "1", 0); });
+  }
   if (rocblas_create_handle(&ctx->blas) != rocblas_status_success) return bail("rocblas_create_handle", "status != success");
   rocblas_set_stream(ctx->blas, ctx->stream);
   {  // the feature map's sincos table (8 KB), computed on the host in long double

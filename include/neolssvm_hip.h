@@ -27,7 +27,8 @@
  *     NLS_ERR_ARG    bad argument               (the Python mirror raises ValueError)
  *     NLS_ERR_HIP    HIP / rocBLAS failure      (RuntimeError)
  *     NLS_ERR_LINALG rocSOLVER info != 0        (numpy.linalg.LinAlgError, like scipy's cho_factor)
- *     NLS_ERR_COMM   the all-reduce hook failed (RuntimeError)
+ *     NLS_ERR_COMM   a collective failed: the all-reduce hook or RCCL returned an error, ANOTHER rank of a sharded call failed (the message
+ *                    names it), or a collective did not complete within the deadline (RuntimeError)
  *   - All matrices are dense, C-contiguous (row-major) float64 unless stated; complex values are
  *     interleaved (re, im) pairs, i.e. numpy complex128.
  *   - Bulk inputs (X, y, s, Xt, Xq) may be HOST or DEVICE pointers; the library asks the HIP runtime
@@ -64,7 +65,7 @@ extern "C" {
 #define NLS_ERR_LINALG 3
 #define NLS_ERR_COMM 4
 
-#define NLS_ABI_VERSION 3
+#define NLS_ABI_VERSION 4
 #define NLS_NUM_TIMINGS 24
 
 typedef struct nls_ctx nls_ctx;
@@ -102,6 +103,23 @@ int nls_comm_get_unique_id(void* id);
 int nls_comm_init_rank(nls_ctx* ctx, const void* id, int rank, int world);
 int nls_comm_destroy(nls_ctx* ctx);
 int nls_comm_allreduce(nls_ctx* ctx, double* host_values, size_t count, int op);
+/* Failure of ONE rank of a sharded call is an error on EVERY rank, never a hang (the reference has nothing distributed; SURVEY.md section 5:
+ * "surface HIP/RCCL errors as status codes"):
+ *   - before every exchange the ranks all-reduce one status slot per rank.  A rank whose local work failed (allocation, launch, argument,
+ *     factorisation) does not leave early: it skips to that vote, and all ranks return from the call at the same point - the failed rank
+ *     with its own code, the others with NLS_ERR_COMM and a message naming the rank and its code (NLS_ERR_LINALG, a property of the shared
+ *     problem, is returned as NLS_ERR_LINALG everywhere).  The communicator stays usable.
+ *   - the host never blocks in the runtime behind a collective: it polls the stream, and gives the communicator up (ncclCommAbort) on an
+ *     asynchronous RCCL error or when the collective has not completed after the time-out (a peer process died or is stuck): NLS_ERR_COMM.
+ *     The context then refuses collective work until it joins a new communicator (nls_comm_init_rank) or leaves (nls_comm_destroy).
+ *     A rank that failed must NOT be restarted by replacing its process image (exec) once it has touched the GPU: exit non-zero, start a child.
+ * nls_comm_set_timeout: seconds > 0, or 0 for the default (environment NLS_COMM_TIMEOUT_S, else 300).  The first collective of a call also
+ * waits for ranks that enter the call late - choose it above the largest skew between the ranks' arrivals.
+ * nls_comm_abort: gives the context's communicator up now (e.g. from a signal handler's deferred work when the job is being cancelled).
+ * nls_comm_state: 0 no communicator, 1 joined, 2 aborted (collective calls fail until nls_comm_init_rank / nls_comm_destroy). */
+int nls_comm_set_timeout(nls_ctx* ctx, double seconds);
+int nls_comm_abort(nls_ctx* ctx);
+int nls_comm_state(const nls_ctx* ctx);
 
 /* ---- device memory plumbing (so a host without a GPU array library can keep inputs resident) -- */
 int nls_device_malloc(nls_ctx* ctx, size_t bytes, void** dptr);
@@ -316,7 +334,10 @@ typedef struct nls_group nls_group;
 typedef struct nls_group_factor nls_group_factor;
 int nls_group_create(const int* devices, int ndev, nls_group** group);
 void nls_group_destroy(nls_group* group);
-/* Message of the last failure of a group call (group == NULL: of nls_group_create); names the rank that failed first. */
+/* Message of the last failure of a group call (group == NULL: of nls_group_create); names the rank that failed first.  A group call
+ * returns - it does not hang - when one member fails: through the status votes above, or, for a failure outside them (an exception on
+ * the member's thread, a failed RCCL call), through the group's abort flag, which the other members' waits poll.  The code returned is
+ * the failing member's own.  If the failure cost members their communicator the group joins a fresh one at its next sharded call. */
 const char* nls_group_last_error(const nls_group* group);
 int nls_group_size(const nls_group* group);
 /* Member context of rank r (owned by the group): pre-step statistics on rank 0, workspace limits, the dual path. */

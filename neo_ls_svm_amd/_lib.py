@@ -17,7 +17,7 @@ _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("NEOLSSVM_HIP_LIB", _HERE / "libneolssvm_hip.so"))
 
 NLS_OK, NLS_ERR_ARG, NLS_ERR_HIP, NLS_ERR_LINALG, NLS_ERR_COMM = 0, 1, 2, 3, 4
-ABI_VERSION = 3
+ABI_VERSION = 4
 FIT_SWEEP_ONLY, FIT_FINISH_IF_BELOW = 1, 2
 COMM_ID_BYTES = 128
 NUM_TIMINGS = 24
@@ -146,6 +146,9 @@ SIGNATURES = {
     "nls_comm_init_rank": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "nls_comm_destroy": (C.c_int, [C.c_void_p]),
     "nls_comm_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
+    "nls_comm_set_timeout": (C.c_int, [C.c_void_p, C.c_double]),
+    "nls_comm_abort": (C.c_int, [C.c_void_p]),
+    "nls_comm_state": (C.c_int, [C.c_void_p]),
     "nls_factor_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "nls_factor_destroy": (C.c_int, [C.c_void_p, C.c_void_p]),
     "nls_device_malloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
@@ -449,6 +452,19 @@ class Context:
 
     def comm_barrier(self):
         self.comm_allreduce([0.0])
+
+    def comm_set_timeout(self, seconds: float):
+        """Deadline of every collective wait (``nls_comm_set_timeout``): after it the communicator is aborted and the call raises
+        ``NlsError`` (NLS_ERR_COMM) instead of waiting for a rank that died or left.  0: ``NLS_COMM_TIMEOUT_S`` / 300 s."""
+        self._check(self.lib.nls_comm_set_timeout(self.handle, float(seconds)))
+
+    def comm_abort(self):
+        """Give the communicator up now (``ncclCommAbort``); collective calls fail until ``comm_init`` / ``comm_destroy``."""
+        self._check(self.lib.nls_comm_abort(self.handle))
+
+    @property
+    def comm_state(self) -> str:
+        return {0: "none", 1: "joined", 2: "aborted"}.get(int(self.lib.nls_comm_state(self.handle)), "?")
 
     _EVD_KINDS = {1: "one-stage real", 2: "one-stage complex", 3: "two-stage real", 4: "two-stage complex", 5: "rocsolver heevd / syevd"}
 

@@ -44,6 +44,8 @@ const RcclApi* rccl_api(std::string* why) {
       api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(sym("ncclGroupStart"));
       api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(sym("ncclGroupEnd"));
       api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
+      api.CommAbort = reinterpret_cast<decltype(api.CommAbort)>(sym("ncclCommAbort"));
+      api.CommGetAsyncError = reinterpret_cast<decltype(api.CommGetAsyncError)>(sym("ncclCommGetAsyncError"));
     }
   });
   if (!ok && why) *why = err;
@@ -67,17 +69,35 @@ extern "C" int nls_comm_destroy(nls_ctx* ctx) {
   if (!ctx) return NLS_ERR_ARG;
   if (ctx->comm) {
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(ctx->stream);  // (nothing collective is pending between calls: every collective is waited for, comm_wait)
     const RcclApi* api = rccl_api(nullptr);
     if (api) (void)api->CommDestroy(ctx->comm);
     ctx->comm = nullptr;
   }
+  ctx->comm_broken = false;
   if (!ctx->allreduce) {
     ctx->rank = 0;
     ctx->world = 1;
   }
   return NLS_OK;
 }
+
+extern "C" int nls_comm_abort(nls_ctx* ctx) {
+  if (!ctx) return NLS_ERR_ARG;
+  if (!ctx->comm) return NLS_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)comm_give_up(ctx, "nls_comm_abort was called");
+  return NLS_OK;
+}
+
+extern "C" int nls_comm_set_timeout(nls_ctx* ctx, double seconds) {
+  if (!ctx) return NLS_ERR_ARG;
+  if (!(seconds >= 0.0) || !std::isfinite(seconds)) return fail(ctx, NLS_ERR_ARG, "nls_comm_set_timeout: seconds must be finite and >= 0 (0: NLS_COMM_TIMEOUT_S / 300 s)");
+  ctx->comm_timeout_s = seconds;
+  return NLS_OK;
+}
+
+extern "C" int nls_comm_state(const nls_ctx* ctx) { return !ctx ? -1 : (ctx->comm_broken ? 2 : (ctx->comm ? 1 : 0)); }
 
 extern "C" int nls_comm_init_rank(nls_ctx* ctx, const void* id, int rank, int world) {
   if (!ctx) return NLS_ERR_ARG;
@@ -89,11 +109,12 @@ extern "C" int nls_comm_init_rank(nls_ctx* ctx, const void* id, int rank, int wo
   HIPCHK(ctx, hipSetDevice(ctx->device));
   ncclUniqueId uid;
   std::memcpy(&uid, id, NLS_COMM_ID_BYTES);
+  if (!ctx->comm_scratch) HIPCHK(ctx, hipMalloc(&ctx->comm_scratch, NLS_COMM_UTIL_MAX * sizeof(double)));  // (before joining: a rank that cannot must not be a member)
   RCCLCHK(ctx, api, api->CommInitRank(&ctx->comm, world, uid, rank));
   ctx->rank = rank;
   ctx->world = world;
+  ctx->comm_broken = false;
   ctx->allreduce = nullptr;  // the communicator replaces a previously registered hook
-  if (!ctx->comm_scratch) HIPCHK(ctx, hipMalloc(&ctx->comm_scratch, NLS_COMM_UTIL_MAX * sizeof(double)));
   return NLS_OK;
 }
 
@@ -101,6 +122,7 @@ extern "C" int nls_comm_allreduce(nls_ctx* ctx, double* host_values, size_t coun
   if (!ctx) return NLS_ERR_ARG;
   if (!host_values || count == 0 || count > NLS_COMM_UTIL_MAX || op < 0 || op > 1)
     return fail(ctx, NLS_ERR_ARG, "nls_comm_allreduce: 1..%d host doubles, op 0|1", NLS_COMM_UTIL_MAX);
+  if (ctx->comm_broken) return comm_refuse_broken(ctx);
   if (!ctx->comm) {
     if (ctx->world > 1) return fail(ctx, NLS_ERR_COMM, "nls_comm_allreduce needs a native communicator (nls_comm_init_rank)");
     return NLS_OK;  // single rank: the values are the result
@@ -108,7 +130,9 @@ extern "C" int nls_comm_allreduce(nls_ctx* ctx, double* host_values, size_t coun
   const RcclApi* api = rccl_api(nullptr);
   HIPCHK(ctx, hipSetDevice(ctx->device));
   HIPCHK(ctx, hipMemcpyAsync(ctx->comm_scratch, host_values, count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  RCCLCHK(ctx, api, api->AllReduce(ctx->comm_scratch, ctx->comm_scratch, count, ncclDouble, op == 0 ? ncclSum : ncclMax, ctx->comm, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // (the caller's buffer is free again; nothing collective is pending here)
+  RCCL_ENQUEUE(ctx, api, api->AllReduce(ctx->comm_scratch, ctx->comm_scratch, count, ncclDouble, op == 0 ? ncclSum : ncclMax, ctx->comm, ctx->stream));
+  NLSCHK(comm_wait(ctx, "ncclAllReduce (nls_comm_allreduce)"));  // bounded: a pageable download behind an unfinished collective would block in the runtime
   HIPCHK(ctx, hipMemcpyAsync(host_values, ctx->comm_scratch, count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return NLS_OK;

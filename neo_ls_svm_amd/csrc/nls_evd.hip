@@ -719,29 +719,21 @@ static int stedc_any(nls_ctx* ctx, int n, double* lam, double* e_work, double* C
 }
 
 // stedc on the (real) tridiagonal matrix.  collective: rank 0 computes, everybody receives (lam, Cr) - the ranks then pair the same
-// eigenvalues with the same basis whatever stedc does on clustered spectra.  A failure on rank 0 (API error or info != 0) travels to all
-// ranks through the broadcast flag instead of leaving them blocked in the collective.
-static int stedc_real(nls_ctx* ctx, int n, double* lam, double* e_work, double* Cr, rocblas_int* dinfo, bool collective) {
+// eigenvalues with the same basis whatever stedc does on clustered spectra.  rc_in: the status of this rank's work since the previous
+// exchange (the tridiagonalisation); together with rank 0's solver status it goes into the vote that guards the two broadcasts, so a
+// failure anywhere - an API error or info != 0 on rank 0 included - is an error on every rank instead of a rank missing from a collective.
+static int stedc_real(nls_ctx* ctx, int n, double* lam, double* e_work, double* Cr, rocblas_int* dinfo, bool collective, int rc_in = NLS_OK) {
   if (!(collective && multi_rank(ctx))) {
+    NLSCHK(rc_in);
     NLSCHK(stedc_any(ctx, n, lam, e_work, Cr, dinfo));
     return check_info(ctx, dinfo, "tridiagonal eigensolver (stedc)");
   }
-  double* flag = nullptr;
-  NLSCHK(ws_get_t(ctx, "evd.flag", 2, &flag));
-  double hflag = 0.0;
-  if (ctx->rank == 0) {
-    const int st = stedc_any(ctx, n, lam, e_work, Cr, dinfo);
-    rocblas_int info = 0;
-    const hipError_t h1 = hipMemcpyAsync(&info, dinfo, sizeof(info), hipMemcpyDeviceToHost, ctx->stream);
-    const hipError_t h2 = hipStreamSynchronize(ctx->stream);
-    hflag = st != NLS_OK ? -1.0 : ((h1 != hipSuccess || h2 != hipSuccess) ? -2.0 : (double)info);
-  }
-  HIPCHK(ctx, hipMemcpyAsync(flag, &hflag, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  NLSCHK(do_broadcast(ctx, flag, 1, 0));
-  HIPCHK(ctx, hipMemcpyAsync(&hflag, flag, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  if (hflag != 0.0)
-    return fail(ctx, NLS_ERR_LINALG, "tridiagonal eigensolver (stedc) on rank 0: %s (code %d)", hflag > 0 ? "no convergence" : "API failure", (int)hflag);
+  int rc = rc_in;
+  if (rc == NLS_OK && ctx->rank == 0) rc = [&]() -> int {
+    NLSCHK(stedc_any(ctx, n, lam, e_work, Cr, dinfo));
+    return check_info(ctx, dinfo, "tridiagonal eigensolver (stedc) on rank 0");
+  }();
+  NLSCHK(comm_vote(ctx, rc, "at the tridiagonal eigensolver (rank 0 solves, every rank receives)"));
   NLSCHK(do_broadcast(ctx, lam, (size_t)n, 0));
   NLSCHK(do_broadcast(ctx, Cr, (size_t)n * n, 0));
   return NLS_OK;
@@ -751,22 +743,29 @@ static int stedc_real(nls_ctx* ctx, int n, double* lam, double* e_work, double* 
 // *used = false: the band reduction met a panel it could not orthogonalise (exactly dependent / zero columns); A has been restored
 // and the caller takes the one-stage path.  collective: see evd_hermitian_core.
 template <class T, int B>
-static int evd_two_stage(nls_ctx* ctx, T* A, int n, double* lam, double* e_work, rocblas_int* dinfo, T* C, bool collective, bool* used) {
+static int evd_two_stage(nls_ctx* ctx, T* A, int n, double* lam, double* e_work, rocblas_int* dinfo, T* C, bool collective, bool* used, int rc_in = NLS_OK,
+                         int* carry = nullptr) {
   constexpr bool CPLX = sizeof(T) == 16;
   *used = false;
+  if (carry) *carry = NLS_OK;  // sharded, *used == false: the status this rank takes into the one-stage path's first vote
+  const bool shared = collective && multi_rank(ctx);  // sharded fit: no early return between exchanges - the status goes into the next vote (comm_vote)
+  if (!shared) NLSCHK(rc_in);
   T *Acopy = nullptr, *tau1 = nullptr, *V2 = nullptr;
   int* dflag = nullptr;
+  int nred = 0;
+  bool fell_back = false, bad = false;
+  static const bool prof = [] { const char* m = std::getenv("NLS_EVD_PROFILE"); return m && m[0] == '1'; }();
+  auto mark = [&](int i) { evd_mark(ctx, i); };
+  int rc = rc_in;
+  if (rc == NLS_OK) rc = [&]() -> int {
   NLSCHK(ws_get_t(ctx, CPLX ? "evd2.Acopy" : "evd2.Acopy_r", (size_t)n * n, &Acopy));
   NLSCHK(ws_get_t(ctx, CPLX ? "evd2.tau1" : "evd2.tau1_r", (size_t)n, &tau1));
   NLSCHK(ws_get_t(ctx, CPLX ? "evd2.V2" : "evd2.V2_r", (size_t)v2_ld(n, B) * v2_cols(n, B), &V2));
   NLSCHK(ws_get_t(ctx, "evd2.flag", 4, &dflag));
   HIPCHK(ctx, hipMemcpyAsync(Acopy, A, sizeof(T) * (size_t)n * n, hipMemcpyDeviceToDevice, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(dflag, 0, 4 * sizeof(int), ctx->stream));
-  int nred = 0;
   unsigned* ctl = nullptr;
   // stage times: nls_evd_stage_ms; NLS_EVD_PROFILE=1 also prints one line on stderr per eigendecomposition
-  static const bool prof = [] { const char* m = std::getenv("NLS_EVD_PROFILE"); return m && m[0] == '1'; }();
-  auto mark = [&](int i) { evd_mark(ctx, i); };
   ctx->evd_kind = 0;
   mark(0);
   // A panel whose columns are dependent to working precision raises the flag (nls_sb.h).  Second attempt: the saved copy again, every
@@ -797,6 +796,7 @@ static int evd_two_stage(nls_ctx* ctx, T* A, int n, double* lam, double* e_work,
     HIPCHK(ctx, hipMemcpyAsync(A, Acopy, sizeof(T) * (size_t)n * n, hipMemcpyDeviceToDevice, ctx->stream));
     if (attempt == 1) {
       ctx->twostage_fallbacks++;
+      fell_back = true;  // (the same matrix on every rank of a sharded fit: the same decision)
       return NLS_OK;
     }
     HIPCHK(ctx, hipMemsetAsync(dflag, 0, 4 * sizeof(int), ctx->stream));
@@ -808,49 +808,69 @@ static int evd_two_stage(nls_ctx* ctx, T* A, int n, double* lam, double* e_work,
   // the saved copy and the one-stage panel takes over (counted in nls_twostage_fallbacks).  In a collective fit the ranks decide together.
   {
     const double scale = std::max(std::sqrt(std::fabs(hinv[1])) * std::sqrt((double)n), std::fabs(hinv[0]));
-    bool bad = hctl[1] != 0 || !std::isfinite(hinv[2]) || !std::isfinite(hinv[3]) || std::fabs(hinv[2] - hinv[0]) > 1e-10 * scale ||
-               std::fabs(hinv[3] - hinv[1]) > 1e-10 * std::fabs(hinv[1]);
+    bad = hctl[1] != 0 || !std::isfinite(hinv[2]) || !std::isfinite(hinv[3]) || std::fabs(hinv[2] - hinv[0]) > 1e-10 * scale ||
+          std::fabs(hinv[3] - hinv[1]) > 1e-10 * std::fabs(hinv[1]);
     if (const char* inj = std::getenv("NLS_CHASE_INJECT_FAILURE"))  // test hook: pretend the check failed
       if (inj[0] == '1') bad = true;
-    if (collective && multi_rank(ctx)) {
+  }
+  return NLS_OK;
+  }();
+  if (shared) {
+    NLSCHK(comm_vote(ctx, rc, "after the reduction to tridiagonal form"));
+    if (!fell_back) {  // the ranks decide together about the chase's invariants (the vote above guards this exchange)
       double* vote = nullptr;
       NLSCHK(ws_get_t(ctx, "evd2.vote", 2, &vote));
       double hv = bad ? 1.0 : 0.0;
       HIPCHK(ctx, hipMemcpyAsync(vote, &hv, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
       NLSCHK(do_allreduce(ctx, vote, 1));
       HIPCHK(ctx, hipMemcpyAsync(&hv, vote, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
       HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
       bad = hv != 0.0;
     }
-    if (bad) {
-      HIPCHK(ctx, hipMemcpyAsync(A, Acopy, sizeof(T) * (size_t)n * n, hipMemcpyDeviceToDevice, ctx->stream));
-      ctx->twostage_fallbacks++;
-      return NLS_OK;
-    }
+  } else {
+    NLSCHK(rc);
   }
+  if (fell_back) return NLS_OK;
   double* Cr = nullptr;
-  if (CPLX)
-    NLSCHK(ws_get_t(ctx, "evd2.Cr", (size_t)n * n, &Cr));
-  else
-    Cr = reinterpret_cast<double*>(C);
-  NLSCHK(stedc_real(ctx, n, lam, e_work, Cr, dinfo, collective));
-  mark(3);
   long c0 = 0, c1 = n;
-  const bool split = collective && multi_rank(ctx);
+  const bool split = shared;
+  rc = NLS_OK;
+  if (bad) {
+    rc = hipMemcpyAsync(A, Acopy, sizeof(T) * (size_t)n * n, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess
+             ? NLS_OK : fail(ctx, NLS_ERR_HIP, "restoring the matrix after a rejected two-stage reduction failed");
+    ctx->twostage_fallbacks++;
+    if (!shared || !carry) return rc;
+    *carry = rc;
+    return NLS_OK;
+  }
+  rc = [&]() -> int {
+    if (CPLX)
+      NLSCHK(ws_get_t(ctx, "evd2.Cr", (size_t)n * n, &Cr));
+    else
+      Cr = reinterpret_cast<double*>(C);
+    return NLS_OK;
+  }();
+  NLSCHK(stedc_real(ctx, n, lam, e_work, Cr, dinfo, collective, rc));
+  mark(3);
   if (split) {
     c0 = (long)n * ctx->rank / ctx->world;
     c1 = (long)n * (ctx->rank + 1) / ctx->world;
   }
-  if (CPLX && c1 > c0) {
-    const long cnt = (c1 - c0) * n;
-    hipLaunchKernelGGL(k_real_to_complex, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream, Cr + c0 * n, cnt,
-                       reinterpret_cast<double2*>(C) + c0 * n);
-    HIPCHK(ctx, hipGetLastError());
-  }
-  NLSCHK((apply_q2<T, B>(ctx, V2, n, C + c0 * n, n, (int)(c1 - c0))));
-  mark(4);
-  NLSCHK(apply_q_blocked<T>(ctx, A, n, n, tau1, C + c0 * n, n, (int)(c1 - c0), B, nred));
-  mark(5);
+  rc = [&]() -> int {
+    if (CPLX && c1 > c0) {
+      const long cnt = (c1 - c0) * n;
+      hipLaunchKernelGGL(k_real_to_complex, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream, Cr + c0 * n, cnt,
+                         reinterpret_cast<double2*>(C) + c0 * n);
+      HIPCHK(ctx, hipGetLastError());
+    }
+    NLSCHK((apply_q2<T, B>(ctx, V2, n, C + c0 * n, n, (int)(c1 - c0))));
+    mark(4);
+    NLSCHK(apply_q_blocked<T>(ctx, A, n, n, tau1, C + c0 * n, n, (int)(c1 - c0), B, nred));
+    mark(5);
+    return fault_point(ctx, "backtransform");
+  }();
+  if (!split) NLSCHK(rc);
   ctx->evd_kind = CPLX ? 4 : 3;
   ctx->evd_n = n;
   if (prof) {
@@ -861,6 +881,7 @@ static int evd_two_stage(nls_ctx* ctx, T* A, int n, double* lam, double* e_work,
                  CPLX ? "complex" : "real", B, c1 - c0, t[0], t[1], t[2], t[3], t[4], t[0] + t[1] + t[2] + t[3] + t[4]);
   }
   if (split) {
+    NLSCHK(comm_vote(ctx, rc, "before the all-gather of the eigenvector blocks"));
     std::vector<size_t> offs((size_t)ctx->world + 1);
     const size_t comps = CPLX ? 2 : 1;
     for (int r = 0; r <= ctx->world; ++r) offs[r] = comps * n * (size_t)((long)n * r / ctx->world);
@@ -874,9 +895,12 @@ static int evd_two_stage(nls_ctx* ctx, T* A, int n, double* lam, double* e_work,
 // (columns) in *Q, which is either A itself (rocSOLVER path) or the workspace "evd.C".
 // collective = true (nls_primal_fit, where every rank holds the same all-reduced matrix): stedc on rank 0 + broadcast,
 // back-transformation split by columns over the ranks, blocks all-gathered (Q bit-identical everywhere).
-static int evd_hermitian_core(nls_ctx* ctx, double2* A, int n, double* lam, double* e_work, rocblas_int* dinfo, double2** Q, bool collective) {
+static int evd_hermitian_core(nls_ctx* ctx, double2* A, int n, double* lam, double* e_work, rocblas_int* dinfo, double2** Q, bool collective, int rc_in) {
+  const bool shared = collective && multi_rank(ctx);  // sharded fit: local failures travel to the next vote instead of returning (comm_vote)
+  if (!shared) NLSCHK(rc_in);
   BLASCHK(ctx, rocblas_set_stream(ctx->blas, ctx->stream));
   if (evd_use_rocsolver() || n < 3) {
+    if (shared) NLSCHK(comm_vote(ctx, rc_in, "before the eigendecomposition"));  // (replicated on every rank: no exchange inside)
     for (int i = 0; i < 5; ++i) evd_mark(ctx, i);
     BLASCHK(ctx, rocsolver_zheevd(ctx->blas, rocblas_evect_original, rocblas_fill_lower, n, reinterpret_cast<rocblas_double_complex*>(A), n, lam,
                                   e_work, dinfo));
@@ -889,21 +913,32 @@ static int evd_hermitian_core(nls_ctx* ctx, double2* A, int n, double* lam, doub
   }
   trd::Z* tau = nullptr;
   double2* C = nullptr;
-  NLSCHK(ws_get_t(ctx, "evd.tau", (size_t)n, &tau));
-  NLSCHK(ws_get_t(ctx, "evd.C", (size_t)n * n, &C));
+  int rc = rc_in;
+  if (rc == NLS_OK) rc = [&]() -> int {
+    NLSCHK(ws_get_t(ctx, "evd.tau", (size_t)n, &tau));
+    NLSCHK(ws_get_t(ctx, "evd.C", (size_t)n * n, &C));
+    return NLS_OK;
+  }();
+  if (!shared) NLSCHK(rc);
   if (evd_use_two_stage(n, true)) {
     bool used = false;
-    NLSCHK((evd_two_stage<trd::Z, 32>(ctx, reinterpret_cast<trd::Z*>(A), n, lam, e_work, dinfo, reinterpret_cast<trd::Z*>(C), collective, &used)));
+    int carry = NLS_OK;
+    NLSCHK((evd_two_stage<trd::Z, 32>(ctx, reinterpret_cast<trd::Z*>(A), n, lam, e_work, dinfo, reinterpret_cast<trd::Z*>(C), collective, &used, rc, &carry)));
     if (used) {
       *Q = C;
       return NLS_OK;
     }
+    rc = carry;  // (sharded: everybody passed the two-stage path's vote, so only a failure after it is still travelling)
   }
-  ctx->evd_kind = 0;
-  evd_mark(ctx, 0);
-  NLSCHK(trd_fused<trd::Z>(ctx, reinterpret_cast<trd::Z*>(A), n, n, lam, e_work, tau));
-  evd_mark(ctx, 1);
-  evd_mark(ctx, 2);
+  double* Cr = nullptr;
+  if (rc == NLS_OK) rc = [&]() -> int {
+    ctx->evd_kind = 0;
+    evd_mark(ctx, 0);
+    NLSCHK(trd_fused<trd::Z>(ctx, reinterpret_cast<trd::Z*>(A), n, n, lam, e_work, tau));
+    evd_mark(ctx, 1);
+    evd_mark(ctx, 2);
+    return ws_get_t(ctx, "evd2.Cr", (size_t)n * n, &Cr);
+  }();
   // The tridiagonal matrix of a Hermitian matrix is REAL (LAPACK convention: the phases live in the reflectors), so its eigenvectors
   // come from dstedc (15 instead of zstedc's 22 ms at n = 4097) and are widened to complex only for the back-transformation.
   // collective: every rank holds the same all-reduced matrix and the tridiagonalisation is bit-reproducible, so the reflectors are
@@ -911,10 +946,12 @@ static int evd_hermitian_core(nls_ctx* ctx, double2* A, int n, double* lam, doub
   // all ranks then pair the same eigenvalues with the same basis whatever rocSOLVER's stedc does on clustered spectra (a failure on
   // rank 0 travels through the broadcast flag: stedc_real).  The back-transformation is split by columns over the ranks and the blocks
   // are all-gathered.
-  const bool split = collective && multi_rank(ctx) && n >= 64;
-  double* Cr = nullptr;
-  NLSCHK(ws_get_t(ctx, "evd2.Cr", (size_t)n * n, &Cr));
-  NLSCHK(stedc_real(ctx, n, lam, e_work, Cr, dinfo, split));
+  const bool split = shared && n >= 64;
+  if (shared && !split) {  // tiny matrices: replicated, no exchange - but the status still has to meet the other ranks'
+    NLSCHK(comm_vote(ctx, rc, "before the tridiagonal eigensolver"));
+    rc = NLS_OK;
+  }
+  NLSCHK(stedc_real(ctx, n, lam, e_work, Cr, dinfo, split, rc));  // (sharded: the vote inside takes rc; else rc is NLS_OK here)
   evd_mark(ctx, 3);
   evd_mark(ctx, 4);
   long c0 = 0, c1 = n;
@@ -922,25 +959,31 @@ static int evd_hermitian_core(nls_ctx* ctx, double2* A, int n, double* lam, doub
     c0 = (long)n * ctx->rank / ctx->world;
     c1 = (long)n * (ctx->rank + 1) / ctx->world;
   }
-  if (c1 > c0) {
-    const long cnt = (c1 - c0) * n;
-    hipLaunchKernelGGL(k_real_to_complex, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream, Cr + c0 * n, cnt, C + c0 * n);
-    HIPCHK(ctx, hipGetLastError());
-  }
-  if (evd_rocsolver_backtransform()) {
-    BLASCHK(ctx, rocsolver_zunmtr(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, n, (rocblas_int)(c1 - c0),
-                                  reinterpret_cast<rocblas_double_complex*>(A), n, reinterpret_cast<rocblas_double_complex*>(tau),
-                                  reinterpret_cast<rocblas_double_complex*>(C + c0 * n), n));
-  } else {
-    NLSCHK(apply_q_blocked<trd::Z>(ctx, reinterpret_cast<trd::Z*>(A), n, n, tau, reinterpret_cast<trd::Z*>(C + c0 * n), n, (int)(c1 - c0)));
-  }
-  evd_mark(ctx, 5);
-  ctx->evd_kind = 2;
-  ctx->evd_n = n;
+  rc = [&]() -> int {
+    if (c1 > c0) {
+      const long cnt = (c1 - c0) * n;
+      hipLaunchKernelGGL(k_real_to_complex, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream, Cr + c0 * n, cnt, C + c0 * n);
+      HIPCHK(ctx, hipGetLastError());
+    }
+    if (evd_rocsolver_backtransform()) {
+      BLASCHK(ctx, rocsolver_zunmtr(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, n, (rocblas_int)(c1 - c0),
+                                    reinterpret_cast<rocblas_double_complex*>(A), n, reinterpret_cast<rocblas_double_complex*>(tau),
+                                    reinterpret_cast<rocblas_double_complex*>(C + c0 * n), n));
+    } else {
+      NLSCHK(apply_q_blocked<trd::Z>(ctx, reinterpret_cast<trd::Z*>(A), n, n, tau, reinterpret_cast<trd::Z*>(C + c0 * n), n, (int)(c1 - c0)));
+    }
+    evd_mark(ctx, 5);
+    ctx->evd_kind = 2;
+    ctx->evd_n = n;
+    return fault_point(ctx, "backtransform");
+  }();
   if (split) {
+    NLSCHK(comm_vote(ctx, rc, "before the all-gather of the eigenvector blocks"));
     std::vector<size_t> offs((size_t)ctx->world + 1);
     for (int r = 0; r <= ctx->world; ++r) offs[r] = (size_t)2 * n * (size_t)((long)n * r / ctx->world);
     NLSCHK(do_allgather_blocks(ctx, reinterpret_cast<double*>(C), offs));
+  } else {
+    NLSCHK(rc);
   }
   *Q = C;
   return NLS_OK;
@@ -992,10 +1035,14 @@ static int evd_symmetric_core(nls_ctx* ctx, double* A, int n, double* lam, doubl
   return NLS_OK;
 }
 
-static int evd_hermitian(nls_ctx* ctx, double2* A, int n, double* lam, double* e_work, rocblas_int* dinfo, double2** Q, bool collective = false) {
+// rc_in (sharded fits): the status of the caller's local work since the previous exchange; it travels into the first vote inside.  The return
+// value is then either a voted failure (every rank has it) or the status of the local tail (evd_unscale), which the caller takes to ITS next vote.
+static int evd_hermitian(nls_ctx* ctx, double2* A, int n, double* lam, double* e_work, rocblas_int* dinfo, double2** Q, bool collective = false,
+                         int rc_in = NLS_OK) {
   double f = 1.0;
-  NLSCHK(evd_prescale(ctx, A, n, 2, &f));
-  NLSCHK(evd_hermitian_core(ctx, A, n, lam, e_work, dinfo, Q, collective));
+  int rc = rc_in;
+  if (rc == NLS_OK) rc = evd_prescale(ctx, A, n, 2, &f);
+  NLSCHK(evd_hermitian_core(ctx, A, n, lam, e_work, dinfo, Q, collective, rc));
   return evd_unscale(ctx, lam, n, f);
 }
 static int evd_symmetric(nls_ctx* ctx, double* A, int n, double* lam, double* e_work, rocblas_int* dinfo, double** Q) {

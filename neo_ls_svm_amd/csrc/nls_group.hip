@@ -21,6 +21,9 @@ struct nls_group {
   std::vector<int> devices;
   std::string err;
   std::vector<nls_group_factor*> factors;
+  // 1 + rank of the first member that failed outside a status vote during the current call: the other members stop waiting for it (comm_wait)
+  std::atomic<int> abort{0};
+  bool rejoin = false;  // a member's communicator was aborted: the next collective call joins the members to a new one first
   // host buffers of ranks > 0 in the sigma-sharded grid (their incumbents' full results), kept between calls: fresh pages cost first-touch faults
   std::vector<std::vector<double>> grid_rows, grid_L, grid_small;
 };
@@ -41,25 +44,78 @@ static int gfail(nls_group* g, int code, const char* fmt, ...) {
   return code;
 }
 
-// fn(rank) on every member: rank 0 on the calling thread, the others on threads of their own.  Returns the first failure in rank order and
-// records its message ("rank r: ...").
+// fn(rank) on every member: rank 0 on the calling thread, the others on threads of their own.  Returns the failure of the rank that failed
+// FIRST of its own accord (not one that merely stopped because a peer had failed) and records its message ("rank r: ...").
+// One member failing must not leave the others waiting in a collective and this call in join(): failures that the
+// ranks' status votes carry end the call on every member at the same point (comm_vote); a member that fails any other way - an exception on
+// its thread included - raises the group's abort flag, which the others' bounded waits poll (comm_wait): they abort their communicators and
+// return NLS_ERR_COMM.  The group then joins a fresh communicator at its next collective call.
 static int fan_out(nls_group* g, const std::function<int(int)>& fn) {
   const int nd = (int)g->ctx.size();
   std::vector<int> rc((size_t)nd, NLS_OK);
+  g->abort.store(0, std::memory_order_release);
+  auto run = [&](int r) {
+    nls_ctx* c = g->ctx[(size_t)r];
+    int code = NLS_OK;
+    try {
+      code = fn(r);
+    } catch (const std::exception& e) {
+      code = fail(c, NLS_ERR_HIP, "exception on the rank's host thread: %s", e.what());
+    } catch (...) {
+      code = fail(c, NLS_ERR_HIP, "unknown exception on the rank's host thread");
+    }
+    if (code != NLS_OK && !c->voted_out) {
+      int none = 0;
+      g->abort.compare_exchange_strong(none, r + 1, std::memory_order_acq_rel);
+    }
+    rc[(size_t)r] = code;
+  };
   std::vector<std::thread> th;
   th.reserve((size_t)nd);
-  for (int r = 1; r < nd; ++r) th.emplace_back([&, r] { rc[(size_t)r] = fn(r); });
-  rc[0] = fn(0);
-  for (auto& t : th) t.join();
-  for (int r = 0; r < nd; ++r)
-    if (rc[(size_t)r] != NLS_OK) {
-      const char* m = nls_last_error(g->ctx[(size_t)r]);
-      return gfail(g, rc[(size_t)r], "rank %d of %d (device %d): %s", r, nd, g->devices[(size_t)r], m && m[0] ? m : "failed");
+  for (int r = 1; r < nd; ++r) {
+    try {
+      th.emplace_back(run, r);
+    } catch (const std::exception& e) {  // no thread for this rank: it fails, the others are told
+      rc[(size_t)r] = fail(g->ctx[(size_t)r], NLS_ERR_HIP, "cannot start the rank's host thread: %s", e.what());
+      int none = 0;
+      g->abort.compare_exchange_strong(none, r + 1, std::memory_order_acq_rel);
     }
-  return NLS_OK;
+  }
+  run(0);
+  for (auto& t : th) t.join();
+  for (nls_ctx* c : g->ctx)
+    if (c->comm_broken) g->rejoin = true;
+  int pick = -1;
+  const int flagged = g->abort.load(std::memory_order_acquire) - 1;
+  if (flagged >= 0 && rc[(size_t)flagged] != NLS_OK) pick = flagged;
+  for (int r = 0; r < nd && pick < 0; ++r)  // a voted failure: the member that returned its own code
+    if (rc[(size_t)r] != NLS_OK && rc[(size_t)r] != NLS_ERR_COMM && !g->ctx[(size_t)r]->vote_victim) pick = r;
+  for (int r = 0; r < nd && pick < 0; ++r)
+    if (rc[(size_t)r] != NLS_OK) pick = r;
+  if (pick < 0) return NLS_OK;
+  const char* m = nls_last_error(g->ctx[(size_t)pick]);
+  return gfail(g, rc[(size_t)pick], "rank %d of %d (device %d): %s", pick, nd, g->devices[(size_t)pick], m && m[0] ? m : "failed");
 }
 
-extern "C" const char* nls_group_last_error(const nls_group* g) { return g ? g->err.c_str() : g_group_create_error.c_str(); }
+// Joins the member contexts to a fresh communicator (group creation; again after a failure that cost a member its communicator).
+static int group_join(nls_group* g) {
+  const int nd = (int)g->ctx.size();
+  for (nls_ctx* c : g->ctx) (void)nls_comm_destroy(c);  // (members that still hold the old one: every collective was waited for, nothing is pending)
+  unsigned char id[NLS_COMM_ID_BYTES];
+  int rc = nls_comm_get_unique_id(id);
+  if (rc != NLS_OK) return gfail(g, rc, "communicator id: %s", nls_last_error(nullptr));
+  rc = fan_out(g, [&](int r) { return nls_comm_init_rank(g->ctx[(size_t)r], id, r, nd); });
+  if (rc == NLS_OK) g->rejoin = false;
+  return rc;
+}
+
+extern "C" const char* nls_group_last_error(const nls_group* g) {
+  if (g) return g->err.c_str();
+  static thread_local std::string copy;  // (nls_group_create may be writing the shared message on another thread)
+  std::lock_guard<std::mutex> lock(g_group_create_mutex);
+  copy = g_group_create_error;
+  return copy.c_str();
+}
 extern "C" int nls_group_size(const nls_group* g) { return g ? (int)g->ctx.size() : 0; }
 extern "C" nls_ctx* nls_group_ctx(nls_group* g, int rank) { return (g && rank >= 0 && rank < (int)g->ctx.size()) ? g->ctx[(size_t)rank] : nullptr; }
 
@@ -93,14 +149,8 @@ extern "C" int nls_group_create(const int* devices, int ndev, nls_group** out) {
     g->devices.push_back(devices[r]);
   }
   if (ndev > 1) {
-    unsigned char id[NLS_COMM_ID_BYTES];
-    int rc = nls_comm_get_unique_id(id);
-    if (rc != NLS_OK) {
-      gfail(nullptr, rc, "communicator id: %s", nls_last_error(nullptr));
-      nls_group_destroy(g);
-      return rc;
-    }
-    rc = fan_out(g, [&](int r) { return nls_comm_init_rank(g->ctx[(size_t)r], id, r, ndev); });
+    for (nls_ctx* c : g->ctx) c->abort_flag = &g->abort;
+    const int rc = group_join(g);
     if (rc != NLS_OK) {
       g_group_create_error = g->err;
       nls_group_destroy(g);
@@ -147,6 +197,7 @@ extern "C" int nls_group_primal_fit(nls_group* g, const nls_primal_fit_args* a) 
   NLSCHK(check_bulk_pointer(g, a->X, "X"));
   NLSCHK(check_bulk_pointer(g, a->y, "y"));
   NLSCHK(check_bulk_pointer(g, a->s, "s"));
+  if (g->rejoin) NLSCHK(group_join(g));  // an earlier failure cost a member its communicator
   return fan_out(g, [&](int r) {
     const int64_t lo = block_lo(a->n, r, nd), hi = block_lo(a->n, r + 1, nd);
     nls_primal_fit_args b = *a;
@@ -208,6 +259,10 @@ extern "C" int nls_group_primal_predict(nls_group* g, const double* X, int64_t m
   if (gf && std::find(g->factors.begin(), g->factors.end(), gf) == g->factors.end())
     return gfail(g, NLS_ERR_ARG, "factor is not a live handle of this group");
   NLSCHK(check_bulk_pointer(g, X, "X"));
+  NLSCHK(check_bulk_pointer(g, beta, "beta"));
+  NLSCHK(check_bulk_pointer(g, L, "L"));
+  NLSCHK(check_bulk_pointer(g, yhat, "yhat"));
+  NLSCHK(check_bulk_pointer(g, sigma, "sigma"));
   const int nd = (int)g->ctx.size();
   return fan_out(g, [&](int r) {
     const int64_t lo = block_lo(m, r, nd), hi = block_lo(m, r + 1, nd);
@@ -426,14 +481,22 @@ extern "C" int nls_group_primal_fit_grid(nls_group* g, const nls_primal_fit_args
     double *beta = nullptr, *L = nullptr, *rows = nullptr, score = 0.0;
   };
   std::vector<Priv> priv((size_t)nd);
+  // (sized from the outputs actually requested; a buffer more than twice what this call needs - n or D dropped - is given back)
+  const bool any_rows = a->loo_residuals || a->loo_leverage || a->loo_std || a->residuals;
+  auto fit = [](std::vector<double>& v, size_t need) {
+    if (v.size() < need || v.capacity() > 2 * need + 1024) {
+      std::vector<double>().swap(v);
+      v.resize(need);
+    }
+  };
   for (int r = 1; r < nd; ++r) {
     auto& rows = g->grid_rows[(size_t)r];
     auto& small = g->grid_small[(size_t)r];
     auto& Lb = g->grid_L[(size_t)r];
-    if (rows.size() < 4 * n) rows.resize(4 * n);
-    if (small.size() < 2 * D1) small.resize(2 * D1);
-    if (a->L && Lb.size() < 2 * D1 * D1) Lb.resize(2 * D1 * D1);
-    priv[(size_t)r].rows = rows.data();
+    fit(rows, any_rows ? 4 * n : 0);
+    fit(small, 2 * D1);
+    fit(Lb, a->L ? 2 * D1 * D1 : 0);
+    priv[(size_t)r].rows = any_rows ? rows.data() : nullptr;
     priv[(size_t)r].beta = small.data();
     priv[(size_t)r].L = a->L ? Lb.data() : nullptr;
   }

@@ -6,7 +6,10 @@
 #include <rocblas/rocblas.h>
 #include <rocsolver/rocsolver.h>
 
+#include <unistd.h>
+
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -32,6 +35,8 @@ struct RcclApi {
   decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
   decltype(&ncclCommInitRank) CommInitRank = nullptr;
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclCommAbort) CommAbort = nullptr;
+  decltype(&ncclCommGetAsyncError) CommGetAsyncError = nullptr;
   decltype(&ncclAllReduce) AllReduce = nullptr;
   decltype(&ncclBroadcast) Broadcast = nullptr;
   decltype(&ncclGroupStart) GroupStart = nullptr;
@@ -70,7 +75,14 @@ struct nls_ctx {
   int rank = 0, world = 1;
   bool solo = false;  // set by the group's sigma-sharded grid: the context fits alone although it has joined the group's communicator
   ncclComm_t comm = nullptr;  // native RCCL communicator (nls_comm_init_rank); takes precedence over the hook
-  double* comm_scratch = nullptr;  // a few doubles on the device for nls_comm_allreduce
+  double* comm_scratch = nullptr;  // a few doubles on the device for nls_comm_allreduce and the status votes (allocated when the context joins)
+  // Failure handling of the collective path ("surface HIP/RCCL errors as status codes"; see comm_wait / comm_vote below)
+  bool comm_broken = false;   // the communicator was aborted (deadline, asynchronous error, a failed group member): collective calls fail until
+                              // nls_comm_init_rank joins a new one (nls_comm_destroy: back to a single rank)
+  bool voted_out = false;     // the last call ended through a status vote: every rank left at the same point, the communicator is intact
+  bool vote_victim = false;   // ... and this rank was fine itself (its error names the rank that was not)
+  double comm_timeout_s = 0;  // > 0: set with nls_comm_set_timeout; else NLS_COMM_TIMEOUT_S, else 300 s
+  std::atomic<int>* abort_flag = nullptr;  // member of a group: 1 + rank of a member that failed outside a vote (the others stop waiting)
   size_t ws_bytes = 0;        // bytes currently held by the workspace arena
   long twostage_rescues = 0;    // eigendecompositions whose band reduction met a degenerate panel and succeeded at the second, perturbed attempt
   long twostage_fallbacks = 0;  // eigendecompositions whose band reduction met a degenerate panel and fell back to the one-stage panel
@@ -242,7 +254,7 @@ struct SpanGuard {  // RAII so early returns still close the span
 
 // ------------------------------------------------------------------------------------------------
 // Collectives of the row-sharded primal fit.  With a native communicator they are RCCL calls enqueued on the
-// library's stream (stream-ordered, no host synchronisation); with only the caller's all-reduce hook the broadcast
+// library's stream, each followed by a bounded wait (comm_wait); with only the caller's all-reduce hook the broadcast
 // and the all-gather are expressed as sums (zeros outside the owned part), which is exact.
 // ------------------------------------------------------------------------------------------------
 #define RCCLCHK(ctx, api, call)                                                                              \
@@ -253,15 +265,103 @@ struct SpanGuard {  // RAII so early returns still close the span
   } while (0)
 
 // A native communicator always takes the collective path, also with one rank (the RCCL calls then run on the device
-// buffers for real: how the single-GPU box validates them); a hook only matters with more than one rank.
-static inline bool multi_rank(const nls_ctx* ctx) { return !ctx->solo && (ctx->comm != nullptr || (ctx->world > 1 && ctx->allreduce)); }
+// buffers for real: how the single-GPU box validates them); a hook only matters with more than one rank.  A context whose
+// communicator was aborted still counts as multi-rank: its collectives fail (NLS_ERR_COMM) instead of silently fitting the shard alone.
+static inline bool multi_rank(const nls_ctx* ctx) {
+  return !ctx->solo && (ctx->comm != nullptr || ctx->comm_broken || (ctx->world > 1 && ctx->allreduce));
+}
+
+// ---- failure handling ---------------------------------------------------------------------------------------------------------------
+// The reference has nothing distributed, so the contract is SURVEY.md section 5's: a failure is a status code on EVERY rank, never a hang.
+//   1. comm_vote: before each exchange the ranks all-reduce one status slot per rank.  A rank whose local work failed (allocation, launch,
+//      argument, factorisation) does not return early - it skips to the next vote and says so; everybody then leaves the call at the same
+//      point (the failed rank with its own code, the others with NLS_ERR_COMM naming it) and the communicator stays usable.
+//   2. comm_wait: the host never blocks inside the runtime behind a collective.  It polls the stream and gives up - aborting the
+//      communicator (ncclCommAbort), which ends the collective's kernel - on an asynchronous RCCL error, when another member of the same
+//      group has failed, or after NLS_COMM_TIMEOUT_S (a peer process died, left the call elsewhere, or is stuck).  Every collective is
+//      followed by this wait, so no later blocking call (a pageable download) can sit behind an unfinished collective.
+static double comm_timeout(const nls_ctx* ctx) {
+  if (ctx->comm_timeout_s > 0) return ctx->comm_timeout_s;
+  if (const char* e = std::getenv("NLS_COMM_TIMEOUT_S")) {
+    const double v = std::atof(e);
+    if (v > 0) return v;
+  }
+  return 300.0;
+}
+
+static double wall();
+
+// Gives the communicator up: ncclCommAbort ends the kernels of the pending collectives; the context keeps its rank / world and refuses
+// collective work until it joins a new communicator.
+static int comm_give_up(nls_ctx* ctx, const char* fmt, ...) {
+  char why[768];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(why, sizeof(why), fmt, ap);
+  va_end(ap);
+  if (ctx->comm) {
+    const RcclApi* api = rccl_api(nullptr);
+    if (api && api->CommAbort) (void)api->CommAbort(ctx->comm);  // (a library without it: the handle is leaked rather than destroyed under a running kernel)
+    ctx->comm = nullptr;
+    const double t0 = wall();  // the aborted kernels leave the stream; bounded - a stream that stays busy is reported, not waited for
+    while (hipStreamQuery(ctx->stream) == hipErrorNotReady && wall() - t0 < 10.0) usleep(200);
+    (void)hipGetLastError();
+  }
+  ctx->comm_broken = true;
+  return fail(ctx, NLS_ERR_COMM, "rank %d of %d: %s - communicator aborted (join a new one with nls_comm_init_rank)", ctx->rank, ctx->world, why);
+}
+
+static int comm_wait(nls_ctx* ctx, const char* what) {
+  if (!ctx->comm) {
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return NLS_OK;
+  }
+  const RcclApi* api = rccl_api(nullptr);
+  const double t0 = wall(), limit = comm_timeout(ctx);
+  for (unsigned long polls = 1;; ++polls) {
+    const hipError_t q = hipStreamQuery(ctx->stream);
+    if (q == hipSuccess) return NLS_OK;
+    (void)hipGetLastError();  // (hipErrorNotReady must not reach the next launch check)
+    if (q != hipErrorNotReady) return comm_give_up(ctx, "%s: the stream failed (%s)", what, hipGetErrorString(q));
+    if ((polls & 31) != 0) continue;
+    if (ctx->abort_flag) {
+      const int who = ctx->abort_flag->load(std::memory_order_acquire);
+      if (who != 0) return comm_give_up(ctx, "%s: rank %d of the group failed", what, who - 1);
+    }
+    if (api && api->CommGetAsyncError) {
+      ncclResult_t ar = ncclSuccess;
+      if (api->CommGetAsyncError(ctx->comm, &ar) == ncclSuccess && ar != ncclSuccess && ar != ncclInProgress)
+        return comm_give_up(ctx, "%s: asynchronous RCCL error: %s", what, api->GetErrorString(ar));
+    }
+    const double waited = wall() - t0;
+    if (waited > limit)
+      return comm_give_up(ctx, "%s did not complete within %g s (NLS_COMM_TIMEOUT_S / nls_comm_set_timeout): a peer rank has failed, has left the call or is stuck",
+                          what, limit);
+    if (waited > 5e-3)
+      usleep(100);
+    else if (waited > 3e-4)
+      std::this_thread::yield();
+  }
+}
+
+#define RCCL_ENQUEUE(ctx, api, call)                                                                       \
+  do {                                                                                                     \
+    ncclResult_t r__ = (call);                                                                             \
+    if (r__ != ncclSuccess) return comm_give_up(ctx, "%s failed: %s (%s:%d)", #call, (api)->GetErrorString(r__), __FILE__, __LINE__); \
+  } while (0)
+
+static inline int comm_refuse_broken(nls_ctx* ctx) {
+  return fail(ctx, NLS_ERR_COMM, "rank %d of %d: the communicator of this context was aborted after an earlier failure - join a new one "
+              "(nls_comm_init_rank) or leave it (nls_comm_destroy)", ctx->rank, ctx->world);
+}
 
 static int do_allreduce(nls_ctx* ctx, double* dbuf, size_t count) {
   if (!multi_rank(ctx)) return NLS_OK;
+  if (ctx->comm_broken) return comm_refuse_broken(ctx);
   if (ctx->comm) {
     const RcclApi* api = rccl_api(nullptr);
-    RCCLCHK(ctx, api, api->AllReduce(dbuf, dbuf, count, ncclDouble, ncclSum, ctx->comm, ctx->stream));
-    return NLS_OK;
+    RCCL_ENQUEUE(ctx, api, api->AllReduce(dbuf, dbuf, count, ncclDouble, ncclSum, ctx->comm, ctx->stream));
+    return comm_wait(ctx, "ncclAllReduce");
   }
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   int rc = ctx->allreduce(dbuf, count, ctx->allreduce_user);
@@ -272,10 +372,11 @@ static int do_allreduce(nls_ctx* ctx, double* dbuf, size_t count) {
 // dbuf[0:count] of rank `root` to every rank.
 static int do_broadcast(nls_ctx* ctx, double* dbuf, size_t count, int root) {
   if (!multi_rank(ctx)) return NLS_OK;
+  if (ctx->comm_broken) return comm_refuse_broken(ctx);
   if (ctx->comm) {
     const RcclApi* api = rccl_api(nullptr);
-    RCCLCHK(ctx, api, api->Broadcast(dbuf, dbuf, count, ncclDouble, root, ctx->comm, ctx->stream));
-    return NLS_OK;
+    RCCL_ENQUEUE(ctx, api, api->Broadcast(dbuf, dbuf, count, ncclDouble, root, ctx->comm, ctx->stream));
+    return comm_wait(ctx, "ncclBroadcast");
   }
   if (ctx->rank != root) HIPCHK(ctx, hipMemsetAsync(dbuf, 0, count * sizeof(double), ctx->stream));
   return do_allreduce(ctx, dbuf, count);
@@ -284,22 +385,93 @@ static int do_broadcast(nls_ctx* ctx, double* dbuf, size_t count, int root) {
 // Rank r owns dbuf[offs[r] : offs[r + 1]) (offs has world + 1 entries, in doubles); afterwards every rank holds all blocks.
 static int do_allgather_blocks(nls_ctx* ctx, double* dbuf, const std::vector<size_t>& offs) {
   if (!multi_rank(ctx)) return NLS_OK;
+  if (ctx->comm_broken) return comm_refuse_broken(ctx);
   if (ctx->comm) {
     const RcclApi* api = rccl_api(nullptr);
-    RCCLCHK(ctx, api, api->GroupStart());
+    RCCL_ENQUEUE(ctx, api, api->GroupStart());
     ncclResult_t first_bad = ncclSuccess;
     for (int r = 0; r < ctx->world && first_bad == ncclSuccess; ++r)
       if (offs[r + 1] > offs[r])
         first_bad = api->Broadcast(dbuf + offs[r], dbuf + offs[r], offs[r + 1] - offs[r], ncclDouble, r, ctx->comm, ctx->stream);
     const ncclResult_t end = api->GroupEnd();  // always: a failed call must not leave the group open
-    if (first_bad != ncclSuccess) return fail(ctx, NLS_ERR_COMM, "ncclBroadcast (all-gather of blocks) failed: %s", api->GetErrorString(first_bad));
-    if (end != ncclSuccess) return fail(ctx, NLS_ERR_COMM, "ncclGroupEnd failed: %s", api->GetErrorString(end));
-    return NLS_OK;
+    if (first_bad != ncclSuccess) return comm_give_up(ctx, "ncclBroadcast (all-gather of blocks) failed: %s", api->GetErrorString(first_bad));
+    if (end != ncclSuccess) return comm_give_up(ctx, "ncclGroupEnd failed: %s", api->GetErrorString(end));
+    return comm_wait(ctx, "all-gather of blocks (grouped ncclBroadcast)");
   }
   const size_t lo = offs[ctx->rank], hi = offs[ctx->rank + 1], tot = offs[ctx->world];
   if (lo > 0) HIPCHK(ctx, hipMemsetAsync(dbuf, 0, lo * sizeof(double), ctx->stream));
   if (tot > hi) HIPCHK(ctx, hipMemsetAsync(dbuf + hi, 0, (tot - hi) * sizeof(double), ctx->stream));
   return do_allreduce(ctx, dbuf, tot);
+}
+
+static const char* nls_code_name(int code) {
+  switch (code) {
+    case NLS_OK: return "NLS_OK";
+    case NLS_ERR_ARG: return "NLS_ERR_ARG";
+    case NLS_ERR_HIP: return "NLS_ERR_HIP";
+    case NLS_ERR_LINALG: return "NLS_ERR_LINALG";
+    case NLS_ERR_COMM: return "NLS_ERR_COMM";
+    default: return "an unknown code";
+  }
+}
+
+// Status vote (see above): `local_rc` is what this rank's work since the previous exchange returned.  One slot per rank, summed: every rank
+// learns WHO failed and with which code.  Returns NLS_OK when everybody is fine; else this rank's own code (its message stands), or
+// NLS_ERR_COMM naming the first failed rank.  Single rank: local_rc.
+static int comm_vote(nls_ctx* ctx, int local_rc, const char* where) {
+  if (!multi_rank(ctx)) return local_rc;
+  if (ctx->voted_out)  // an earlier vote of this call has failed: every rank is on its way out, nobody votes again
+    return local_rc != NLS_OK ? local_rc : fail(ctx, NLS_ERR_COMM, "internal error: a vote %s after a failed vote", where);
+  if (ctx->comm_broken) return local_rc != NLS_OK ? local_rc : comm_refuse_broken(ctx);
+  const int W = ctx->world;
+  if (!ctx->comm_scratch || W > NLS_COMM_UTIL_MAX) return local_rc != NLS_OK ? local_rc : fail(ctx, NLS_ERR_COMM, "status vote %s: no vote buffer", where);
+  std::vector<double> hv((size_t)W, 0.0);
+  hv[(size_t)ctx->rank] = (double)local_rc;
+  const std::string own = ctx->err;  // (a failing vote must not bury the local message)
+  int rc = NLS_OK;
+  if (hipMemcpyAsync(ctx->comm_scratch, hv.data(), sizeof(double) * W, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+      hipStreamSynchronize(ctx->stream) != hipSuccess)  // hv is a local; nothing collective is pending here
+    rc = comm_give_up(ctx, "status vote %s: upload failed", where);
+  if (rc == NLS_OK) rc = do_allreduce(ctx, ctx->comm_scratch, (size_t)W);
+  if (rc == NLS_OK && (hipMemcpyAsync(hv.data(), ctx->comm_scratch, sizeof(double) * W, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                       hipStreamSynchronize(ctx->stream) != hipSuccess))
+    rc = comm_give_up(ctx, "status vote %s: download failed", where);
+  if (rc != NLS_OK) {  // the vote itself failed: the communicator is gone (comm_give_up)
+    if (local_rc == NLS_OK) return rc;
+    ctx->err = own;
+    return local_rc;
+  }
+  int first = -1, nbad = 0;
+  for (int r = 0; r < W; ++r)
+    if (hv[(size_t)r] != 0.0) {
+      if (first < 0) first = r;
+      ++nbad;
+    }
+  if (first < 0) return NLS_OK;
+  ctx->voted_out = true;
+  if (local_rc != NLS_OK) return local_rc;
+  ctx->vote_victim = true;
+  // (a factorisation / eigensolver failure is a property of the shared problem, not of the rank that met it: the same code everywhere)
+  const int code = (int)hv[(size_t)first] == NLS_ERR_LINALG ? NLS_ERR_LINALG : NLS_ERR_COMM;
+  return fail(ctx, code, "rank %d of %d failed with %s %s%s; every rank left the call there (this is rank %d; the communicator stays usable)", first, W,
+              nls_code_name((int)hv[(size_t)first]), where, nbad > 1 ? " (and other ranks with it)" : "", ctx->rank);
+}
+
+// Test hook: NLS_FAULT_INJECT="site", "site:rank" or "site:rank:code" makes the named step of the sharded fit fail on that rank (every rank
+// without one) with NLS_ERR_HIP (or the given code: 3 = NLS_ERR_LINALG) - the asymmetric, local failure the votes exist for.  Read per call.
+// Sites: prepare, gram, evd, backtransform, sweep, select, cholesky.
+static int fault_point(nls_ctx* ctx, const char* site) {
+  const char* e = std::getenv("NLS_FAULT_INJECT");
+  if (!e || !e[0]) return NLS_OK;
+  const size_t ls = std::strlen(site);
+  if (std::strncmp(e, site, ls) != 0 || (e[ls] != 0 && e[ls] != ':')) return NLS_OK;
+  int code = NLS_ERR_HIP;
+  if (e[ls] == ':') {
+    if (std::atoi(e + ls + 1) != ctx->rank) return NLS_OK;
+    if (const char* c2 = std::strchr(e + ls + 1, ':')) code = std::atoi(c2 + 1);
+  }
+  if (code < NLS_ERR_ARG || code > NLS_ERR_COMM) code = NLS_ERR_HIP;
+  return fail(ctx, code, "injected fault at '%s' on rank %d (NLS_FAULT_INJECT)", site, ctx->rank);
 }
 
 // Page-locks a caller's host output buffer for the duration of a call so that its (large) download runs at full PCIe rate instead of

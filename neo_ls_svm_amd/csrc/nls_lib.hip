@@ -1,5 +1,6 @@
 // Host side of libneolssvm_hip.so: context, workspace, stage orchestration of the primal path and the C ABI of
 // include/neolssvm_hip.h.  Device code lives in nls_gemm.h / nls_gemm3m.h / nls_kernels.h; the dual path is nls_dual.hip.
+#include <functional>
 #include <mutex>
 
 #include "nls_host.h"
@@ -264,7 +265,11 @@ extern "C" const char* nls_last_error(const nls_ctx* ctx) { return ctx ? ctx->er
 extern "C" int nls_set_allreduce(nls_ctx* ctx, nls_allreduce_fn fn, void* user, int rank, int world) {
   if (!ctx) return NLS_ERR_ARG;
   if (world < 1 || rank < 0 || rank >= world) return fail(ctx, NLS_ERR_ARG, "bad rank/world %d/%d", rank, world);
-  if (ctx->comm) return fail(ctx, NLS_ERR_ARG, "the context already has a native communicator (nls_comm_destroy first)");
+  if (ctx->comm || ctx->comm_broken) return fail(ctx, NLS_ERR_ARG, "the context already has a native communicator (nls_comm_destroy first)");
+  if (fn && world > 1 && !ctx->comm_scratch) {  // the status votes' buffer (comm_vote): allocated while nothing can be waiting for this rank
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMalloc(&ctx->comm_scratch, NLS_COMM_UTIL_MAX * sizeof(double)));
+  }
   ctx->allreduce = (world > 1) ? fn : nullptr;
   ctx->allreduce_user = user;
   ctx->rank = (fn && world > 1) ? rank : 0;
@@ -409,7 +414,7 @@ extern "C" int nls_featuremap(nls_ctx* ctx, const double* X, int64_t n, int d, c
 struct PrimalState {
   MapParams mp;
   long n = 0, n_pad = 0, rc = 0;  // local rows, padded, rows per chunk
-  double n_total = 0, s_sum = 0, sy_sum = 0;
+  double n_total = 0, s_sum = 0, sy_sum = 0, hn = 0;
   double c = 0;  // 1 / (n_total * D1): the reference's normalised complexity diagonal (_neo_ls_svm.py:117-118)
   const double *dX = nullptr, *dy = nullptr, *ds = nullptr;
   double* s_norm = nullptr;  // n_pad
@@ -444,8 +449,9 @@ static void plan_primal_chunks(nls_ctx* ctx, PrimalState& st, size_t fixed_bytes
   }
 }
 
-// Normalise the weights by the global sum (_neo_ls_svm.py:110) and set c.
-static int primal_prepare(nls_ctx* ctx, PrimalState& st, const double* X, const double* y, const double* s, long n, int d) {
+// Normalise the weights by the global sum (_neo_ls_svm.py:110) and set c.  Two halves around the first exchange of a sharded fit: the local
+// half uploads the inputs and sums this rank's weights, the second all-reduces {sum s, sum s y, n} and normalises.
+static int primal_prepare_local(nls_ctx* ctx, PrimalState& st, const double* X, const double* y, const double* s, long n, int d, double** sums_out) {
   st.n = n;
   st.n_pad = round_up(std::max<long>(n, 1), BM);
   {
@@ -464,8 +470,13 @@ static int primal_prepare(nls_ctx* ctx, PrimalState& st, const double* X, const 
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, ctx->stream, part, nblk, 2L, sums, 0);
     HIPCHK(ctx, hipGetLastError());
   }
-  double hn = (double)n;
-  HIPCHK(ctx, hipMemcpyAsync(sums + 2, &hn, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  st.hn = (double)n;  // (a member: the copy may still be in flight when this returns)
+  HIPCHK(ctx, hipMemcpyAsync(sums + 2, &st.hn, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  *sums_out = sums;
+  return NLS_OK;
+}
+static int primal_prepare_finish(nls_ctx* ctx, PrimalState& st, double* sums) {
+  const long n = st.n, nblk = (n + 255) / 256;
   {
     SpanGuard g(ctx, NLS_T_ALLREDUCE);
     NLSCHK(do_allreduce(ctx, sums, 3));
@@ -493,9 +504,9 @@ static int primal_prepare(nls_ctx* ctx, PrimalState& st, const double* X, const 
   return NLS_OK;
 }
 
-// Phase A: normal equations (packed Gram tiles of F = S phi + border vectors) accumulated over row chunks and
-// all-reduced across ranks.
-static int primal_gram_phase(nls_ctx* ctx, PrimalState& st, double* timings) {
+// Phase A: normal equations (packed Gram tiles of F = S phi + border vectors) accumulated over this rank's row chunks (the all-reduce
+// across ranks follows in primal_front).
+static int primal_gram_local(nls_ctx* ctx, PrimalState& st, double* timings) {
   const MapParams& mp = st.mp;
   st.nt = mp.Kf / BM;
   st.ntri = st.nt * (st.nt + 1) / 2;
@@ -568,6 +579,28 @@ static int primal_gram_phase(nls_ctx* ctx, PrimalState& st, double* timings) {
       }
     }
   }
+  return NLS_OK;
+}
+
+// Everything up to the all-reduced normal equations, shared by nls_primal_fit and nls_gram_only.  In a sharded fit every exchange is preceded
+// by a status vote (comm_vote, nls_host.h): a rank whose local work failed skips to the vote, and all ranks leave together.
+static int primal_front(nls_ctx* ctx, PrimalState& st, int args_rc, const double* X, const double* y, const double* s, long n, int d, const double* shift,
+                        const double* scale, const double* B, int D, double* timings, const std::function<void()>& plan) {
+  double* sums = nullptr;
+  int rc = args_rc;
+  if (rc == NLS_OK) rc = [&]() -> int {
+    NLSCHK(upload_map(ctx, shift, scale, B, d, D, &st.mp));
+    NLSCHK(primal_prepare_local(ctx, st, X, y, s, n, d, &sums));
+    return fault_point(ctx, "prepare");
+  }();
+  NLSCHK(comm_vote(ctx, rc, "before the exchange of the weight sums"));
+  rc = [&]() -> int {
+    NLSCHK(primal_prepare_finish(ctx, st, sums));
+    plan();
+    NLSCHK(primal_gram_local(ctx, st, timings));
+    return fault_point(ctx, "gram");
+  }();
+  NLSCHK(comm_vote(ctx, rc, "before the all-reduce of the normal equations"));
   {
     SpanGuard g(ctx, NLS_T_ALLREDUCE);
     NLSCHK(do_allreduce(ctx, st.gacc, st.gram_elems));
@@ -587,14 +620,14 @@ static int assemble_A(nls_ctx* ctx, const PrimalState& st, double scale, double2
 extern "C" int nls_gram_only(nls_ctx* ctx, const double* X, const double* y, const double* s, int64_t n, int d,
                              const double* shift, const double* scale, const double* B, int D, double* A, double* b) {
   if (!ctx) return NLS_ERR_ARG;
-  if (!X || !y || !s || n < 0) return fail(ctx, NLS_ERR_ARG, "X/y/s NULL or n < 0");
+  ctx->voted_out = ctx->vote_victim = false;
   HIPCHK(ctx, hipSetDevice(ctx->device));
   PrimalState st;
-  NLSCHK(upload_map(ctx, shift, scale, B, d, D, &st.mp));
-  NLSCHK(primal_prepare(ctx, st, X, y, s, n, d));
-  st.rc = pick_row_chunk(ctx, n, st.mp, 0);
-  st.plane_rows = st.rc;
-  NLSCHK(primal_gram_phase(ctx, st, nullptr));
+  const int args_rc = (!X || !y || !s || n < 0) ? fail(ctx, NLS_ERR_ARG, "X/y/s NULL or n < 0") : NLS_OK;
+  NLSCHK(primal_front(ctx, st, args_rc, X, y, s, n, d, shift, scale, B, D, nullptr, [&] {
+    st.rc = pick_row_chunk(ctx, n, st.mp, 0);
+    st.plane_rows = st.rc;
+  }));
   const int D1 = st.mp.D1;
   double2 *Acm = nullptr, *Arm = nullptr, *db = nullptr;
   NLSCHK(ws_get_t(ctx, "evd.A", (size_t)D1 * D1, &Acm));
@@ -886,10 +919,16 @@ extern "C" int nls_zcholesky_only(nls_ctx* ctx, double* A, int n, int* info) {
 extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
   if (!ctx) return NLS_ERR_ARG;
   if (!a) return fail(ctx, NLS_ERR_ARG, "args is NULL");
-  if (!a->X || !a->y || !a->s || !a->gammas) return fail(ctx, NLS_ERR_ARG, "X, y, s and gammas must not be NULL");
-  if (a->n < 1 || a->G < 1) return fail(ctx, NLS_ERR_ARG, "n and G must be >= 1 (n=%ld, G=%d)", (long)a->n, a->G);
-  if (a->gamma_index_in >= a->G) return fail(ctx, NLS_ERR_ARG, "gamma_index_in out of range");
-  if (a->flags & ~(NLS_FIT_SWEEP_ONLY | NLS_FIT_FINISH_IF_BELOW)) return fail(ctx, NLS_ERR_ARG, "unknown flag bits 0x%x", (unsigned)a->flags);
+  ctx->voted_out = ctx->vote_victim = false;
+  // In a sharded fit a rank never leaves between two exchanges on its own (its peers would wait for it): the status of each stretch of local
+  // work - these argument checks included - goes into the vote before the next exchange (comm_vote, nls_host.h).  One rank: plain early returns.
+  const int args_rc = [&]() -> int {
+    if (!a->X || !a->y || !a->s || !a->gammas) return fail(ctx, NLS_ERR_ARG, "X, y, s and gammas must not be NULL");
+    if (a->n < 1 || a->G < 1) return fail(ctx, NLS_ERR_ARG, "n and G must be >= 1 (n=%ld, G=%d)", (long)a->n, a->G);
+    if (a->gamma_index_in >= a->G) return fail(ctx, NLS_ERR_ARG, "gamma_index_in out of range");
+    if (a->flags & ~(NLS_FIT_SWEEP_ONLY | NLS_FIT_FINISH_IF_BELOW)) return fail(ctx, NLS_ERR_ARG, "unknown flag bits 0x%x", (unsigned)a->flags);
+    return NLS_OK;
+  }();
   HIPCHK(ctx, hipSetDevice(ctx->device));
   const double t_start = wall();
   double tm[NLS_NUM_TIMINGS];
@@ -901,46 +940,30 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
   const long n = a->n;
   const int G = a->G, is_clf = a->is_classifier ? 1 : 0;
   Prefault prefault;  // a fresh pageable L_ buffer: its pages are touched by helper threads behind the Gram / eigendecomposition (joined before the download)
-  if (a->L) prefault.start(a->L, sizeof(double2) * (size_t)(a->D + 1) * (size_t)(a->D + 1));
+  if (a->L && args_rc == NLS_OK) prefault.start(a->L, sizeof(double2) * (size_t)(a->D + 1) * (size_t)(a->D + 1));
   static const bool host_marks = [] { const char* m = std::getenv("NLS_HOST_MARKS"); return m && m[0] == '1'; }();
   if (host_marks) std::fprintf(stderr, "[nls host] nls_primal_fit entered at %.3f ms\n", 1e3 * std::fmod(wall(), 1000.0));
-  NLSCHK(upload_map(ctx, a->shift, a->scale, a->B, a->d, a->D, &st.mp));
-  if (host_marks) std::fprintf(stderr, "[nls host] map uploaded at %.3f ms\n", 1e3 * std::fmod(wall(), 1000.0));
   const MapParams& mp = st.mp;
-  const int D1 = mp.D1, Kf = mp.Kf, Np = mp.Np;
-  const int Gp = (int)round_up(G, BN);
-  NLSCHK(primal_prepare(ctx, st, a->X, a->y, a->s, n, a->d));
-  const size_t fixed = 2ull * st.n_pad * Gp * 8 + 6ull * D1 * D1 * 16 + 2ull * Kf * Np * 8 + (size_t)Np * Gp * 8;
-  plan_primal_chunks(ctx, st, fixed);
-  tm[NLS_T_ROW_CHUNK] = (double)st.rc;
+  const int Gp = (int)round_up(std::max(G, 1), BN);
 
-  // ---- phase A: normal equations ---------------------------------------------------------------
-  NLSCHK(primal_gram_phase(ctx, st, tm));
+  // ---- phase A: map, weights, normal equations (two exchanges: the weight sums, the packed Gram block) ----------------------------
+  NLSCHK(primal_front(ctx, st, args_rc, a->X, a->y, a->s, n, a->d, a->shift, a->scale, a->B, a->D, tm, [&] {
+    const size_t fixed = 2ull * st.n_pad * Gp * 8 + 6ull * st.mp.D1 * st.mp.D1 * 16 + 2ull * st.mp.Kf * st.mp.Np * 8 + (size_t)st.mp.Np * Gp * 8;
+    plan_primal_chunks(ctx, st, fixed);
+    tm[NLS_T_ROW_CHUNK] = (double)st.rc;
+  }));
+  const int D1 = mp.D1, Kf = mp.Kf, Np = mp.Np;
+  (void)Kf;
 
   // ---- phase B: EVD of A / c (P4) --------------------------------------------------------------
   double2 *Acm = nullptr, *Qcm = nullptr, *db = nullptr;
   double *lam = nullptr, *evd_e = nullptr, *dgam = nullptr, *R = nullptr;
   rocblas_int* dinfo = nullptr;
   RotBuffers rb;
-  NLSCHK(ws_get_t(ctx, "evd.A", (size_t)D1 * D1, &Acm));
-  NLSCHK(ws_get_t(ctx, "evd.Q", (size_t)D1 * D1, &Qcm));
-  NLSCHK(ws_get_t(ctx, "evd.b", (size_t)D1, &db));
-  NLSCHK(ws_get_t(ctx, "evd.lam", (size_t)D1, &lam));
-  NLSCHK(ws_get_t(ctx, "evd.e", (size_t)D1, &evd_e));
-  NLSCHK(ws_get_t(ctx, "evd.info", 4, &dinfo));
-  NLSCHK(rot_buffers(ctx, mp, &rb));
   HostPin pinL;  // the Gram kernels are in flight: page-lock the L_ output now, behind them
-  if (a->L) pinL.pin(a->L, sizeof(double2) * (size_t)D1 * D1);
   std::vector<double> hnodes, hW;
-  bool compressed = sweep_compression(a->gammas, G, Gp, hnodes, hW);  // final once the smallest eigenvalue is known (below)
+  bool compressed = false;  // final once the smallest eigenvalue is known (below)
   double* Wd = nullptr;
-  NLSCHK(ws_get_t(ctx, "sweep.gammas", (size_t)std::max(G, SWEEP_GN), &dgam));
-  NLSCHK(ws_get_t(ctx, "sweep.R", (size_t)Np * Gp, &R));
-  if (compressed) {
-    NLSCHK(ws_get_t(ctx, "sweep.W", (size_t)SWEEP_GN * Gp, &Wd));
-    HIPCHK(ctx, hipMemcpyAsync(Wd, hW.data(), sizeof(double) * hW.size(), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // hW is a local of this call
-  }
   // Identity complexity matrix (the only one the reference reaches): A / c = Q Lam Q^H with c = 1 / (n (D+1)), Q unitary,
   // leverage s^2 |phi Q|^2 / c.  General C (8(f) #4): C <- C / mean|diag C| / (n (D+1)) (_neo_ls_svm.py:117), C = Lc Lc^H,
   // Lc^-1 A Lc^-H = W Lam W^H, Q = Lc^-H W, which is what eigh(A, b=C) returns (Q^H C Q = I, so lu_solve(C Q, x) = Q^H x):
@@ -950,155 +973,195 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
   const double inv_c = general_C ? 1.0 : 1.0 / st.c;
   double2 *Cn = nullptr, *Lc = nullptr;
   double2* Qev_keep = nullptr;  // the eigenvectors (column-major), also needed for the re-solve at gamma*
+  int rc = [&]() -> int {
+    NLSCHK(ws_get_t(ctx, "evd.A", (size_t)D1 * D1, &Acm));
+    NLSCHK(ws_get_t(ctx, "evd.Q", (size_t)D1 * D1, &Qcm));
+    NLSCHK(ws_get_t(ctx, "evd.b", (size_t)D1, &db));
+    NLSCHK(ws_get_t(ctx, "evd.lam", (size_t)D1, &lam));
+    NLSCHK(ws_get_t(ctx, "evd.e", (size_t)D1, &evd_e));
+    NLSCHK(ws_get_t(ctx, "evd.info", 4, &dinfo));
+    NLSCHK(rot_buffers(ctx, mp, &rb));
+    if (a->L) pinL.pin(a->L, sizeof(double2) * (size_t)D1 * D1);
+    compressed = sweep_compression(a->gammas, G, Gp, hnodes, hW);
+    NLSCHK(ws_get_t(ctx, "sweep.gammas", (size_t)std::max(G, SWEEP_GN), &dgam));
+    NLSCHK(ws_get_t(ctx, "sweep.R", (size_t)Np * Gp, &R));
+    if (compressed) {
+      NLSCHK(ws_get_t(ctx, "sweep.W", (size_t)SWEEP_GN * Gp, &Wd));
+      HIPCHK(ctx, hipMemcpyAsync(Wd, hW.data(), sizeof(double) * hW.size(), hipMemcpyHostToDevice, ctx->stream));
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // hW is a local of this call
+    }
+    return NLS_OK;
+  }();
   {
     SpanGuard g(ctx, NLS_T_EVD);
-    NLSCHK(assemble_A(ctx, st, 1.0, Acm, db));
-    NLSCHK(assemble_A(ctx, st, inv_c, Qcm, nullptr));
-    if (general_C) {
-      NLSCHK(ws_get_t(ctx, "gevd.C", (size_t)D1 * D1, &Cn));
-      NLSCHK(ws_get_t(ctx, "gevd.L", (size_t)D1 * D1, &Lc));
-      double dsum = 0.0;
-      for (int k = 0; k < D1; ++k) dsum += std::fabs(a->Cmat[(size_t)k * D1 + k]);
-      if (!(dsum > 0.0) || !std::isfinite(dsum)) return fail(ctx, NLS_ERR_ARG, "complexity matrix has a zero or non-finite diagonal");
-      const double cscale = 1.0 / (dsum / D1) / (st.n_total * (double)D1);
-      std::vector<double2> hC((size_t)D1 * D1);
-      for (size_t k = 0; k < hC.size(); ++k) hC[k] = make_double2(a->Cmat[k] * cscale, 0.0);  // symmetric: row-major == column-major
-      HIPCHK(ctx, hipMemcpyAsync(Cn, hC.data(), sizeof(double2) * hC.size(), hipMemcpyHostToDevice, ctx->stream));
-      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-      HIPCHK(ctx, hipMemcpyAsync(Lc, Cn, sizeof(double2) * (size_t)D1 * D1, hipMemcpyDeviceToDevice, ctx->stream));
-      BLASCHK(ctx, rocblas_set_stream(ctx->blas, ctx->stream));
-      // (the library's own factorisation: rocsolver_zpotrf is not safe when two contexts fit at the same time, profiles/r04_two_contexts.md)
-      NLSCHK(zpotrf_lower(ctx, ctx->stream, ctx->blas, Lc, D1, D1, reinterpret_cast<int*>(dinfo), 0));
-      NLSCHK(check_info(ctx, dinfo, "Cholesky factorisation of the complexity matrix"));
-      const rocblas_double_complex one(1.0, 0.0);
-      auto* zL = reinterpret_cast<const rocblas_double_complex*>(Lc);
-      auto* zA = reinterpret_cast<rocblas_double_complex*>(Qcm);
-      BLASCHK(ctx, rocblas_ztrsm(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, D1, D1,
-                                 &one, zL, D1, zA, D1));
-      BLASCHK(ctx, rocblas_ztrsm(ctx->blas, rocblas_side_right, rocblas_fill_lower, rocblas_operation_conjugate_transpose,
-                                 rocblas_diagonal_non_unit, D1, D1, &one, zL, D1, zA, D1));
-    }
+    if (rc == NLS_OK) rc = [&]() -> int {
+      NLSCHK(assemble_A(ctx, st, 1.0, Acm, db));
+      NLSCHK(assemble_A(ctx, st, inv_c, Qcm, nullptr));
+      if (general_C) {
+        NLSCHK(ws_get_t(ctx, "gevd.C", (size_t)D1 * D1, &Cn));
+        NLSCHK(ws_get_t(ctx, "gevd.L", (size_t)D1 * D1, &Lc));
+        double dsum = 0.0;
+        for (int k = 0; k < D1; ++k) dsum += std::fabs(a->Cmat[(size_t)k * D1 + k]);
+        if (!(dsum > 0.0) || !std::isfinite(dsum)) return fail(ctx, NLS_ERR_ARG, "complexity matrix has a zero or non-finite diagonal");
+        const double cscale = 1.0 / (dsum / D1) / (st.n_total * (double)D1);
+        std::vector<double2> hC((size_t)D1 * D1);
+        for (size_t k = 0; k < hC.size(); ++k) hC[k] = make_double2(a->Cmat[k] * cscale, 0.0);  // symmetric: row-major == column-major
+        HIPCHK(ctx, hipMemcpyAsync(Cn, hC.data(), sizeof(double2) * hC.size(), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(Lc, Cn, sizeof(double2) * (size_t)D1 * D1, hipMemcpyDeviceToDevice, ctx->stream));
+        BLASCHK(ctx, rocblas_set_stream(ctx->blas, ctx->stream));
+        // (the library's own factorisation: rocsolver_zpotrf is not safe when two contexts fit at the same time, profiles/r04_two_contexts.md)
+        NLSCHK(zpotrf_lower(ctx, ctx->stream, ctx->blas, Lc, D1, D1, reinterpret_cast<int*>(dinfo), 0));
+        NLSCHK(check_info(ctx, dinfo, "Cholesky factorisation of the complexity matrix"));
+        const rocblas_double_complex one(1.0, 0.0);
+        auto* zL = reinterpret_cast<const rocblas_double_complex*>(Lc);
+        auto* zA = reinterpret_cast<rocblas_double_complex*>(Qcm);
+        BLASCHK(ctx, rocblas_ztrsm(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, D1, D1,
+                                   &one, zL, D1, zA, D1));
+        BLASCHK(ctx, rocblas_ztrsm(ctx->blas, rocblas_side_right, rocblas_fill_lower, rocblas_operation_conjugate_transpose,
+                                   rocblas_diagonal_non_unit, D1, D1, &one, zL, D1, zA, D1));
+      }
+      return fault_point(ctx, "evd");
+    }();
     double2* Qev = nullptr;  // eigenvectors: in Qcm (rocSOLVER path) or in the EVD's own workspace
-    NLSCHK(evd_hermitian(ctx, Qcm, D1, lam, evd_e, dinfo, &Qev, true));
-    if (general_C) {
-      const rocblas_double_complex one(1.0, 0.0);
-      BLASCHK(ctx, rocblas_ztrsm(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_conjugate_transpose,
-                                 rocblas_diagonal_non_unit, D1, D1, &one, reinterpret_cast<const rocblas_double_complex*>(Lc), D1,
-                                 reinterpret_cast<rocblas_double_complex*>(Qev), D1));
-    }
-    NLSCHK(build_rot_planes(ctx, mp, Qev, 1L, (long)D1, false, rb));  // column-major Q
-    Qev_keep = Qev;
-    hipLaunchKernelGGL(k_compute_v, dim3((unsigned)Np), dim3(256), 0, ctx->stream, Qev, (long)D1, db, D1, inv_c, rb.vr, rb.vi);
-    if (compressed) {
-      // The interpolation identity needs every pole -lam_j well to the left of the grid: measured through nls_sweep_weights
-      // (tests/test_sweep_compression.py), the interpolant of 1 / (gamma + lam) is exact to rounding (1.8e-15) for lam >= -gamma_min / 8,
-      // 6e-14 at -gamma_min / 4 and 5e-10 at -gamma_min / 2 (the pole is then 0.69 from the first Chebyshev piece).  A / c is positive
-      // semi-definite, so lam_min >= -eps lam_max ~ -1e-12 for the path's matrices (lam_max ~ D + 1); an eigenvalue below
-      // -gamma_min / 8 (degenerate weights: lam_max up to 2 n (D+1)) takes the reference's own formula evaluated directly.
-      double lam0 = 0.0;
-      HIPCHK(ctx, hipMemcpyAsync(&lam0, lam, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-      if (!(lam0 > -0.125 * a->gammas[0])) compressed = false;
-    }
-    Gr = compressed ? SWEEP_GN : Gp;
-    HIPCHK(ctx, hipMemcpyAsync(dgam, compressed ? hnodes.data() : a->gammas, sizeof(double) * (compressed ? SWEEP_GN : G), hipMemcpyHostToDevice,
-                               ctx->stream));
-    const long tot = (long)Np * Gr;
-    hipLaunchKernelGGL(k_rgrid, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, lam, dgam, D1, compressed ? SWEEP_GN : G, Np,
-                       Gr, R);
-    HIPCHK(ctx, hipGetLastError());
+    // (sharded: the status of the stretch above travels into the eigendecomposition's first vote; its exchanges are guarded inside)
+    rc = evd_hermitian(ctx, Qcm, D1, lam, evd_e, dinfo, &Qev, true, rc);
+    if (rc == NLS_OK) rc = [&]() -> int {
+      if (general_C) {
+        const rocblas_double_complex one(1.0, 0.0);
+        BLASCHK(ctx, rocblas_ztrsm(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_conjugate_transpose,
+                                   rocblas_diagonal_non_unit, D1, D1, &one, reinterpret_cast<const rocblas_double_complex*>(Lc), D1,
+                                   reinterpret_cast<rocblas_double_complex*>(Qev), D1));
+      }
+      NLSCHK(build_rot_planes(ctx, mp, Qev, 1L, (long)D1, false, rb));  // column-major Q
+      Qev_keep = Qev;
+      hipLaunchKernelGGL(k_compute_v, dim3((unsigned)Np), dim3(256), 0, ctx->stream, Qev, (long)D1, db, D1, inv_c, rb.vr, rb.vi);
+      if (compressed) {
+        // The interpolation identity needs every pole -lam_j well to the left of the grid: measured through nls_sweep_weights
+        // (tests/test_sweep_compression.py), the interpolant of 1 / (gamma + lam) is exact to rounding (1.8e-15) for lam >= -gamma_min / 8,
+        // 6e-14 at -gamma_min / 4 and 5e-10 at -gamma_min / 2 (the pole is then 0.69 from the first Chebyshev piece).  A / c is positive
+        // semi-definite, so lam_min >= -eps lam_max ~ -1e-12 for the path's matrices (lam_max ~ D + 1); an eigenvalue below
+        // -gamma_min / 8 (degenerate weights: lam_max up to 2 n (D+1)) takes the reference's own formula evaluated directly.
+        double lam0 = 0.0;
+        HIPCHK(ctx, hipMemcpyAsync(&lam0, lam, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if (!(lam0 > -0.125 * a->gammas[0])) compressed = false;
+      }
+      Gr = compressed ? SWEEP_GN : Gp;
+      HIPCHK(ctx, hipMemcpyAsync(dgam, compressed ? hnodes.data() : a->gammas, sizeof(double) * (compressed ? SWEEP_GN : G), hipMemcpyHostToDevice,
+                                 ctx->stream));
+      const long tot = (long)Np * Gr;
+      hipLaunchKernelGGL(k_rgrid, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, lam, dgam, D1, compressed ? SWEEP_GN : G, Np,
+                         Gr, R);
+      HIPCHK(ctx, hipGetLastError());
+      return NLS_OK;
+    }();
   }
 
   // ---- phase C: rotation + sweep per row chunk (P5, P6) ---------------------------------------
   double *U = nullptr, *Gm = nullptr, *num = nullptr, *hs = nullptr;
-  NLSCHK(ws_get_t(ctx, "chunk.U", (size_t)st.rc * Np, &U));
-  NLSCHK(ws_get_t(ctx, "chunk.Gm", (size_t)st.rc * Np, &Gm));
-  NLSCHK(ws_get_t(ctx, "sweep.num", (size_t)st.n_pad * Gp, &num));
-  NLSCHK(ws_get_t(ctx, "sweep.hs", (size_t)st.n_pad * Gp, &hs));
   double *T1 = nullptr, *T2 = nullptr;  // compressed sweep: U Rn and (Gm Rn) / c of one row chunk
-  if (compressed) {
-    NLSCHK(ws_get_t(ctx, "sweep.T1", (size_t)st.rc * SWEEP_GN, &T1));
-    NLSCHK(ws_get_t(ctx, "sweep.T2", (size_t)st.rc * SWEEP_GN, &T2));
-  }
-  static const bool small_sweep = [] { const char* e = std::getenv("NLS_SWEEP_SMALL"); return !(e && e[0] == '0'); }();  // NLS_SWEEP_SMALL=0: the 128-wide tile for every G
-  for (long r0 = 0; r0 < n; r0 += st.rc) {
-    const long rows = std::min<long>(st.rc, n - r0);
-    const long rows_pad = round_up(rows, BM);
-    if (!st.resident) {
-      SpanGuard g(ctx, NLS_T_FEATUREMAP);
-      NLSCHK(launch_featuremap_planes(ctx, mp, st.dX + r0 * mp.d, rows, rows_pad, st.rs + r0, st.Fc, st.Fs));
-      tm[NLS_T_FEATUREMAP_LAUNCHES] += 1;
-      tm[NLS_T_FEATUREMAP_FLOPS] += 2.0 * rows * mp.d * mp.D;
-    }
-    {
-      SpanGuard g(ctx, NLS_T_ROTATE);
-      NLSCHK(launch_rotate(ctx, mp, planes_c(st, r0), planes_s(st, r0), rb.Mr, rb.Mi, rb.mbr, rb.mbi, rb.vr, rb.vi, U, Gm,
-                           st.inv_rs + r0, rows_pad));
-      tm[NLS_T_ROTATE_LAUNCHES] += 1;
-      tm[NLS_T_ROTATE_FLOPS] += 8.0 * rows * (double)D1 * D1;
-    }
-    {
-      SpanGuard g(ctx, NLS_T_SWEEP);
-      if (compressed) {
-        hipLaunchKernelGGL(k_sweep, dim3(1, (unsigned)(rows_pad / BM), 2), dim3(Cfg4::NTHREADS), SMEM_REAL, ctx->stream, U, Gm, Np, R,
-                           SWEEP_GN, inv_c, T1, T2, 0L);
-        hipLaunchKernelGGL(k_sweep, dim3((unsigned)(Gp / BN), (unsigned)(rows_pad / BM), 2), dim3(Cfg4::NTHREADS), SMEM_REAL, ctx->stream,
-                           T1, T2, SWEEP_GN, Wd, Gp, 1.0, num, hs, r0);
-      } else if (small_sweep && G <= 32) {  // short grids (the 32-point grid of the gamma x sigma sweep): the streaming form, 32 columns
-        hipLaunchKernelGGL(k_sweep_small<2>, dim3(1, (unsigned)((rows_pad + 255) / 256), 2), dim3(256), 0, ctx->stream, U, Gm, Np, R, Gp, inv_c, num, hs, Gp, r0, rows_pad);
-      } else if (small_sweep && G <= 64) {
-        hipLaunchKernelGGL(k_sweep_small<4>, dim3(1, (unsigned)((rows_pad + 255) / 256), 2), dim3(256), 0, ctx->stream, U, Gm, Np, R, Gp, inv_c, num, hs, Gp, r0, rows_pad);
-      } else {
-        hipLaunchKernelGGL(k_sweep, dim3((unsigned)(Gp / BN), (unsigned)(rows_pad / BM), 2), dim3(Cfg4::NTHREADS), SMEM_REAL, ctx->stream, U,
-                           Gm, Np, R, Gp, inv_c, num, hs, r0);
-      }
-      HIPCHK(ctx, hipGetLastError());
-      tm[NLS_T_SWEEP_LAUNCHES] += 1;
-      tm[NLS_T_SWEEP_FLOPS] += 4.0 * rows * (double)D1 * G;
-    }
-  }
-
-  // ---- P7: per-gamma errors, selection ---------------------------------------------------------
-  // rows per block of the error reduction: at most 256, fewer for small n so that there are ~4 blocks per CU
-  const int loo_rows = (int)std::max<long>(16, std::min<long>(LOO_ROWS_PER_BLOCK, n / (4L * ctx->cus)));
-  const long nblk = (n + loo_rows - 1) / loo_rows;
   double *part = nullptr, *errs = nullptr;
-  NLSCHK(ws_get_t(ctx, "loo.part", (size_t)nblk * 3 * Gp, &part));
-  NLSCHK(ws_get_t(ctx, "loo.errs", (size_t)3 * Gp, &errs));
-  {
-    SpanGuard g(ctx, NLS_T_LOO);
-    hipLaunchKernelGGL(k_loo_errors, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, num, hs, st.dy, st.s_norm, n, G, Gp, is_clf,
-                       loo_rows, part);
-    hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)((3 * Gp + 31) / 32)), dim3(256), 0, ctx->stream, part, nblk, 3L * Gp, errs, 0);
-    HIPCHK(ctx, hipGetLastError());
-  }
+  if (rc == NLS_OK) rc = [&]() -> int {
+    NLSCHK(ws_get_t(ctx, "chunk.U", (size_t)st.rc * Np, &U));
+    NLSCHK(ws_get_t(ctx, "chunk.Gm", (size_t)st.rc * Np, &Gm));
+    NLSCHK(ws_get_t(ctx, "sweep.num", (size_t)st.n_pad * Gp, &num));
+    NLSCHK(ws_get_t(ctx, "sweep.hs", (size_t)st.n_pad * Gp, &hs));
+    if (compressed) {
+      NLSCHK(ws_get_t(ctx, "sweep.T1", (size_t)st.rc * SWEEP_GN, &T1));
+      NLSCHK(ws_get_t(ctx, "sweep.T2", (size_t)st.rc * SWEEP_GN, &T2));
+    }
+    NLSCHK(fault_point(ctx, "sweep"));
+    const char* ess = std::getenv("NLS_SWEEP_SMALL");  // NLS_SWEEP_SMALL=0: the 128-wide tile for every G (read per call, like the other knobs)
+    const bool small_sweep = !(ess && ess[0] == '0');
+    for (long r0 = 0; r0 < n; r0 += st.rc) {
+      const long rows = std::min<long>(st.rc, n - r0);
+      const long rows_pad = round_up(rows, BM);
+      if (!st.resident) {
+        SpanGuard g(ctx, NLS_T_FEATUREMAP);
+        NLSCHK(launch_featuremap_planes(ctx, mp, st.dX + r0 * mp.d, rows, rows_pad, st.rs + r0, st.Fc, st.Fs));
+        tm[NLS_T_FEATUREMAP_LAUNCHES] += 1;
+        tm[NLS_T_FEATUREMAP_FLOPS] += 2.0 * rows * mp.d * mp.D;
+      }
+      {
+        SpanGuard g(ctx, NLS_T_ROTATE);
+        NLSCHK(launch_rotate(ctx, mp, planes_c(st, r0), planes_s(st, r0), rb.Mr, rb.Mi, rb.mbr, rb.mbi, rb.vr, rb.vi, U, Gm,
+                             st.inv_rs + r0, rows_pad));
+        tm[NLS_T_ROTATE_LAUNCHES] += 1;
+        tm[NLS_T_ROTATE_FLOPS] += 8.0 * rows * (double)D1 * D1;
+      }
+      {
+        SpanGuard g(ctx, NLS_T_SWEEP);
+        if (compressed) {
+          hipLaunchKernelGGL(k_sweep, dim3(1, (unsigned)(rows_pad / BM), 2), dim3(Cfg4::NTHREADS), SMEM_REAL, ctx->stream, U, Gm, Np, R,
+                             SWEEP_GN, inv_c, T1, T2, 0L);
+          hipLaunchKernelGGL(k_sweep, dim3((unsigned)(Gp / BN), (unsigned)(rows_pad / BM), 2), dim3(Cfg4::NTHREADS), SMEM_REAL, ctx->stream,
+                             T1, T2, SWEEP_GN, Wd, Gp, 1.0, num, hs, r0);
+        } else if (small_sweep && G <= 32) {  // short grids (the 32-point grid of the gamma x sigma sweep): the streaming form, 32 columns
+          hipLaunchKernelGGL(k_sweep_small<2>, dim3(1, (unsigned)((rows_pad + 255) / 256), 2), dim3(256), 0, ctx->stream, U, Gm, Np, R, Gp, inv_c, num, hs, Gp, r0, rows_pad);
+        } else if (small_sweep && G <= 64) {
+          hipLaunchKernelGGL(k_sweep_small<4>, dim3(1, (unsigned)((rows_pad + 255) / 256), 2), dim3(256), 0, ctx->stream, U, Gm, Np, R, Gp, inv_c, num, hs, Gp, r0, rows_pad);
+        } else {
+          hipLaunchKernelGGL(k_sweep, dim3((unsigned)(Gp / BN), (unsigned)(rows_pad / BM), 2), dim3(Cfg4::NTHREADS), SMEM_REAL, ctx->stream, U,
+                             Gm, Np, R, Gp, inv_c, num, hs, r0);
+        }
+        HIPCHK(ctx, hipGetLastError());
+        tm[NLS_T_SWEEP_LAUNCHES] += 1;
+        tm[NLS_T_SWEEP_FLOPS] += 4.0 * rows * (double)D1 * G;
+      }
+    }
+
+    // ---- P7: per-gamma errors ------------------------------------------------------------------
+    // rows per block of the error reduction: at most 256, fewer for small n so that there are ~4 blocks per CU
+    const int loo_rows = (int)std::max<long>(16, std::min<long>(LOO_ROWS_PER_BLOCK, n / (4L * ctx->cus)));
+    const long nblk = (n + loo_rows - 1) / loo_rows;
+    NLSCHK(ws_get_t(ctx, "loo.part", (size_t)nblk * 3 * Gp, &part));
+    NLSCHK(ws_get_t(ctx, "loo.errs", (size_t)3 * Gp, &errs));
+    {
+      SpanGuard g(ctx, NLS_T_LOO);
+      hipLaunchKernelGGL(k_loo_errors, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, num, hs, st.dy, st.s_norm, n, G, Gp, is_clf,
+                         loo_rows, part);
+      hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)((3 * Gp + 31) / 32)), dim3(256), 0, ctx->stream, part, nblk, 3L * Gp, errs, 0);
+      HIPCHK(ctx, hipGetLastError());
+    }
+    return NLS_OK;
+  }();
+  NLSCHK(comm_vote(ctx, rc, "before the all-reduce of the per-gamma errors"));
   {
     SpanGuard g(ctx, NLS_T_ALLREDUCE);
     NLSCHK(do_allreduce(ctx, errs, (size_t)3 * Gp));
   }
+
+  // ---- P7: selection (the same arithmetic on the same all-reduced numbers on every rank) -----------
   std::vector<double> herrs((size_t)3 * Gp), hobj((size_t)G);
   double lam_min = 0.0;  // smallest eigenvalue of A / c (of C^-1 A for a general C): the positive-definiteness test of gamma* C + A below
-  HIPCHK(ctx, hipMemcpyAsync(herrs.data(), errs, sizeof(double) * 3 * Gp, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipMemcpyAsync(&lam_min, lam, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  for (int g = 0; g < G; ++g)  // _neo_ls_svm.py:159-165 (same summation order as the reference)
-    hobj[g] = is_clf ? (herrs[Gp + g] + herrs[2 * Gp + g]) + herrs[g] : herrs[g];
   int opt = a->gamma_index_in;
-  if (opt < 0) {
-    // numpy.argmin semantics: first minimum, a NaN wins (first NaN is returned).
-    opt = 0;
-    for (int g = 0; g < G; ++g) {
-      if (std::isnan(hobj[g])) {
-        opt = g;
-        break;
+  double gamma_opt = 0.0;
+  bool finish = false;
+  double *loo_res = nullptr, *loo_lev = nullptr, *loo_std = nullptr, *res = nullptr, *cpart = nullptr, *csum = nullptr;
+  rc = [&]() -> int {
+    HIPCHK(ctx, hipMemcpyAsync(herrs.data(), errs, sizeof(double) * 3 * Gp, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(&lam_min, lam, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int g = 0; g < G; ++g)  // _neo_ls_svm.py:159-165 (same summation order as the reference)
+      hobj[g] = is_clf ? (herrs[Gp + g] + herrs[2 * Gp + g]) + herrs[g] : herrs[g];
+    if (opt < 0) {
+      // numpy.argmin semantics: first minimum, a NaN wins (first NaN is returned).
+      opt = 0;
+      for (int g = 0; g < G; ++g) {
+        if (std::isnan(hobj[g])) {
+          opt = g;
+          break;
+        }
+        if (hobj[g] < hobj[opt]) opt = g;
       }
-      if (hobj[g] < hobj[opt]) opt = g;
     }
-  }
-  const double gamma_opt = a->gammas[opt];
-  const bool finish = !(a->flags & NLS_FIT_SWEEP_ONLY) && !((a->flags & NLS_FIT_FINISH_IF_BELOW) && !(hobj[opt] < a->finish_below));
-  if (a->finished) *a->finished = finish ? 1 : 0;
-  if (!finish) {  // a non-winning sigma of a gamma x sigma grid: the error curve is all that is needed
+    gamma_opt = a->gammas[opt];
+    finish = !(a->flags & NLS_FIT_SWEEP_ONLY) && !((a->flags & NLS_FIT_FINISH_IF_BELOW) && !(hobj[opt] < a->finish_below));
+    return NLS_OK;
+  }();
+  if (rc == NLS_OK && !finish) {  // a non-winning sigma of a gamma x sigma grid: the error curve is all that is needed (no further exchange: every rank
+    if (a->finished) *a->finished = 0;  // decides the same from the same numbers)
     NLSCHK(spans_collect(ctx, tm));
     if (a->lam) HIPCHK(ctx, hipMemcpy(a->lam, lam, sizeof(double) * D1, hipMemcpyDeviceToHost));
     if (a->loo_errors) std::memcpy(a->loo_errors, herrs.data(), sizeof(double) * G);
@@ -1108,36 +1171,39 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
     if (a->timings) std::memcpy(a->timings, tm, sizeof(tm));
     return NLS_OK;
   }
+  if (rc == NLS_OK) rc = [&]() -> int {
+    if (a->finished) *a->finished = 1;
+    // gamma* C + A = c Q^-H (gamma* + Lam) Q^-1 is positive definite iff gamma* + lam_min > 0: the test the reference's cho_factor makes
+    // (_neo_ls_svm.py:177 raises LinAlgError otherwise).  It is made here, from the eigenvalues, because the factorisation itself runs only
+    // when the caller asks for L_ (and then beside everything else, on a side stream).
+    if (!(gamma_opt + lam_min > 0.0))
+      return fail(ctx, NLS_ERR_LINALG, "gamma* C + A is not positive definite at gamma* = %g (smallest eigenvalue of A / c: %g)", gamma_opt, lam_min);
 
-  // gamma* C + A = c Q^-H (gamma* + Lam) Q^-1 is positive definite iff gamma* + lam_min > 0: the test the reference's cho_factor makes
-  // (_neo_ls_svm.py:177 raises LinAlgError otherwise).  It is made here, from the eigenvalues, because the factorisation itself runs only
-  // when the caller asks for L_ (and then beside everything else, on a side stream).
-  if (!(gamma_opt + lam_min > 0.0))
-    return fail(ctx, NLS_ERR_LINALG, "gamma* C + A is not positive definite at gamma* = %g (smallest eigenvalue of A / c: %g)", gamma_opt, lam_min);
-
-  // ---- column of the selected gamma (P7 outputs, P9 sigma) -------------------------------------
-  double *loo_res = nullptr, *loo_lev = nullptr, *loo_std = nullptr, *res = nullptr, *cpart = nullptr, *csum = nullptr;
-  NLSCHK(ws_get_t(ctx, "out.loo_res", (size_t)st.n_pad, &loo_res));
-  NLSCHK(ws_get_t(ctx, "out.loo_lev", (size_t)st.n_pad, &loo_lev));
-  NLSCHK(ws_get_t(ctx, "out.loo_std", (size_t)st.n_pad, &loo_std));
-  NLSCHK(ws_get_t(ctx, "out.res", (size_t)st.n_pad, &res));
-  const long cblk = (n + 255) / 256;
-  NLSCHK(ws_get_t(ctx, "loo.cpart", (size_t)cblk * 2, &cpart));
-  NLSCHK(ws_get_t(ctx, "loo.csum", 4, &csum));
-  const double ybar = st.sy_sum / st.s_sum;
-  {
-    SpanGuard g(ctx, NLS_T_LOO);
-    hipLaunchKernelGGL(k_loo_column, dim3((unsigned)cblk), dim3(256), 0, ctx->stream, num, hs, st.dy, st.s_norm, n, Gp, opt, is_clf,
-                       ybar, loo_res, loo_lev, loo_std, res, cpart);
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, ctx->stream, cpart, cblk, 2L, csum, 0);
-    HIPCHK(ctx, hipGetLastError());
-  }
+    // ---- column of the selected gamma (P7 outputs, P9 sigma) -----------------------------------
+    NLSCHK(fault_point(ctx, "select"));
+    NLSCHK(ws_get_t(ctx, "out.loo_res", (size_t)st.n_pad, &loo_res));
+    NLSCHK(ws_get_t(ctx, "out.loo_lev", (size_t)st.n_pad, &loo_lev));
+    NLSCHK(ws_get_t(ctx, "out.loo_std", (size_t)st.n_pad, &loo_std));
+    NLSCHK(ws_get_t(ctx, "out.res", (size_t)st.n_pad, &res));
+    const long cblk = (n + 255) / 256;
+    NLSCHK(ws_get_t(ctx, "loo.cpart", (size_t)cblk * 2, &cpart));
+    NLSCHK(ws_get_t(ctx, "loo.csum", 4, &csum));
+    const double ybar = st.sy_sum / st.s_sum;
+    {
+      SpanGuard g(ctx, NLS_T_LOO);
+      hipLaunchKernelGGL(k_loo_column, dim3((unsigned)cblk), dim3(256), 0, ctx->stream, num, hs, st.dy, st.s_norm, n, Gp, opt, is_clf,
+                         ybar, loo_res, loo_lev, loo_std, res, cpart);
+      hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, ctx->stream, cpart, cblk, 2L, csum, 0);
+      HIPCHK(ctx, hipGetLastError());
+    }
+    return NLS_OK;
+  }();
+  NLSCHK(comm_vote(ctx, rc, "before the all-reduce of the score sums"));
   {
     SpanGuard g(ctx, NLS_T_ALLREDUCE);
     NLSCHK(do_allreduce(ctx, csum, 2));
   }
-  double hsum[2];
-  HIPCHK(ctx, hipMemcpyAsync(hsum, csum, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  double hsum[2] = {0.0, 0.0};
 
   // ---- P8: re-solve at gamma* -------------------------------------------------------------------
   // The reference re-solves with the Cholesky factor at gamma* "for better accuracy" (_neo_ls_svm.py:176-178).  When the caller asks for L_
@@ -1147,7 +1213,6 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
   // factorisation: beta = Q (v / (gamma* + lam)) from the eigendecomposition - the same (gamma* C + A)^-1 b, A + gamma c I = c Q (Lam + gamma) Q^H -
   // and positive definiteness was checked on the eigenvalues above.  In a collective fit rank 0's beta is broadcast: identical everywhere.
   double2* dbeta = nullptr;
-  NLSCHK(ws_get_t(ctx, "chol.beta", (size_t)D1, &dbeta));
   rocblas_int* dinfo2 = nullptr;
   bool side = false;
   struct SideJoin {  // an early (error) return must not leave the side streams writing into the caller's L
@@ -1159,99 +1224,116 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
   } side_join;
   bool side_copy = false, y_carried = false;
   double2* ysolve = nullptr;  // beta = cho_solve(L_, b): L y = b is carried through the factorisation, L^H beta = y follows the download
-  if (a->L) {
-    if (!ctx->stream2) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));  // (the dual path's look-ahead may have made it)
-    if (!ctx->blas2) {
-      if (rocblas_create_handle(&ctx->blas2) != rocblas_status_success) return fail(ctx, NLS_ERR_HIP, "rocblas_create_handle (side stream) failed");
-      BLASCHK(ctx, rocblas_set_stream(ctx->blas2, ctx->stream2));
-    }
-    for (auto& e : ctx->side_ev)
-      if (!e) HIPCHK(ctx, hipEventCreate(&e));
-    NLSCHK(ws_get_t(ctx, "chol.info2", 4, &dinfo2));
-    side = true;
-    hipStream_t s2 = ctx->stream2;
-    side_join.s = s2;
-    HIPCHK(ctx, hipEventRecord(ctx->side_ev[0], ctx->stream));  // everything that produced Acm / gamma* is behind this point
-    HIPCHK(ctx, hipStreamWaitEvent(s2, ctx->side_ev[0], 0));
-    if (general_C) {  // gamma* C + A (_neo_ls_svm.py:177)
-      const long tot = (long)D1 * D1;
-      hipLaunchKernelGGL(k_axpy_z, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s2, Cn, gamma_opt, tot, Acm);
-    } else {
-      hipLaunchKernelGGL(k_add_diag, dim3((unsigned)((D1 + 255) / 256)), dim3(256), 0, s2, Acm, (long)D1, D1, gamma_opt * st.c);
-    }
-    HIPCHK(ctx, hipGetLastError());
-    // Own blocked right-looking factorisation (nls_zpotrf.h: panels of 64, three launches per panel).  A block column of 512 is final once
-    // its last panel's trailing update has run, and travels to the host on the copy stream - conjugated there: the column-major lower factor L
-    // (A = L L^H) is, byte for byte, the conjugate of the row-major upper factor U = L^H that scipy's cho_factor(lower=False) returns - while
-    // the following block columns are factored.  (Round 3: rocsolver_zpotrf on 512-wide diagonal blocks + rocBLAS ztrsm / zherk, 18 ms at
-    // D + 1 = 4097; a monolithic rocsolver_zpotrf 16.5 ms + 12.7 ms of download in sequence.)
-    constexpr int NBK = 512;
-    const int nblk = (D1 + NBK - 1) / NBK;
-    NLSCHK(ensure_copy_stream(ctx, nblk));
-    side_join.s2 = ctx->copy_stream;
-    NLSCHK(ws_get_t(ctx, "chol.solve", (size_t)D1, &ysolve));
-    NLSCHK(zpotrf_lower(ctx, s2, ctx->blas2, Acm, D1, (long)D1, reinterpret_cast<int*>(dinfo2), NBK, db, ysolve, &y_carried));
-    HIPCHK(ctx, hipEventRecord(ctx->side_ev[1], s2));
-    side_copy = true;
-  }
-  {
-    SpanGuard g(ctx, NLS_T_RESIDUALS);
-    const int nchunks = (D1 + 255) / 256;
-    double2* bpart = nullptr;
-    NLSCHK(ws_get_t(ctx, "chol.bpart", (size_t)nchunks * D1, &bpart));
-    hipLaunchKernelGGL(k_beta_evd_partial, dim3((unsigned)((D1 + 63) / 64), (unsigned)nchunks), dim3(256), 0, ctx->stream, Qev_keep, (long)D1, D1, rb.vr, rb.vi,
-                       lam, gamma_opt, bpart);
-    hipLaunchKernelGGL(k_beta_evd_finish, dim3((unsigned)((D1 + 255) / 256)), dim3(256), 0, ctx->stream, bpart, nchunks, D1, dbeta);
-    HIPCHK(ctx, hipGetLastError());
-  }
-
-  // residuals_ = Re(phi beta) - y (P8) came out of k_loo_column: the sweep's table holds Re(phi beta(gamma)) on the whole grid (round 2 made another
-  // pass over the feature planes for it - 11 ms at c3, and a second feature map when the planes are not resident).
-
-  // ---- outputs ---------------------------------------------------------------------------------
-  {
-    SpanGuard g(ctx, NLS_T_DOWNLOAD);
-    auto d2h = [&](void* dst, const void* src, size_t bytes) -> int {
-      if (dst) HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
-      return NLS_OK;
-    };
-    NLSCHK(d2h(a->lam, lam, sizeof(double) * D1));
-    NLSCHK(d2h(a->loo_residuals, loo_res, sizeof(double) * n));
-    NLSCHK(d2h(a->loo_leverage, loo_lev, sizeof(double) * n));
-    NLSCHK(d2h(a->loo_std, loo_std, sizeof(double) * n));
-    NLSCHK(d2h(a->residuals, res, sizeof(double) * n));
-  }
-  if (side_copy) {  // everything else is enqueued: the block columns of L_ now follow the factorisation (pageable memory: each copy blocks this thread)
-    prefault.join();
-    NLSCHK(download_block_columns(ctx, a->L, Acm, D1, (long)D1, sizeof(double2), 512, true));
-    HIPCHK(ctx, hipEventRecord(ctx->side_ev[2], ctx->copy_stream));
-  }
-  if (side_copy) {
-    // beta = cho_solve(L_, b) (_neo_ls_svm.py:178).  The copy stream has conjugated the factor in place on its way out (Acm now holds
-    // Lc = conj(L), i.e. scipy's upper factor read column-major), so: L x = b <=> Lc conj(x) = conj(b);  L^H beta = x <=> Lc^T beta = x.
-    hipStream_t s2 = ctx->stream2;
-    double2* tmp = ysolve;
-    HIPCHK(ctx, hipStreamWaitEvent(s2, ctx->side_ev[2], 0));
-    if (y_carried) {  // y = L^-1 b came out of the factorisation: L^H beta = y against the conjugated factor
-      NLSCHK(zpotrf_solve_conj_tail(ctx, s2, Acm, D1, (long)D1, tmp));
-    } else {  // (NLS_POTRF=rocsolver)
-      const auto* zL = reinterpret_cast<const rocblas_double_complex*>(Acm);
-      hipLaunchKernelGGL(k_conj_vec, dim3((unsigned)((D1 + 255) / 256)), dim3(256), 0, s2, db, D1, tmp);
+  rc = [&]() -> int {
+    HIPCHK(ctx, hipMemcpyAsync(hsum, csum, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    NLSCHK(ws_get_t(ctx, "chol.beta", (size_t)D1, &dbeta));
+    if (a->L) {
+      NLSCHK(fault_point(ctx, "cholesky"));
+      if (!ctx->stream2) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));  // (the dual path's look-ahead may have made it)
+      if (!ctx->blas2) {
+        if (rocblas_create_handle(&ctx->blas2) != rocblas_status_success) return fail(ctx, NLS_ERR_HIP, "rocblas_create_handle (side stream) failed");
+        BLASCHK(ctx, rocblas_set_stream(ctx->blas2, ctx->stream2));
+      }
+      for (auto& e : ctx->side_ev)
+        if (!e) HIPCHK(ctx, hipEventCreate(&e));
+      NLSCHK(ws_get_t(ctx, "chol.info2", 4, &dinfo2));
+      side = true;
+      hipStream_t s2 = ctx->stream2;
+      side_join.s = s2;
+      HIPCHK(ctx, hipEventRecord(ctx->side_ev[0], ctx->stream));  // everything that produced Acm / gamma* is behind this point
+      HIPCHK(ctx, hipStreamWaitEvent(s2, ctx->side_ev[0], 0));
+      if (general_C) {  // gamma* C + A (_neo_ls_svm.py:177)
+        const long tot = (long)D1 * D1;
+        hipLaunchKernelGGL(k_axpy_z, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s2, Cn, gamma_opt, tot, Acm);
+      } else {
+        hipLaunchKernelGGL(k_add_diag, dim3((unsigned)((D1 + 255) / 256)), dim3(256), 0, s2, Acm, (long)D1, D1, gamma_opt * st.c);
+      }
       HIPCHK(ctx, hipGetLastError());
-      BLASCHK(ctx, rocblas_ztrsv(ctx->blas2, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, D1, zL, D1,
-                                 reinterpret_cast<rocblas_double_complex*>(tmp), 1));
-      hipLaunchKernelGGL(k_conj_vec, dim3((unsigned)((D1 + 255) / 256)), dim3(256), 0, s2, tmp, D1, tmp);
-      HIPCHK(ctx, hipGetLastError());
-      BLASCHK(ctx, rocblas_ztrsv(ctx->blas2, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, D1, zL, D1,
-                                 reinterpret_cast<rocblas_double_complex*>(tmp), 1));
+      // Own blocked right-looking factorisation (nls_zpotrf.h: panels of 64, three launches per panel).  A block column of 512 is final once
+      // its last panel's trailing update has run, and travels to the host on the copy stream - conjugated there: the column-major lower factor L
+      // (A = L L^H) is, byte for byte, the conjugate of the row-major upper factor U = L^H that scipy's cho_factor(lower=False) returns - while
+      // the following block columns are factored.  (Round 3: rocsolver_zpotrf on 512-wide diagonal blocks + rocBLAS ztrsm / zherk, 18 ms at
+      // D + 1 = 4097; a monolithic rocsolver_zpotrf 16.5 ms + 12.7 ms of download in sequence.)
+      constexpr int NBK = 512;
+      const int nblk = (D1 + NBK - 1) / NBK;
+      NLSCHK(ensure_copy_stream(ctx, nblk));
+      side_join.s2 = ctx->copy_stream;
+      NLSCHK(ws_get_t(ctx, "chol.solve", (size_t)D1, &ysolve));
+      NLSCHK(zpotrf_lower(ctx, s2, ctx->blas2, Acm, D1, (long)D1, reinterpret_cast<int*>(dinfo2), NBK, db, ysolve, &y_carried));
+      HIPCHK(ctx, hipEventRecord(ctx->side_ev[1], s2));
+      side_copy = true;
     }
-    HIPCHK(ctx, hipEventRecord(ctx->side_ev[3], s2));
-    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_ev[3], 0));
-    HIPCHK(ctx, hipMemcpyAsync(dbeta, tmp, sizeof(double2) * D1, hipMemcpyDeviceToDevice, ctx->stream));
-  }
+    {
+      SpanGuard g(ctx, NLS_T_RESIDUALS);
+      const int nchunks = (D1 + 255) / 256;
+      double2* bpart = nullptr;
+      NLSCHK(ws_get_t(ctx, "chol.bpart", (size_t)nchunks * D1, &bpart));
+      hipLaunchKernelGGL(k_beta_evd_partial, dim3((unsigned)((D1 + 63) / 64), (unsigned)nchunks), dim3(256), 0, ctx->stream, Qev_keep, (long)D1, D1, rb.vr, rb.vi,
+                         lam, gamma_opt, bpart);
+      hipLaunchKernelGGL(k_beta_evd_finish, dim3((unsigned)((D1 + 255) / 256)), dim3(256), 0, ctx->stream, bpart, nchunks, D1, dbeta);
+      HIPCHK(ctx, hipGetLastError());
+    }
+
+    // residuals_ = Re(phi beta) - y (P8) came out of k_loo_column: the sweep's table holds Re(phi beta(gamma)) on the whole grid (round 2 made another
+    // pass over the feature planes for it - 11 ms at c3, and a second feature map when the planes are not resident).
+
+    // ---- outputs -------------------------------------------------------------------------------
+    {
+      SpanGuard g(ctx, NLS_T_DOWNLOAD);
+      auto d2h = [&](void* dst, const void* src, size_t bytes) -> int {
+        if (dst) HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        return NLS_OK;
+      };
+      NLSCHK(d2h(a->lam, lam, sizeof(double) * D1));
+      NLSCHK(d2h(a->loo_residuals, loo_res, sizeof(double) * n));
+      NLSCHK(d2h(a->loo_leverage, loo_lev, sizeof(double) * n));
+      NLSCHK(d2h(a->loo_std, loo_std, sizeof(double) * n));
+      NLSCHK(d2h(a->residuals, res, sizeof(double) * n));
+    }
+    if (side_copy) {  // everything else is enqueued: the block columns of L_ now follow the factorisation (pageable memory: each copy blocks this thread)
+      prefault.join();
+      NLSCHK(download_block_columns(ctx, a->L, Acm, D1, (long)D1, sizeof(double2), 512, true));
+      HIPCHK(ctx, hipEventRecord(ctx->side_ev[2], ctx->copy_stream));
+    }
+    if (side_copy) {
+      // beta = cho_solve(L_, b) (_neo_ls_svm.py:178).  The copy stream has conjugated the factor in place on its way out (Acm now holds
+      // Lc = conj(L), i.e. scipy's upper factor read column-major), so: L x = b <=> Lc conj(x) = conj(b);  L^H beta = x <=> Lc^T beta = x.
+      hipStream_t s2 = ctx->stream2;
+      double2* tmp = ysolve;
+      HIPCHK(ctx, hipStreamWaitEvent(s2, ctx->side_ev[2], 0));
+      if (y_carried) {  // y = L^-1 b came out of the factorisation: L^H beta = y against the conjugated factor
+        NLSCHK(zpotrf_solve_conj_tail(ctx, s2, Acm, D1, (long)D1, tmp));
+      } else {  // (NLS_POTRF=rocsolver)
+        const auto* zL = reinterpret_cast<const rocblas_double_complex*>(Acm);
+        hipLaunchKernelGGL(k_conj_vec, dim3((unsigned)((D1 + 255) / 256)), dim3(256), 0, s2, db, D1, tmp);
+        HIPCHK(ctx, hipGetLastError());
+        BLASCHK(ctx, rocblas_ztrsv(ctx->blas2, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, D1, zL, D1,
+                                   reinterpret_cast<rocblas_double_complex*>(tmp), 1));
+        hipLaunchKernelGGL(k_conj_vec, dim3((unsigned)((D1 + 255) / 256)), dim3(256), 0, s2, tmp, D1, tmp);
+        HIPCHK(ctx, hipGetLastError());
+        BLASCHK(ctx, rocblas_ztrsv(ctx->blas2, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit, D1, zL, D1,
+                                   reinterpret_cast<rocblas_double_complex*>(tmp), 1));
+      }
+      HIPCHK(ctx, hipEventRecord(ctx->side_ev[3], s2));
+      HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_ev[3], 0));
+      HIPCHK(ctx, hipMemcpyAsync(dbeta, tmp, sizeof(double2) * D1, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    if (side && multi_rank(ctx)) {
+      // sharded: rank 0's factorisation is judged BEFORE its beta is broadcast - a non-positive pivot goes into the vote below and every rank
+      // raises the same LinAlgError (one rank: the check after the outputs, as before, so that the side streams keep running beside them)
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream2));
+      rocblas_int info2 = 0;
+      HIPCHK(ctx, hipMemcpy(&info2, dinfo2, sizeof(info2), hipMemcpyDeviceToHost));
+      if (info2 != 0) return fail(ctx, NLS_ERR_LINALG, "Cholesky factorisation of gamma* C + A: pivot %d is not positive (matrix not positive definite)", (int)info2);
+    }
+    return NLS_OK;
+  }();
   if (multi_rank(ctx)) {
+    NLSCHK(comm_vote(ctx, rc, "before the broadcast of rank 0's beta"));
     SpanGuard g(ctx, NLS_T_ALLREDUCE);
     NLSCHK(do_broadcast(ctx, reinterpret_cast<double*>(dbeta), (size_t)2 * D1, 0));
+  } else {
+    NLSCHK(rc);
   }
   if (a->beta) HIPCHK(ctx, hipMemcpyAsync(a->beta, dbeta, sizeof(double2) * D1, hipMemcpyDeviceToHost, ctx->stream));
   if (side) {  // join the side streams; their stage times go into the cholesky / download slots

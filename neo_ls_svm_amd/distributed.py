@@ -47,17 +47,23 @@ def _rendezvous_files(key: str | None) -> tuple[Path, Path | None]:
     return base / f"nls_rccl_id_{os.getppid()}_{port}_{run}_{attempt}", base / f"nls_rccl_id_port{port}_{run}_{attempt}"
 
 
-def _launch_nonce() -> bytes:
+def _launch_nonce(explicit_key: bool = False) -> bytes:
     """What the ranks of ONE launch share and a previous launch does not: NLS_RENDEZVOUS_NONCE when the launcher sets it, else the
-    launcher's process id (all ranks of a launch are children of one launcher process), the rendezvous port, the elastic run id and
-    restart count.  Rank 0 writes it into the payload; a reader joins only a payload that carries ITS OWN nonce - so an id file that a
-    dead launch left under the same explicit key (its post-barrier unlink never ran) is not joined by the next launch's ranks while
-    they wait for their rank 0 to replace it."""
+    rendezvous address and port, the elastic run id and restart count - and, for an automatic (launcher-derived) name only, the launcher's
+    process id.  Rank 0 writes it into the payload; a reader joins only a payload that carries ITS OWN nonce - so an id file that a dead
+    launch left under the same explicit key (its post-barrier unlink never ran) is not joined by the next launch's ranks while they wait for
+    their rank 0 to replace it.
+    An explicit key is the rendezvous of ranks that need NOT be children of one launcher (several nodes on a shared NLS_RENDEZVOUS_DIR,
+    per-node daemons of mpirun / srun, hand-started ranks): their parent pids differ, so the pid is not part of their nonce - only values
+    every rank of the launch has (two launches that share key, address, port and run id must set NLS_RENDEZVOUS_NONCE)."""
     explicit = os.environ.get("NLS_RENDEZVOUS_NONCE")
     if explicit:
         return explicit.encode()
     port, run = os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none")
-    return f"{os.getppid()}_{port}_{run}_{os.environ.get('TORCHELASTIC_RESTART_COUNT', '0')}".encode()
+    attempt = os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")
+    if explicit_key:
+        return f"{os.environ.get('MASTER_ADDR', 'local')}_{port}_{run}_{attempt}".encode()
+    return f"{os.getppid()}_{port}_{run}_{attempt}".encode()
 
 
 def _fresh_seconds() -> float:
@@ -93,7 +99,7 @@ def _read_fresh(path: Path, explicit_key: bool) -> bytes | None:
         stamp, _, nonce = raw[128:].partition(b"|")
         float(stamp.decode())  # well-formed payload
         if explicit_key:
-            return raw[:128] if nonce == _launch_nonce() else None
+            return raw[:128] if nonce == _launch_nonce(explicit_key=True) else None
         probe = path.with_name(f"{path.name}.probe{os.getpid()}")
         try:  # "now" as the filesystem that holds the file sees it (a shared directory may be served by another clock)
             fd = os.open(probe, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, "O_NOFOLLOW", 0), 0o600)
@@ -117,7 +123,7 @@ def exchange_unique_id(ctx, rank: int, world: int, key: str | None = None, timeo
         uid = ctx.comm_unique_id()
         for path in (primary, secondary):
             if path is not None:
-                _publish(path, uid + repr(time.time()).encode() + b"|" + _launch_nonce())
+                _publish(path, uid + repr(time.time()).encode() + b"|" + _launch_nonce(explicit_key=key is not None))
         return uid
     t0 = time.monotonic()
     while True:

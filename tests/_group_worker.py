@@ -6,7 +6,11 @@ modes (argv[1]; argv[2] = world):
   estimator  NeoLSSVM(devices=[0] * world) reproduces the reference fixtures like the single-device estimator does, and its own single-device twin to 1e-9
   grid       gamma x sigma grid: C driver on one context == the Python reference driver bit for bit; Group (sigma-sharded) == one context
   big        D = 4096 (4097 = 8 * 512 + 1 eigenvector columns over the ranks), one- or two-stage EVD per NLS_EVD
-  fail       an injected ncclBroadcast failure surfaces as NlsError from the group call, no hang
+  fail       an injected ncclBroadcast failure (every member's) surfaces as NlsError from the group call, no hang
+  fault      ONE member fails locally (NLS_FAULT_INJECT=site:rank[:code]): the group call returns that member's error at the next status vote,
+             at once; the same communicator carries the next call
+  lost       ONE member's RCCL call fails (NLS_SHIM_FAIL_RANK / _CALL): the group's abort flag releases the others at once (not the
+             deadline); the group joins a new communicator at its next call
 Prints "OK" on success."""
 
 from __future__ import annotations
@@ -249,7 +253,75 @@ def mode_fail(world):
     grp.close()
 
 
+def _fit_equals_solo(hp, grp, clf=False):
+    X, y, s, shift, scale, B = problem(clf=clf)
+    solo = hp.Context(0)
+    r1 = hp.primal_fit(X, y, s, shift, scale, B, clf, ctx=solo)
+    solo.close()
+    r = hp.primal_fit(X, y, s, shift, scale, B, clf, ctx=grp)
+    compare_fits(r, r1, B.shape[1] + 1)
+
+
+def mode_fault(world):
+    import os
+    import time
+
+    import numpy.linalg as npl
+
+    import neo_ls_svm_amd as hp
+    from neo_ls_svm_amd._lib import NlsError
+
+    spec = os.environ["NLS_FAULT_INJECT"]
+    site, bad, *code = spec.split(":")
+    linalg = bool(code) and code[0] == "3"
+    grp = hp.Group([0] * world)
+    X, y, s, shift, scale, B = problem()
+    t0 = time.monotonic()
+    try:
+        hp.primal_fit(X, y, s, shift, scale, B, False, ctx=grp)
+    except (NlsError, npl.LinAlgError) as exc:
+        waited, msg = time.monotonic() - t0, str(exc)
+        assert waited < 60.0, f"{waited:.1f} s: the deadline, not the vote, ended the call"
+        assert isinstance(exc, npl.LinAlgError if linalg else NlsError), (type(exc), msg)
+        # the group reports the member that failed of its own accord, with that member's message
+        assert f"rank {bad} of {world}" in msg and "injected fault" in msg and f"'{site}'" in msg, msg
+    else:
+        raise AssertionError(f"the injected fault at {spec} did not surface")
+    assert all(c.comm_state == "joined" for c in grp.contexts)  # everybody left at the same vote: the communicator is intact
+    del os.environ["NLS_FAULT_INJECT"]
+    _fit_equals_solo(hp, grp)
+    grp.close()
+
+
+def mode_lost(world):
+    import os
+    import time
+
+    import neo_ls_svm_amd as hp
+    from neo_ls_svm_amd._lib import NlsError
+
+    bad = int(os.environ["NLS_SHIM_FAIL_RANK"])
+    grp = hp.Group([0] * world)
+    X, y, s, shift, scale, B = problem()
+    t0 = time.monotonic()
+    try:
+        hp.primal_fit(X, y, s, shift, scale, B, False, ctx=grp)
+    except NlsError as exc:
+        waited, msg = time.monotonic() - t0, str(exc)
+        # NLS_COMM_TIMEOUT_S is 240 s in this test: returning within seconds shows the abort flag, not the deadline, released the members
+        assert waited < 60.0, f"{waited:.1f} s"
+        assert f"rank {bad} of {world}" in msg and "injected" in msg, msg
+    else:
+        raise AssertionError("the lost RCCL call did not surface")
+    states = [c.comm_state for c in grp.contexts]
+    assert states[bad] == "aborted", states
+    del os.environ["NLS_SHIM_FAIL_RANK"], os.environ["NLS_SHIM_FAIL_CALL"]
+    _fit_equals_solo(hp, grp)  # the group joins its members to a new communicator first
+    assert all(c.comm_state == "joined" for c in grp.contexts)
+    grp.close()
+
+
 if __name__ == "__main__":
     mode, world = sys.argv[1], int(sys.argv[2])
-    {"fit": mode_fit, "estimator": mode_estimator, "grid": mode_grid, "big": mode_big, "fail": mode_fail}[mode](world)
+    {"fit": mode_fit, "estimator": mode_estimator, "grid": mode_grid, "big": mode_big, "fail": mode_fail, "fault": mode_fault, "lost": mode_lost}[mode](world)
     print("OK", flush=True)

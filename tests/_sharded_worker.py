@@ -182,6 +182,7 @@ def run_gpu_native(rank, world, expect_failure=False):
                 hp.primal_fit(X[lo:hi], y[lo:hi], s[lo:hi], shift, scale, B, clf, ctx=ctx, want_L=(rank == 0))
             except NlsError as exc:  # NLS_ERR_COMM -> NlsError (RuntimeError); the message names the RCCL call
                 assert "ncclBroadcast" in str(exc) or "Broadcast" in str(exc), str(exc)
+                assert ctx.comm_state == "aborted"  # a failed RCCL call costs the context its communicator
                 ctx.close()
                 return
             raise AssertionError("the injected ncclBroadcast failure did not surface")
@@ -216,11 +217,117 @@ def run_gpu_native(rank, world, expect_failure=False):
     ctx.close()
 
 
+def _native_ctx(rank, world):
+    import neo_ls_svm_amd as hp
+    from neo_ls_svm_amd.distributed import init_from_env
+
+    ctx = hp.Context(0)
+    init_from_env(ctx)
+    assert ctx.comm_world == world and ctx.comm_state == "joined"
+    return hp, ctx
+
+
+def run_gpu_fault(rank, world):
+    """ONE rank fails locally (NLS_FAULT_INJECT="site:rank[:code]": an allocation / launch / factorisation failure as the library sees it) in the
+    middle of a sharded fit.  Every rank must return an error - the failed one its own, the others NLS_ERR_COMM naming it - at the next status
+    vote, i.e. at once (long before the collective deadline), and the SAME communicator must carry the next fit."""
+    import time
+
+    import numpy.linalg as npl
+
+    from neo_ls_svm_amd._lib import NlsError
+    from neo_ls_svm_amd.distributed import row_shard
+
+    spec = os.environ["NLS_FAULT_INJECT"]
+    site, bad, *code = spec.split(":")
+    bad, linalg = int(bad), (code and code[0] == "3")
+    hp, ctx = _native_ctx(rank, world)
+    X, y, s, shift, scale, B = problem(n=5000, d=12, D=200, clf=False)
+    lo, hi = row_shard(X.shape[0], rank, world)
+    t0 = time.monotonic()
+    try:
+        hp.primal_fit(X[lo:hi], y[lo:hi], s[lo:hi], shift, scale, B, False, ctx=ctx, want_L=(rank == 0))
+    except (NlsError, npl.LinAlgError) as exc:
+        waited, msg = time.monotonic() - t0, str(exc)
+        assert waited < 60.0, f"rank {rank} waited {waited:.1f} s: the deadline, not the vote, ended the call"
+        if linalg:
+            assert isinstance(exc, npl.LinAlgError), (type(exc), msg)  # a property of the shared problem: the same error everywhere
+        else:
+            assert isinstance(exc, NlsError), (type(exc), msg)
+        if rank == bad:
+            assert "injected fault" in msg and f"'{site}'" in msg, msg
+        else:
+            assert f"rank {bad} of {world} failed with" in msg and ("NLS_ERR_LINALG" if linalg else "NLS_ERR_HIP") in msg, msg
+    else:
+        raise AssertionError(f"rank {rank}: the injected fault at {spec} did not surface")
+    assert ctx.comm_state == "joined"  # everybody left at the same vote: nothing is pending on the communicator
+    del os.environ["NLS_FAULT_INJECT"]
+    r = hp.primal_fit(X[lo:hi], y[lo:hi], s[lo:hi], shift, scale, B, False, ctx=ctx, want_L=(rank == 0))
+    solo = hp.Context(0)
+    r1 = hp.primal_fit(X, y, s, shift, scale, B, False, ctx=solo)
+    solo.close()
+    assert r["opt"] == r1["opt"] and np.max(np.abs(r["beta"] - r1["beta"])) < 1e-8 * np.max(np.abs(r1["beta"]))
+    ctx.close()
+
+
+def run_gpu_lost_rank(rank, world, how):
+    """ONE rank is lost in a way no vote can carry: `call` - an RCCL call of that rank alone returns an error (NLS_SHIM_FAIL_RANK / _CALL) and the
+    rank leaves; `dead` - its process exits before the fit.  The others are inside a collective with a peer that will never come: the
+    library's deadline (NLS_COMM_TIMEOUT_S, set short by the test) must end their wait with NLS_ERR_COMM and an aborted communicator, which
+    then refuses further collective work at once; a new communicator cannot include the lost rank, so the survivors stop there."""
+    import time
+
+    from neo_ls_svm_amd._lib import NlsError
+    from neo_ls_svm_amd.distributed import row_shard
+
+    bad = int(os.environ["NLS_TEST_LOST_RANK"])
+    deadline = float(os.environ["NLS_COMM_TIMEOUT_S"])
+    hp, ctx = _native_ctx(rank, world)
+    X, y, s, shift, scale, B = problem(n=5000, d=12, D=200, clf=False)
+    lo, hi = row_shard(X.shape[0], rank, world)
+    if how == "dead" and rank == bad:
+        sys.stdout.flush()
+        os._exit(7)  # (no interpreter shutdown: the communicator is simply gone, as after a crash)
+    t0 = time.monotonic()
+    try:
+        hp.primal_fit(X[lo:hi], y[lo:hi], s[lo:hi], shift, scale, B, False, ctx=ctx, want_L=(rank == 0))
+    except NlsError as exc:
+        waited, msg = time.monotonic() - t0, str(exc)
+        if rank == bad:
+            assert "failed" in msg and "injected" in msg and waited < 30.0, (waited, msg)
+        else:
+            assert "did not complete within" in msg and "NLS_COMM_TIMEOUT_S" in msg, msg
+            assert 0.5 * deadline < waited < deadline + 60.0, waited
+    else:
+        raise AssertionError(f"rank {rank}: the fit returned although rank {bad} was lost")
+    assert ctx.comm_state == "aborted"
+    t0 = time.monotonic()
+    try:
+        hp.primal_fit(X[lo:hi], y[lo:hi], s[lo:hi], shift, scale, B, False, ctx=ctx, want_L=False)
+    except NlsError as exc:
+        assert "aborted" in str(exc) and time.monotonic() - t0 < 5.0, str(exc)
+    else:
+        raise AssertionError("a context with an aborted communicator must refuse a sharded fit")
+    ctx.comm_destroy()  # leaving the communicator makes the context a single rank again
+    assert ctx.comm_state == "none"
+    r = hp.primal_fit(X[:500], y[:500], s[:500], shift, scale, B, False, ctx=ctx, want_L=False)
+    assert r["beta"].shape == (B.shape[1] + 1,)
+    ctx.close()
+
+
 if __name__ == "__main__":
     mode = sys.argv[1]
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     if mode in ("gpu_rccl", "gpu_rccl_fail"):
         run_gpu_native(rank, world, expect_failure=(mode == "gpu_rccl_fail"))
+        print(f"OK {rank}", flush=True)
+        sys.exit(0)
+    if mode == "gpu_rccl_fault":
+        run_gpu_fault(rank, world)
+        print(f"OK {rank}", flush=True)
+        sys.exit(0)
+    if mode in ("gpu_rccl_lost_call", "gpu_rccl_lost_dead"):
+        run_gpu_lost_rank(rank, world, mode.rsplit("_", 1)[1])
         print(f"OK {rank}", flush=True)
         sys.exit(0)
     import torch  # noqa: F811

@@ -39,6 +39,23 @@ def main():
     comm = C.c_void_p()
     assert lib.ncclCommInitRank(C.byref(comm), world, uid, rank) == 0
     DOUBLE, SUM, MAX = 8, 0, 2
+    if len(sys.argv) > 3 and sys.argv[3] == "asymmetric":  # NLS_SHIM_FAIL_RANK / NLS_SHIM_FAIL_CALL: one rank's call fails, the others time out
+        lib.ncclCommGetAsyncError.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        lib.ncclCommAbort.argtypes = [C.c_void_p]
+        bad, call = int(os.environ["NLS_SHIM_FAIL_RANK"]), int(os.environ["NLS_SHIM_FAIL_CALL"])
+        a = np.ones(16)
+        for k in range(1, call + 1):
+            t0 = time.monotonic()
+            rc = lib.ncclAllReduce(a.ctypes.data, a.ctypes.data, a.size, DOUBLE, SUM, comm, None)
+            if k < call:
+                assert rc == 0 and np.all(a == world**k)
+            elif rank == bad:
+                assert rc != 0 and b"injected" in lib.ncclGetErrorString(rc) and time.monotonic() - t0 < 1.0
+            else:
+                assert rc != 0 and b"time-out" in lib.ncclGetErrorString(rc) and time.monotonic() - t0 > 2.0
+        assert lib.ncclCommAbort(comm) == 0
+        print(f"OK {rank}", flush=True)
+        return
     fail_at = int(os.environ.get("NLS_SHIM_FAIL_BROADCAST", "0"))
 
     # all-reduce (sum) larger than a slot (NLS_SHIM_SLOT_BYTES is small in the test): chunking; in place

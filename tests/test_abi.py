@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared_symbols():
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
-    assert lib.nls_abi_version() == 3
+    assert lib.nls_abi_version() == 4
 
 
 def test_struct_layout_matches_header():
@@ -186,7 +186,7 @@ def test_rendezvous_file_exchange(tmp_path, monkeypatch):
     assert (prim.stat().st_mode & 0o777) == 0o600
     # an explicit key is the caller's own rendezvous: joined whatever its age (a rank may arrive long after rank 0 published) - when it
     # carries THIS launch's nonce ...
-    old = bytes(range(1, 129)) + repr(0.0).encode() + b"|" + distributed._launch_nonce()
+    old = bytes(range(1, 129)) + repr(0.0).encode() + b"|" + distributed._launch_nonce(explicit_key=True)
     (tmp_path / "nls_rccl_id_job.1").write_bytes(old)
     os.utime(tmp_path / "nls_rccl_id_job.1", (1.0, 1.0))
     assert distributed.exchange_unique_id(Ctx(), 1, 2, key="job.1", timeout=0.2) == bytes(range(1, 129))
@@ -217,6 +217,45 @@ def test_rendezvous_file_exchange(tmp_path, monkeypatch):
     prim.unlink()  # a rank whose parent pid differs would not find the primary: after 15 s it takes the fresh secondary
     monkeypatch.setattr(distributed.time, "monotonic", iter([0.0, 16.0, 17.0, 18.0]).__next__)
     assert distributed.exchange_unique_id(Ctx(), 1, 2, timeout=100) == bytes(range(128))
+
+
+def test_rendezvous_explicit_key_joins_ranks_of_different_parents(tmp_path, monkeypatch):
+    """An explicit key is the rendezvous of ranks that are NOT children of one launcher (several nodes on a shared directory, per-node
+    daemons, hand-started ranks): a reader whose parent pid differs from the publisher's must still join the payload - the default nonce
+    under an explicit key holds only what every rank of the launch shares (address, port, run id, restart count)."""
+    import threading
+
+    from neo_ls_svm_amd import distributed
+
+    monkeypatch.setenv("NLS_RENDEZVOUS_DIR", str(tmp_path))
+    monkeypatch.setenv("MASTER_ADDR", "10.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", "29511")
+
+    class Ctx:
+        def comm_unique_id(self):
+            return bytes(range(128))
+
+    parents = {threading.get_ident(): 1000}
+    monkeypatch.setattr(distributed.os, "getppid", lambda: parents.get(threading.get_ident(), 1))
+    got = {}
+
+    def reader(rank, ppid):
+        parents[threading.get_ident()] = ppid
+        got[rank] = distributed.exchange_unique_id(Ctx(), rank, 3, key="multinode", timeout=20)
+
+    ts = [threading.Thread(target=reader, args=(r, 2000 + r)) for r in (1, 2)]  # two readers, two other parents
+    for t in ts:
+        t.start()
+    got[0] = distributed.exchange_unique_id(Ctx(), 0, 3, key="multinode")
+    for t in ts:
+        t.join()
+    assert got == {0: bytes(range(128)), 1: bytes(range(128)), 2: bytes(range(128))}
+    # another launch (another port) with the same key does not join this one's leftover
+    monkeypatch.setenv("MASTER_PORT", "29512")
+    with pytest.raises(TimeoutError):
+        distributed.exchange_unique_id(Ctx(), 1, 2, key="multinode", timeout=0.2)
+    # without a key the parent pid stays part of the nonce (and of the primary file name)
+    assert distributed._launch_nonce() != distributed._launch_nonce(explicit_key=True)
 
 
 def test_no_cpu_fallback_without_gpu():

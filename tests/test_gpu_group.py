@@ -59,5 +59,21 @@ def test_group_world8_at_4097_columns(evd):
 
 
 def test_group_failure_is_an_error_not_a_hang():
-    """The 2nd ``ncclBroadcast`` of every rank fails (stand-in's injection): the group call returns NLS_ERR_COMM naming the rank."""
+    """The 2nd ``ncclBroadcast`` of every member fails (the stand-in's symmetric injection): the group call returns NLS_ERR_COMM naming a rank."""
     _run("fail", 3, {"NLS_SHIM_FAIL_BROADCAST": "2"}, timeout=300)
+
+
+@pytest.mark.parametrize("world, spec", [(2, "gram:1"), (3, "cholesky:0:3"), (8, "prepare:4"), (8, "evd:0"), (8, "backtransform:6"), (8, "sweep:1"), (8, "select:7")])
+def test_one_member_fails_locally_the_group_call_returns(world, spec):
+    """One member of the group fails on its own (``NLS_FAULT_INJECT=site:rank[:code]``) at each stretch of the sharded fit: no member is
+    left in a collective and the one call returns the failing member's error (``LinAlgError`` for a factorisation failure) - at the next
+    status vote, not at the deadline - and the next call on the same group, the same communicator, is right."""
+    _run("fault", world, {"NLS_FAULT_INJECT": spec, "NLS_COMM_TIMEOUT_S": "240"}, timeout=900)
+
+
+@pytest.mark.parametrize("world, bad, call", [(2, 1, 4), (8, 5, 8), (8, 0, 3)])
+def test_one_member_loses_an_rccl_call_the_abort_flag_releases_the_others(world, bad, call):
+    """The ``call``-th collective of ONE member fails inside the communication library; that member's thread returns, the others are
+    inside a collective it will never join.  The group's abort flag (polled by their bounded waits) releases them at once - with the
+    deadline at 240 s the call must still return within seconds - and the group joins a fresh communicator for the next call."""
+    _run("lost", world, {"NLS_SHIM_FAIL_RANK": str(bad), "NLS_SHIM_FAIL_CALL": str(call), "NLS_COMM_TIMEOUT_S": "240"}, timeout=900)

@@ -27,7 +27,8 @@ def build_shim(host_only: bool) -> Path:
     out = SHIM_DIR / ("librccl_hostonly.so" if host_only else "librccl.so.1")
     if not out.exists() or out.stat().st_mtime < SHIM_SRC.stat().st_mtime:
         SHIM_DIR.mkdir(exist_ok=True)
-        cmd = [HIPCC, "-shared", "-fPIC", "-O2", "-std=c++17", str(SHIM_SRC), "-o", str(out), "-lrt"] + (["-DSHIM_HOST_ONLY"] if host_only else [])
+        # (gfx950 named: the GPU build carries a kernel and may be compiled in a container without a GPU, then travel to the box)
+        cmd = [HIPCC, "-shared", "-fPIC", "-O2", "-std=c++17", str(SHIM_SRC), "-o", str(out), "-lrt"] + (["-DSHIM_HOST_ONLY"] if host_only else ["--offload-arch=gfx950"])
         subprocess.run(cmd, check=True, capture_output=True, text=True)
     return out
 
@@ -38,7 +39,9 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run_ranks(argv, world, env_extra, timeout):
+def _run_ranks(argv, world, env_extra, timeout, expect_exit=None):
+    """expect_exit: {rank: exit code} for ranks that are meant to die (they print no OK line)."""
+    expect_exit = expect_exit or {}
     port = _free_port()
     procs = []
     for rank in range(world):
@@ -55,7 +58,10 @@ def _run_ranks(argv, world, env_extra, timeout):
             raise
         outs.append(out)
     for rank, (p, out) in enumerate(zip(procs, outs)):
-        assert p.returncode == 0 and f"OK {rank}" in out, f"rank {rank} failed:\n{out[-3000:]}"
+        if rank in expect_exit:
+            assert p.returncode == expect_exit[rank], f"rank {rank}: exit code {p.returncode}, expected {expect_exit[rank]}:\n{out[-3000:]}"
+        else:
+            assert p.returncode == 0 and f"OK {rank}" in out, f"rank {rank} failed:\n{out[-3000:]}"
 
 
 @pytest.mark.parametrize("world, fail_at", [(2, 0), (3, 0), (3, 1), (3, 3)])
@@ -68,6 +74,26 @@ def test_shim_protocol_cpu(world, fail_at):
         if fail_at:
             env["NLS_SHIM_FAIL_BROADCAST"] = str(fail_at)
         _run_ranks([str(HERE / "_shim_worker.py"), str(lib), str(Path(td) / "id")], world, env, timeout=120)
+
+
+def test_shim_asymmetric_failure_cpu():
+    """The stand-in's ASYMMETRIC injection (``NLS_SHIM_FAIL_RANK`` / ``NLS_SHIM_FAIL_CALL``): the 2nd collective call of rank 1 alone returns an
+    error; the other ranks are left in the exchange and get the stand-in's own time-out (host-only build: the calls are synchronous)."""
+    lib = build_shim(host_only=True)
+    with tempfile.TemporaryDirectory() as td:
+        env = {"NLS_SHIM_SLOT_BYTES": "8192", "NLS_SHIM_TIMEOUT_S": "3", "NLS_SHIM_FAIL_RANK": "1", "NLS_SHIM_FAIL_CALL": "2"}
+        _run_ranks([str(HERE / "_shim_worker.py"), str(lib), str(Path(td) / "id"), "asymmetric"], 3, env, timeout=120)
+
+
+def test_the_gpu_build_of_the_shim_compiles_and_exports_what_the_library_binds():
+    """``csrc/nls_comm.hip`` resolves ten ``nccl*`` symbols (``ncclCommAbort`` and ``ncclCommGetAsyncError`` since round 6): the stand-in must
+    have them all, or the library would refuse it at load time on the GPU box."""
+    import ctypes
+
+    lib = ctypes.CDLL(str(build_shim(host_only=False)))
+    for name in ("ncclGetUniqueId", "ncclCommInitRank", "ncclCommDestroy", "ncclCommAbort", "ncclCommGetAsyncError", "ncclAllReduce",
+                 "ncclBroadcast", "ncclGroupStart", "ncclGroupEnd", "ncclGetErrorString"):  # fmt: skip
+        assert hasattr(lib, name), name
 
 
 def _launch_native(mode, world, extra_env=None, timeout=900):
@@ -96,22 +122,57 @@ def test_native_communicator_two_stage_evd(world):
 
 @pytest.mark.gpu
 def test_native_communicator_failure_is_an_error_on_every_rank():
-    """Failure injection: the 2nd ``ncclBroadcast`` of every rank (the eigenvalues, after the status flag of the rank-0 ``stedc``)
-    returns an error: every rank must get NLS_ERR_COMM (``NlsError``) - nobody hangs."""
+    """Symmetric failure injection: the 2nd ``ncclBroadcast`` of every rank (the real eigenvectors of rank 0's tridiagonal solve, after the
+    eigenvalues) returns an error: every rank must get NLS_ERR_COMM (``NlsError``) - nobody hangs."""
     _launch_native("gpu_rccl_fail", 2, {"NLS_SHIM_FAIL_BROADCAST": "2"}, timeout=300)
 
 
 @pytest.mark.gpu
 def test_native_communicator_failure_inside_the_group():
-    """... and inside the grouped all-gather (broadcasts 4.. of a fit: flag, lam, eigenvectors come first): the group is closed,
+    """... and inside the grouped all-gather (broadcasts 3.. of a fit: eigenvalues and real eigenvectors come first): the group is closed,
     the error surfaces, nobody hangs."""
-    _launch_native("gpu_rccl_fail", 2, {"NLS_SHIM_FAIL_BROADCAST": "5"}, timeout=300)
+    _launch_native("gpu_rccl_fail", 2, {"NLS_SHIM_FAIL_BROADCAST": "4"}, timeout=300)
 
 
 @pytest.mark.gpu
 def test_native_communicator_failure_world8():
     """World 8, the failure inside the grouped all-gather of eight unequal blocks (the 7th broadcast of every rank)."""
     _launch_native("gpu_rccl_fail", 8, {"NLS_SHIM_FAIL_BROADCAST": "7"}, timeout=600)
+
+
+# ---- ONE rank fails; the others must not be left waiting (SURVEY.md section 5; include/neolssvm_hip.h, "Failure of ONE rank ...") -------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("world, spec", [(2, "gram:1"), (2, "prepare:0"), (2, "cholesky:0:3"), (8, "evd:5"), (8, "backtransform:3"), (8, "sweep:7"),
+                                         (8, "select:2")])  # fmt: skip
+def test_one_rank_fails_locally_every_rank_returns_at_the_vote(world, spec):
+    """A local failure on ONE rank (``NLS_FAULT_INJECT=site:rank[:code]`` - what a failed allocation or launch looks like from inside the
+    library) at each stretch of the sharded fit: the rank goes to the next status vote instead of leaving, every rank returns an error
+    at once - its own on the failed rank, NLS_ERR_COMM naming rank and code on the others, ``LinAlgError`` everywhere for a factorisation
+    failure on rank 0 - and the same communicator carries the next fit."""
+    _launch_native("gpu_rccl_fault", world, {"NLS_FAULT_INJECT": spec, "NLS_COMM_TIMEOUT_S": "240"}, timeout=900)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world, bad, call", [(2, 1, 5), (8, 3, 9)])
+def test_one_rank_loses_an_rccl_call_the_others_meet_the_deadline(world, bad, call):
+    """The ``call``-th collective of rank ``bad`` ALONE fails inside the communication library (the stand-in's asymmetric injection): that
+    rank returns at once; the others sit in a collective whose peer has left and are released by the library's own deadline
+    (``NLS_COMM_TIMEOUT_S`` = 10 s here, far below the stand-in's safety net): NLS_ERR_COMM, communicator aborted, further
+    collective calls refused, ``nls_comm_destroy`` makes the context a single rank again."""
+    env = {"NLS_SHIM_FAIL_RANK": str(bad), "NLS_SHIM_FAIL_CALL": str(call), "NLS_TEST_LOST_RANK": str(bad), "NLS_COMM_TIMEOUT_S": "10"}
+    _launch_native("gpu_rccl_lost_call", world, env, timeout=900)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world, bad", [(2, 0), (8, 6)])
+def test_one_rank_dies_the_others_meet_the_deadline(world, bad):
+    """Rank ``bad``'s PROCESS exits (code 7) after joining the communicator and before the fit: the survivors' first status vote never
+    completes; the deadline ends it on every survivor."""
+    lib = build_shim(host_only=False)
+    with tempfile.TemporaryDirectory() as td:
+        env = {"NLS_RCCL_LIB": str(lib), "NLS_RENDEZVOUS_DIR": td, "NLS_SHIM_SLOT_BYTES": str(1 << 20), "NLS_SHIM_TIMEOUT_S": "300",
+               "NLS_TEST_LOST_RANK": str(bad), "NLS_COMM_TIMEOUT_S": "10"}  # fmt: skip
+        _run_ranks([str(HERE / "_sharded_worker.py"), "gpu_rccl_lost_dead"], world, env, 900, expect_exit={bad: 7})
 
 
 def _bench_line(out):

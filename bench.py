@@ -465,8 +465,15 @@ def main():
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the NeoLSSVM.fit wall-time leg (pre-step + solver + calibration split)")
+    ap.add_argument("--as-rank", type=int, default=0, help="with --of W: the virtual rank whose share of the sharded fit this ONE process measures")
+    ap.add_argument("--of", type=int, default=0, help="virtual world size W (> 1): one rank's share of a W-GPU row-sharded fit of the configuration, on one GPU - "
+                    "its row block, the rank-0 tridiagonal solve (as rank 0), its own eigenvector column block, every exchange with its real payload through a "
+                    "one-rank RCCL communicator (enqueue + local pass timed, no link)")  # fmt: skip
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
+    virt = args.of if args.of > 1 else 0
+    if virt and (args.gpus > 1 or "sigmas" in cfg or cfg.get("dual") or not 0 <= args.as_rank < virt):
+        raise SystemExit("--as-rank / --of: one process (--gpus 1), a row-sharded primal configuration, 0 <= rank < W")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(spawn_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
@@ -487,13 +494,15 @@ def main():
     ctx = hp.Context(dev)
     # Row sharding: the fitting context itself joins the communicator.  Sigma sharding (c5): every rank fits all rows on
     # its own, so the communicator lives on a second context that only serves the barrier / the merge of the small tables.
-    use_comm = world > 1 or os.environ.get("NLS_BENCH_FORCE_COMM") == "1"
+    use_comm = world > 1 or os.environ.get("NLS_BENCH_FORCE_COMM") == "1" or virt > 0
     cctx = None
     if use_comm:
         cctx = hp.Context(dev) if grid_mode else ctx
         init_from_env(cctx)
 
     lo, hi = (0, n) if grid_mode else ((n * rank) // world, (n * (rank + 1)) // world)
+    if virt:
+        lo, hi = (n * args.as_rank) // virt, (n * (args.as_rank + 1)) // virt
     shift, scale, B = affine_params(n, d, D, ctx=ctx)
     X, y = synth(n, d, lo, hi)
     s = np.ones(hi - lo)
@@ -516,13 +525,18 @@ def main():
             return {"opt": g["gamma_index"], "sigma_index": g["sigma_index"], "loo_score": best.get("loo_score"), "timings": g["timings"],
                     "finished_count": g["finished_count"]}  # fmt: skip
         # row-sharded fit: every rank ends with the same beta / lam / curve; the factor L_ (an output only) is produced and downloaded by rank 0
-        return hp.primal_fit(X_, y_, s_, shift, scale, B, False, gammas=gammas, ctx=ctx, want_L=(rank == 0))
+        return hp.primal_fit(X_, y_, s_, shift, scale, B, False, gammas=gammas, ctx=ctx, want_L=(rank == 0 and (not virt or args.as_rank == 0)))
 
     if grid_mode or rank == 0:
         # the L_ outputs of the loop: two page-locked host buffers reserved once, like the inputs (a C caller allocates - and may register - its
         # output buffer once; the Python mirror would otherwise create them during the first steps and page-lock them when they are first recycled)
         hp.reserve_factor_outputs((D + 1, D + 1), np.complex128, ctx, 2)
     r = None
+    full = None
+    if virt:  # one COMPLETE fit of the same rows first: the virtual rank takes its peers' eigenvector blocks from what it leaves on the device
+        ctx.comm_set_virtual_rank(capture=True)
+        full = step()
+        ctx.comm_set_virtual_rank(args.as_rank, virt)
     for _ in range(args.warmup):
         r = step()  # (held like the timed results: the loop is in its steady state before the clock starts)
     barrier()
@@ -538,7 +552,7 @@ def main():
         elapsed = float(cctx.comm_allreduce([elapsed], "max")[0])
 
     pcie = None
-    if world == 1 and not grid_mode:  # the same step with host-resident inputs: one pageable H2D copy of X inside the call
+    if world == 1 and not grid_mode and not virt:  # the same step with host-resident inputs: one pageable H2D copy of X inside the call
         tp = time.perf_counter()
         step(X, y, s)
         ctx.synchronize()
@@ -553,7 +567,7 @@ def main():
         # Traffic past L2 comes from separate rocprofv3 PMC passes (it cannot be read live); per row because every launch
         # streams (rows x panels) with the same reuse pattern.
         traffic = k1_traffic = traffic_src = mfma_busy = mfma_busy_src = gram_pmc = None
-        for src in ("r05_pmc_summary.json", "r04_pmc_summary.json"):  # the newest counter passes committed (tools/pmc_passes_r05.sh / _r04.sh, same layout)
+        for src in ("r06_pmc_summary.json", "r05_pmc_summary.json", "r04_pmc_summary.json"):  # the newest counter passes committed (tools/evidence_pass.sh <tag> pmc)
             try:
                 pmc = json.loads((ROOT / "profiles" / src).read_text())
                 pr = pmc["k_rotate3"]
@@ -614,7 +628,13 @@ def main():
                 "workload": cfg["name"],
                 "n": n, "d": d, "D": D, "G": G,
                 "rows_per_gpu": hi - lo,
-                "parallelism": (f"sigma-shard x{world}, rows replicated" if grid_mode else f"row-shard x{world}, RCCL all-reduce of A||b") if world > 1 else "single GPU",
+                "parallelism": (f"sigma-shard x{world}, rows replicated" if grid_mode else f"row-shard x{world}, RCCL all-reduce of A||b") if world > 1
+                else ("single GPU" if not virt else
+                      f"VIRTUAL rank {args.as_rank} of {virt} on one GPU: rows [{lo}, {hi}) of {n}; tridiagonal eigensolver {'run (rank 0)' if args.as_rank == 0 else 'not run'}; "
+                      f"back-transformation of this rank's eigenvector columns only; the status votes and every exchange (weight sums, {8 * (2 * (Kf // 128) * (Kf // 128 + 1) // 2 * 128 * 128 + 4 * Kf + 8) / 1e6:.0f} MB "
+                      f"all-reduce of A||b, {8 * (D + 1) ** 2 / 1e6:.0f} MB broadcast of the real eigenvectors, all-gather of {virt} column blocks, error vectors, beta) "
+                      "go through a ONE-rank RCCL communicator with their real payloads - enqueue and local pass timed, no xGMI link; the peers' blocks are a "
+                      "device copy of a complete fit's (results = the complete fit's, checked below)"),
                 "affine": f"package pre-step (AffineSeparator + ORF RandomState 42) fitted on the first {min(n, PRESTEP_PREFIX)} rows (SURVEY 8d)",
                 "gamma_index": r["opt"],
                 "sigma_index": r.get("sigma_index"),
@@ -633,13 +653,19 @@ def main():
                 "frac": rot_exec_tflops / FP64_MFMA_PEAK_TFLOPS,
                 "frac_is": "executed-MFMA utilisation (flops the kernel executes / time / peak); frac_algorithmic is SURVEY 8(d)'s figure",
                 "frac_algorithmic": rot_alg_tflops / FP64_MFMA_PEAK_TFLOPS,
-                "mfma_busy": mfma_busy,
-                "mfma_busy_source": None if mfma_busy is None else f"{mfma_busy_src}: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 matrix pipes), its own rocprofv3 --pmc pass",
                 "traffic": traffic,
-                "traffic_unit": "bytes/launch beyond L2 (2 x FETCH_SIZE + WRITE_SIZE, Infinity-Cache hits included), from separate rocprofv3 --pmc passes",
-                "traffic_source": traffic_src,
+                "from_profiles": {
+                    "what": "NOT measured by this run: counter values read from the committed rocprofv3 --pmc summaries under profiles/ (separate passes "
+                    "of the same kernels; counters cannot be read live) and scaled to this run's rows per launch.  `traffic` above repeats the value "
+                    "because the bench contract names that key; everything else in `roofline` is measured live with HIP events",
+                    "mfma_busy": mfma_busy,
+                    "mfma_busy_source": None if mfma_busy is None else f"{mfma_busy_src}: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 matrix pipes), its own rocprofv3 --pmc pass",
+                    "traffic": traffic,
+                    "traffic_unit": "bytes/launch beyond L2 (2 x FETCH_SIZE + WRITE_SIZE, Infinity-Cache hits included)",
+                    "traffic_source": traffic_src,
+                    "traffic_over_algorithmic": None if traffic is None else traffic / ((rot_rows / rot_launches) * 16.0 * (Kf + Np) + 16.0 * Kf * Np),
+                },
                 "algorithmic_bytes_per_launch": (rot_rows / rot_launches) * 16.0 * (Kf + Np) + 16.0 * Kf * Np,
-                "traffic_over_algorithmic": None if traffic is None else traffic / ((rot_rows / rot_launches) * 16.0 * (Kf + Np) + 16.0 * Kf * Np),
                 "note": "achieved / frac = EXECUTED MFMA flops (3M complex product: 6 rows Kf Np, Kf = ceil(D/128)*128, Np = ceil((D+1)/64)*64) / kernel "
                 "time: the matrix-pipe utilisation.  frac_algorithmic = SURVEY 8(d)'s algorithmic 8 rows (D+1)^2 flops of the four-product form / time / "
                 "peak: it exceeds the executed figure by algorithmic_gain (3 instead of 4 real products per complex product, D+1 padded to Np) and may "
@@ -662,11 +688,15 @@ def main():
                 "frac_is": "executed-MFMA utilisation over the whole gram stage (k_gram3 + slab reduction + border sums); 3 rows Kf^2 executed flops",
                 "frac_algorithmic": stage["gram_flops"] / max(stage["gram"], 1e-12) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
                 "avg_launch_ms": 1e3 * stage["gram"] / max(stage["gram_launches"], 1.0),
-                "mfma_busy": None if not gram_pmc else gram_pmc.get("mfma_busy"),
-                "traffic": None if not gram_pmc else (gram_pmc["fetch_bytes_x2"] + gram_pmc["write_bytes"]) * (rows_all / max(stage["gram_launches"], 1.0)) / gram_pmc["rows_per_launch"],
                 "algorithmic_bytes_per_launch": (rows_all / max(stage["gram_launches"], 1.0)) * 16.0 * Kf + 8.0 * Kf * Kf,
-                "traffic_over_algorithmic": None if not gram_pmc else (gram_pmc["fetch_bytes_x2"] + gram_pmc["write_bytes"]) / (gram_pmc["rows_per_launch"] * 16.0 * Kf + 8.0 * Kf * Kf),
-                "traffic_source": None if not gram_pmc else f"{gram_pmc['source']} ({gram_pmc.get('order')})",
+                "traffic": None if not gram_pmc else (gram_pmc["fetch_bytes_x2"] + gram_pmc["write_bytes"]) * (rows_all / max(stage["gram_launches"], 1.0)) / gram_pmc["rows_per_launch"],
+                "from_profiles": {
+                    "what": "NOT measured by this run: committed rocprofv3 --pmc summaries (see roofline.from_profiles.what)",
+                    "mfma_busy": None if not gram_pmc else gram_pmc.get("mfma_busy"),
+                    "traffic": None if not gram_pmc else (gram_pmc["fetch_bytes_x2"] + gram_pmc["write_bytes"]) * (rows_all / max(stage["gram_launches"], 1.0)) / gram_pmc["rows_per_launch"],
+                    "traffic_over_algorithmic": None if not gram_pmc else (gram_pmc["fetch_bytes_x2"] + gram_pmc["write_bytes"]) / (gram_pmc["rows_per_launch"] * 16.0 * Kf + 8.0 * Kf * Kf),
+                    "traffic_source": None if not gram_pmc else f"{gram_pmc['source']} ({gram_pmc.get('order')})",
+                },
             },
             "roofline_k1": {
                 "kernel": "k_featuremap (+ k_shift_pad)",
@@ -676,6 +706,8 @@ def main():
                 "unit": "GB/s",
                 "frac": fm_gbs / HBM_PEAK_GBS,
                 "traffic": None if k1_traffic is None else k1_traffic * fm_rows / fm_launches,
+                "from_profiles": {"what": "NOT measured by this run (see roofline.from_profiles.what)", "traffic": None if k1_traffic is None else k1_traffic * fm_rows / fm_launches,
+                                  "traffic_over_algorithmic": None if k1_traffic is None else k1_traffic * fm_rows / fm_bytes},
                 "avg_launch_ms": 1e3 * stage["featuremap"] / fm_launches,
                 "algorithmic_bytes_per_launch": fm_bytes / fm_launches,
             },
@@ -685,6 +717,15 @@ def main():
             },
             "evd_stage_ms": ctx.evd_stage_ms(),
         }
+        if virt:
+            bd = float(np.max(np.abs(r["beta"] - full["beta"])) / np.max(np.abs(full["beta"])))
+            out["virtual_rank"] = {
+                "rank": args.as_rank, "of": virt, "global_n": n, "projected_fits_per_s_before_links": out["value"],
+                "equals_complete_fit": {"argmin_equal": bool(r["opt"] == full["opt"]), "beta_max_rel_diff": bd,
+                                        "loo_errors_max_rel_diff": float(np.max(np.abs(r["loo_errors_gammas"] - full["loo_errors_gammas"])) / np.max(np.abs(full["loo_errors_gammas"])))},
+                "note": "value = 1 / (this rank's time per fit): what a W-GPU node would reach if the links were free; n_gpus stays 1 (one GPU ran)",
+            }  # fmt: skip
+            args.no_cpu_baseline = args.no_end_to_end = True
         if not args.no_cpu_baseline and world == 1:
             ctx.release_workspace()
 

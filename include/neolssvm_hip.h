@@ -117,6 +117,13 @@ int nls_comm_allreduce(nls_ctx* ctx, double* host_values, size_t count, int op);
  * waits for ranks that enter the call late - choose it above the largest skew between the ranks' arrivals.
  * nls_comm_abort: gives the context's communicator up now (e.g. from a signal handler's deferred work when the job is being cancelled).
  * nls_comm_state: 0 no communicator, 1 joined, 2 aborted (collective calls fail until nls_comm_init_rank / nls_comm_destroy). */
+/* Measurement hook (bench.py --as-rank r --of W; no production use): on a context that is the ONLY rank of a native communicator,
+ * world > 1 makes nls_primal_fit do the share of rank `rank` of `world` ranks on the rows it is given - the tridiagonal eigensolver only
+ * as rank 0, its own column block of the back-transformation, and every exchange with its real payload pushed through the one-rank
+ * communicator (the enqueue and the local pass of the collective are timed; no link is).  The other ranks' eigenvector blocks (and, for
+ * rank != 0, rank 0's eigenpairs) come from a copy that a complete call on the SAME inputs with capture = 1 (world <= 1) left on the
+ * device, so the fitted results are those of the complete call.  world <= 1, capture = 0: off. */
+int nls_comm_set_virtual_rank(nls_ctx* ctx, int rank, int world, int capture);
 int nls_comm_set_timeout(nls_ctx* ctx, double seconds);
 int nls_comm_abort(nls_ctx* ctx);
 int nls_comm_state(const nls_ctx* ctx);
@@ -232,9 +239,11 @@ typedef struct nls_primal_fit_args {
   double* loo_residuals; /* n         column of the selected gamma                            */
   double* loo_leverage;  /* n                                                                 */
   double* loo_std;       /* n                                                                 */
-  double* residuals;     /* n         Re(phi beta) - y at gamma* (_neo_ls_svm.py:179).  Read off the sweep's table, i.e. with the */
-                         /*           eigendecomposition's beta(gamma*); `beta` itself is cho_solve(L, b) - the same vector to        */
-                         /*           cond(gamma* C + A) eps, so Re(phi beta) - y equals this to that accuracy (tested: 1e-9 relative) */
+  double* residuals;     /* n         Re(phi beta) - y with the RETURNED beta (_neo_ls_svm.py:178-182; clipped for a classifier).     */
+                         /*           When beta is the Cholesky re-solve (L requested, or a sharded fit) one more pass over the       */
+                         /*           feature planes evaluates it (8-13 ms at n = 10^6, D = 4096); NLS_FIT_RESIDUALS_FROM_SWEEP takes */
+                         /*           the sweep table's column instead (the eigendecomposition's beta(gamma*): equal to              */
+                         /*           cond(gamma* C + A) eps, ~1e-9 relative).  With L == NULL on one rank beta IS that vector.       */
   double* loo_score;     /* 1         weighted accuracy / R^2 of the LOO predictions          */
   int32_t* gamma_index;  /* 1         selected grid index                                     */
   int32_t* finished;     /* 1         1 when P8 / P9 ran (beta, L, residuals, row outputs written), else 0 */
@@ -245,6 +254,7 @@ typedef struct nls_primal_fit_args {
 #define NLS_FIT_SWEEP_ONLY 1      /* stop after the gamma selection (P1-P7): no Cholesky re-solve, no residuals / L / beta */
 #define NLS_FIT_FINISH_IF_BELOW 2 /* run P8 / P9 only when objective[selected] < finish_below: a gamma x sigma grid    */
                                   /* finishes only the sigmas that beat the incumbent (the others need the curve only) */
+#define NLS_FIT_RESIDUALS_FROM_SWEEP 4 /* residuals: the sweep table's column, no extra pass (see `residuals` above)   */
 
 /* indices into timings[] */
 #define NLS_T_TOTAL 0

@@ -18,7 +18,7 @@ LIB_PATH = Path(os.environ.get("NEOLSSVM_HIP_LIB", _HERE / "libneolssvm_hip.so")
 
 NLS_OK, NLS_ERR_ARG, NLS_ERR_HIP, NLS_ERR_LINALG, NLS_ERR_COMM = 0, 1, 2, 3, 4
 ABI_VERSION = 4
-FIT_SWEEP_ONLY, FIT_FINISH_IF_BELOW = 1, 2
+FIT_SWEEP_ONLY, FIT_FINISH_IF_BELOW, FIT_RESIDUALS_FROM_SWEEP = 1, 2, 4
 COMM_ID_BYTES = 128
 NUM_TIMINGS = 24
 TIMING_NAMES = {
@@ -146,6 +146,7 @@ SIGNATURES = {
     "nls_comm_init_rank": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "nls_comm_destroy": (C.c_int, [C.c_void_p]),
     "nls_comm_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
+    "nls_comm_set_virtual_rank": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "nls_comm_set_timeout": (C.c_int, [C.c_void_p, C.c_double]),
     "nls_comm_abort": (C.c_int, [C.c_void_p]),
     "nls_comm_state": (C.c_int, [C.c_void_p]),
@@ -452,6 +453,12 @@ class Context:
 
     def comm_barrier(self):
         self.comm_allreduce([0.0])
+
+    def comm_set_virtual_rank(self, rank: int = 0, world: int = 0, capture: bool = False):
+        """Measurement hook (``nls_comm_set_virtual_rank``; ``bench.py --as-rank r --of W``): this context, the only rank of a native
+        communicator, does rank ``rank``'s share of a ``world``-rank sharded fit; ``capture=True`` (with world <= 1) makes the next complete
+        fit leave the eigenpairs the virtual ranks take their peers' blocks from."""
+        self._check(self.lib.nls_comm_set_virtual_rank(self.handle, int(rank), int(world), 1 if capture else 0))
 
     def comm_set_timeout(self, seconds: float):
         """Deadline of every collective wait (``nls_comm_set_timeout``): after it the communicator is aborted and the call raises

@@ -97,6 +97,18 @@ extern "C" int nls_comm_set_timeout(nls_ctx* ctx, double seconds) {
   return NLS_OK;
 }
 
+extern "C" int nls_comm_set_virtual_rank(nls_ctx* ctx, int rank, int world, int capture) {
+  if (!ctx) return NLS_ERR_ARG;
+  if (world > 1 && (rank < 0 || rank >= world || world > NLS_COMM_UTIL_MAX)) return fail(ctx, NLS_ERR_ARG, "nls_comm_set_virtual_rank: rank %d outside world %d", rank, world);
+  if ((world > 1 || capture) && (!ctx->comm || ctx->world != 1))
+    return fail(ctx, NLS_ERR_ARG, "nls_comm_set_virtual_rank: the context must be the only rank of a native communicator (nls_comm_init_rank with world 1)");
+  if (world > 1 && capture) return fail(ctx, NLS_ERR_ARG, "nls_comm_set_virtual_rank: capture belongs to a complete call (world <= 1)");
+  ctx->virt_rank = world > 1 ? rank : 0;
+  ctx->virt_world = world > 1 ? world : 0;
+  ctx->virt_capture = capture != 0;
+  return NLS_OK;
+}
+
 extern "C" int nls_comm_state(const nls_ctx* ctx) { return !ctx ? -1 : (ctx->comm_broken ? 2 : (ctx->comm ? 1 : 0)); }
 
 extern "C" int nls_comm_init_rank(nls_ctx* ctx, const void* id, int rank, int world) {

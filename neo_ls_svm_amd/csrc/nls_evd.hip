@@ -718,6 +718,27 @@ static int stedc_any(nls_ctx* ctx, int n, double* lam, double* e_work, double* C
   return stedc_dc(ctx, n, lam, e_work, Cr, dinfo);
 }
 
+// Measurement hook (nls_comm_set_virtual_rank): the eigenvector blocks of the OTHER virtual ranks.  A real peer would have sent them; here
+// they come from the copy a complete call of the same problem left in "virt.Q" (the timed steps of a bench repeat one problem) - a device
+// copy standing in for the arrival of the all-gather.  Without such a copy (virt_n != n) this returns NLS_ERR_ARG: the caller runs one
+// complete fit first (nls_comm_set_virtual_rank(ctx, 0, 1, capture = 1)).
+static int virtual_other_blocks(nls_ctx* ctx, double2* C, int n, long c0, long c1) {
+  if (ctx->virt_capture) {
+    double2* Qfull = nullptr;
+    NLSCHK(ws_get_t(ctx, "virt.Q", (size_t)n * n, &Qfull));
+    HIPCHK(ctx, hipMemcpyAsync(Qfull, C, sizeof(double2) * (size_t)n * n, hipMemcpyDeviceToDevice, ctx->stream));
+    ctx->virt_n = n;
+    return NLS_OK;
+  }
+  if (ctx->virt_world <= 1) return NLS_OK;
+  if (ctx->virt_n != n) return fail(ctx, NLS_ERR_ARG, "virtual rank: no captured eigenvectors of order %d (run one complete fit with capture first)", n);
+  double2* Qfull = nullptr;
+  NLSCHK(ws_get_t(ctx, "virt.Q", (size_t)n * n, &Qfull));
+  if (c0 > 0) HIPCHK(ctx, hipMemcpyAsync(C, Qfull, sizeof(double2) * (size_t)c0 * n, hipMemcpyDeviceToDevice, ctx->stream));
+  if (c1 < n) HIPCHK(ctx, hipMemcpyAsync(C + c1 * n, Qfull + c1 * n, sizeof(double2) * (size_t)(n - c1) * n, hipMemcpyDeviceToDevice, ctx->stream));
+  return NLS_OK;
+}
+
 // stedc on the (real) tridiagonal matrix.  collective: rank 0 computes, everybody receives (lam, Cr) - the ranks then pair the same
 // eigenvalues with the same basis whatever stedc does on clustered spectra.  rc_in: the status of this rank's work since the previous
 // exchange (the tridiagonalisation); together with rank 0's solver status it goes into the vote that guards the two broadcasts, so a
@@ -729,13 +750,26 @@ static int stedc_real(nls_ctx* ctx, int n, double* lam, double* e_work, double* 
     return check_info(ctx, dinfo, "tridiagonal eigensolver (stedc)");
   }
   int rc = rc_in;
-  if (rc == NLS_OK && ctx->rank == 0) rc = [&]() -> int {
+  if (rc == NLS_OK && work_rank(ctx) == 0) rc = [&]() -> int {
     NLSCHK(stedc_any(ctx, n, lam, e_work, Cr, dinfo));
     return check_info(ctx, dinfo, "tridiagonal eigensolver (stedc) on rank 0");
   }();
   NLSCHK(comm_vote(ctx, rc, "at the tridiagonal eigensolver (rank 0 solves, every rank receives)"));
   NLSCHK(do_broadcast(ctx, lam, (size_t)n, 0));
   NLSCHK(do_broadcast(ctx, Cr, (size_t)n * n, 0));
+  if (ctx->virt_capture || ctx->virt_world > 1) {  // measurement hook (nls_comm_set_virtual_rank): what rank 0 would have sent
+    double *vlam = nullptr, *vCr = nullptr;
+    NLSCHK(ws_get_t(ctx, "virt.lam", (size_t)n, &vlam));
+    NLSCHK(ws_get_t(ctx, "virt.Cr", (size_t)n * n, &vCr));
+    if (ctx->virt_capture) {
+      HIPCHK(ctx, hipMemcpyAsync(vlam, lam, sizeof(double) * n, hipMemcpyDeviceToDevice, ctx->stream));
+      HIPCHK(ctx, hipMemcpyAsync(vCr, Cr, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToDevice, ctx->stream));
+    } else if (work_rank(ctx) != 0) {
+      if (ctx->virt_n != n) return fail(ctx, NLS_ERR_ARG, "virtual rank: no captured eigenpairs of order %d (run one complete fit with capture first)", n);
+      HIPCHK(ctx, hipMemcpyAsync(lam, vlam, sizeof(double) * n, hipMemcpyDeviceToDevice, ctx->stream));
+      HIPCHK(ctx, hipMemcpyAsync(Cr, vCr, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+  }
   return NLS_OK;
 }
 
@@ -854,8 +888,8 @@ static int evd_two_stage(nls_ctx* ctx, T* A, int n, double* lam, double* e_work,
   NLSCHK(stedc_real(ctx, n, lam, e_work, Cr, dinfo, collective, rc));
   mark(3);
   if (split) {
-    c0 = (long)n * ctx->rank / ctx->world;
-    c1 = (long)n * (ctx->rank + 1) / ctx->world;
+    c0 = (long)n * work_rank(ctx) / work_world(ctx);
+    c1 = (long)n * (work_rank(ctx) + 1) / work_world(ctx);
   }
   rc = [&]() -> int {
     if (CPLX && c1 > c0) {
@@ -882,10 +916,12 @@ static int evd_two_stage(nls_ctx* ctx, T* A, int n, double* lam, double* e_work,
   }
   if (split) {
     NLSCHK(comm_vote(ctx, rc, "before the all-gather of the eigenvector blocks"));
-    std::vector<size_t> offs((size_t)ctx->world + 1);
+    const int W = work_world(ctx);
+    std::vector<size_t> offs((size_t)W + 1);
     const size_t comps = CPLX ? 2 : 1;
-    for (int r = 0; r <= ctx->world; ++r) offs[r] = comps * n * (size_t)((long)n * r / ctx->world);
+    for (int r = 0; r <= W; ++r) offs[r] = comps * n * (size_t)((long)n * r / W);
     NLSCHK(do_allgather_blocks(ctx, reinterpret_cast<double*>(C), offs));
+    if (CPLX) NLSCHK(virtual_other_blocks(ctx, reinterpret_cast<double2*>(C), n, c0, c1));
   }
   *used = true;
   return NLS_OK;
@@ -956,8 +992,8 @@ static int evd_hermitian_core(nls_ctx* ctx, double2* A, int n, double* lam, doub
   evd_mark(ctx, 4);
   long c0 = 0, c1 = n;
   if (split) {
-    c0 = (long)n * ctx->rank / ctx->world;
-    c1 = (long)n * (ctx->rank + 1) / ctx->world;
+    c0 = (long)n * work_rank(ctx) / work_world(ctx);
+    c1 = (long)n * (work_rank(ctx) + 1) / work_world(ctx);
   }
   rc = [&]() -> int {
     if (c1 > c0) {
@@ -979,9 +1015,11 @@ static int evd_hermitian_core(nls_ctx* ctx, double2* A, int n, double* lam, doub
   }();
   if (split) {
     NLSCHK(comm_vote(ctx, rc, "before the all-gather of the eigenvector blocks"));
-    std::vector<size_t> offs((size_t)ctx->world + 1);
-    for (int r = 0; r <= ctx->world; ++r) offs[r] = (size_t)2 * n * (size_t)((long)n * r / ctx->world);
+    const int W = work_world(ctx);
+    std::vector<size_t> offs((size_t)W + 1);
+    for (int r = 0; r <= W; ++r) offs[r] = (size_t)2 * n * (size_t)((long)n * r / W);
     NLSCHK(do_allgather_blocks(ctx, reinterpret_cast<double*>(C), offs));
+    NLSCHK(virtual_other_blocks(ctx, C, n, c0, c1));
   } else {
     NLSCHK(rc);
   }

@@ -335,7 +335,7 @@ int grid_local_pass(nls_ctx* ctx, const nls_primal_fit_args* a, const double* si
     int32_t opt = -1, finished = 0;
     std::fill(tm.begin(), tm.end(), 0.0);
     b.B = Bs.data();
-    b.flags = out->best_k < 0 ? 0 : NLS_FIT_FINISH_IF_BELOW;
+    b.flags = (a->flags & NLS_FIT_RESIDUALS_FROM_SWEEP) | (out->best_k < 0 ? 0 : NLS_FIT_FINISH_IF_BELOW);
     b.finish_below = out->best_k < 0 ? 0.0 : out->best_score;
     b.lam = lam.data();
     b.loo_errors = out->table.data() + (size_t)k * G;
@@ -375,7 +375,8 @@ int grid_check_args(nls_ctx* ctx, nls_group* g, const nls_primal_fit_args* a, co
   if (!a || !gr) return bad("args / grid is NULL");
   if (!a->X || !a->y || !a->s || !a->gammas || !a->B) return bad("X, y, s, B and gammas must not be NULL");
   if (a->n < 1 || a->G < 1 || a->d < 1 || a->D < 1) return bad("n, d, D and G must be >= 1");
-  if (a->gamma_index_in != -1 || a->flags != 0) return bad("the grid selects gamma itself: gamma_index_in must be -1 and flags 0");
+  if (a->gamma_index_in != -1 || (a->flags & ~NLS_FIT_RESIDUALS_FROM_SWEEP) != 0)
+    return bad("the grid selects gamma itself: gamma_index_in must be -1 and flags 0 (or NLS_FIT_RESIDUALS_FROM_SWEEP)");
   if (!gr->sigmas || gr->Sg < 1) return bad("sigmas NULL or Sg < 1");
   if (!gr->sigma_index || !gr->gamma_index || !gr->best_valid) return bad("sigma_index, gamma_index and best_valid must not be NULL");
   for (int k = 0; k < gr->Sg; ++k)

@@ -83,6 +83,13 @@ struct nls_ctx {
   bool vote_victim = false;   // ... and this rank was fine itself (its error names the rank that was not)
   double comm_timeout_s = 0;  // > 0: set with nls_comm_set_timeout; else NLS_COMM_TIMEOUT_S, else 300 s
   std::atomic<int>* abort_flag = nullptr;  // member of a group: 1 + rank of a member that failed outside a vote (the others stop waiting)
+  // Measurement hook (nls_comm_set_virtual_rank; bench.py --as-rank r --of W): the context, inside a ONE-rank communicator, does the work of
+  // rank virt_rank of virt_world ranks - its row block is the caller's business; here: the rank-0 tridiagonal solve (or not), its own
+  // column block of the back-transformation, every exchange with its real payload pushed through the communicator - and takes the other
+  // ranks' eigenvector blocks from the copy a first, complete call left behind (virt_Q), so that the results stay those of a real fit.
+  int virt_rank = 0, virt_world = 0;
+  int virt_n = 0;  // order of the matrix whose eigenpairs the workspace "virt.*" holds (0: none yet)
+  bool virt_capture = false;  // the next collective eigendecompositions leave their (lam, real tridiagonal eigenvectors, Q) there
   size_t ws_bytes = 0;        // bytes currently held by the workspace arena
   long twostage_rescues = 0;    // eigendecompositions whose band reduction met a degenerate panel and succeeded at the second, perturbed attempt
   long twostage_fallbacks = 0;  // eigendecompositions whose band reduction met a degenerate panel and fell back to the one-stage panel
@@ -270,6 +277,9 @@ struct SpanGuard {  // RAII so early returns still close the span
 static inline bool multi_rank(const nls_ctx* ctx) {
   return !ctx->solo && (ctx->comm != nullptr || ctx->comm_broken || (ctx->world > 1 && ctx->allreduce));
 }
+// Rank / world as the WORK is divided (the communicator's own, or the virtual ones of the measurement hook).
+static inline int work_rank(const nls_ctx* ctx) { return ctx->virt_world > 1 ? ctx->virt_rank : ctx->rank; }
+static inline int work_world(const nls_ctx* ctx) { return ctx->virt_world > 1 ? ctx->virt_world : ctx->world; }
 
 // ---- failure handling ---------------------------------------------------------------------------------------------------------------
 // The reference has nothing distributed, so the contract is SURVEY.md section 5's: a failure is a status code on EVERY rank, never a hang.
@@ -311,6 +321,11 @@ static int comm_give_up(nls_ctx* ctx, const char* fmt, ...) {
   return fail(ctx, NLS_ERR_COMM, "rank %d of %d: %s - communicator aborted (join a new one with nls_comm_init_rank)", ctx->rank, ctx->world, why);
 }
 
+static bool comm_trace() {  // NLS_COMM_TRACE=1 (diagnostic): one line on stderr per collective wait - rank, what, how long
+  const char* e = std::getenv("NLS_COMM_TRACE");
+  return e && e[0] == '1';
+}
+
 static int comm_wait(nls_ctx* ctx, const char* what) {
   if (!ctx->comm) {
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -318,9 +333,14 @@ static int comm_wait(nls_ctx* ctx, const char* what) {
   }
   const RcclApi* api = rccl_api(nullptr);
   const double t0 = wall(), limit = comm_timeout(ctx);
+  const bool trace = comm_trace();
+  if (trace) std::fprintf(stderr, "[nls comm] rank %d of %d waits for %s\n", ctx->rank, ctx->world, what);
   for (unsigned long polls = 1;; ++polls) {
     const hipError_t q = hipStreamQuery(ctx->stream);
-    if (q == hipSuccess) return NLS_OK;
+    if (q == hipSuccess) {
+      if (trace) std::fprintf(stderr, "[nls comm] rank %d of %d: %s done after %.3f ms\n", ctx->rank, ctx->world, what, 1e3 * (wall() - t0));
+      return NLS_OK;
+    }
     (void)hipGetLastError();  // (hipErrorNotReady must not reach the next launch check)
     if (q != hipErrorNotReady) return comm_give_up(ctx, "%s: the stream failed (%s)", what, hipGetErrorString(q));
     if ((polls & 31) != 0) continue;
@@ -390,15 +410,17 @@ static int do_allgather_blocks(nls_ctx* ctx, double* dbuf, const std::vector<siz
     const RcclApi* api = rccl_api(nullptr);
     RCCL_ENQUEUE(ctx, api, api->GroupStart());
     ncclResult_t first_bad = ncclSuccess;
-    for (int r = 0; r < ctx->world && first_bad == ncclSuccess; ++r)
+    const int W = work_world(ctx);
+    const bool virt = ctx->virt_world > 1;  // (measurement hook: the payloads of all W blocks through the one-rank communicator)
+    for (int r = 0; r < W && first_bad == ncclSuccess; ++r)
       if (offs[r + 1] > offs[r])
-        first_bad = api->Broadcast(dbuf + offs[r], dbuf + offs[r], offs[r + 1] - offs[r], ncclDouble, r, ctx->comm, ctx->stream);
+        first_bad = api->Broadcast(dbuf + offs[r], dbuf + offs[r], offs[r + 1] - offs[r], ncclDouble, virt ? 0 : r, ctx->comm, ctx->stream);
     const ncclResult_t end = api->GroupEnd();  // always: a failed call must not leave the group open
     if (first_bad != ncclSuccess) return comm_give_up(ctx, "ncclBroadcast (all-gather of blocks) failed: %s", api->GetErrorString(first_bad));
     if (end != ncclSuccess) return comm_give_up(ctx, "ncclGroupEnd failed: %s", api->GetErrorString(end));
     return comm_wait(ctx, "all-gather of blocks (grouped ncclBroadcast)");
   }
-  const size_t lo = offs[ctx->rank], hi = offs[ctx->rank + 1], tot = offs[ctx->world];
+  const size_t lo = offs[work_rank(ctx)], hi = offs[work_rank(ctx) + 1], tot = offs[work_world(ctx)];
   if (lo > 0) HIPCHK(ctx, hipMemsetAsync(dbuf, 0, lo * sizeof(double), ctx->stream));
   if (tot > hi) HIPCHK(ctx, hipMemsetAsync(dbuf + hi, 0, (tot - hi) * sizeof(double), ctx->stream));
   return do_allreduce(ctx, dbuf, tot);
@@ -423,10 +445,10 @@ static int comm_vote(nls_ctx* ctx, int local_rc, const char* where) {
   if (ctx->voted_out)  // an earlier vote of this call has failed: every rank is on its way out, nobody votes again
     return local_rc != NLS_OK ? local_rc : fail(ctx, NLS_ERR_COMM, "internal error: a vote %s after a failed vote", where);
   if (ctx->comm_broken) return local_rc != NLS_OK ? local_rc : comm_refuse_broken(ctx);
-  const int W = ctx->world;
+  const int W = work_world(ctx);
   if (!ctx->comm_scratch || W > NLS_COMM_UTIL_MAX) return local_rc != NLS_OK ? local_rc : fail(ctx, NLS_ERR_COMM, "status vote %s: no vote buffer", where);
   std::vector<double> hv((size_t)W, 0.0);
-  hv[(size_t)ctx->rank] = (double)local_rc;
+  hv[(size_t)work_rank(ctx)] = (double)local_rc;
   const std::string own = ctx->err;  // (a failing vote must not bury the local message)
   int rc = NLS_OK;
   if (hipMemcpyAsync(ctx->comm_scratch, hv.data(), sizeof(double) * W, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||

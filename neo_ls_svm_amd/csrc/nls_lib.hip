@@ -185,7 +185,8 @@ extern "C" int nls_ctx_create(int device, nls_ctx** out) {
     std::vector<double> tab((size_t)4 * SINCOS_TAB_N);
     sincos_tab_fill(tab.data());
     if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->sintab), sizeof(double) * tab.size())) != hipSuccess ||
-        (e = hipMemcpy(ctx->sintab, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice)) != hipSuccess) {
+        (e = hipMemcpyAsync(ctx->sintab, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess ||
+        (e = hipStreamSynchronize(ctx->stream)) != hipSuccess) {  // (never the null stream: it waits for other work on the device)
       rocblas_destroy_handle(ctx->blas);
       (void)hipStreamDestroy(ctx->stream);
       return bail("sincos table upload", hipGetErrorString(e));
@@ -328,18 +329,26 @@ extern "C" int nls_device_free(nls_ctx* ctx, void* dptr) {
 }
 extern "C" int nls_memcpy_h2d(nls_ctx* ctx, void* dst, const void* src, size_t bytes) {
   if (!ctx) return NLS_ERR_ARG;
-  HIPCHK(ctx, hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));  // (the library's own stream: the null stream would wait for every blocking stream of the device)
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return NLS_OK;
 }
 extern "C" int nls_memcpy_d2h(nls_ctx* ctx, void* dst, const void* src, size_t bytes) {
   if (!ctx) return NLS_ERR_ARG;
-  HIPCHK(ctx, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return NLS_OK;
 }
 extern "C" int nls_synchronize(nls_ctx* ctx) {
   if (!ctx) return NLS_ERR_ARG;
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  HIPCHK(ctx, hipDeviceSynchronize());
+  // the context's own streams, not the device: other contexts (another rank of a group on this device in the tests, the host application's
+  // own work) are none of this context's business - and may legitimately be waiting for it
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  for (hipStream_t st : {ctx->stream2, ctx->copy_stream, ctx->copy_lane[0], ctx->copy_lane[1], ctx->copy_lane[2]})
+    if (st) HIPCHK(ctx, hipStreamSynchronize(st));
   return NLS_OK;
 }
 extern "C" int nls_device_info(nls_ctx* ctx, char* name, int name_len, int* compute_units, size_t* hbm_bytes) {
@@ -926,7 +935,7 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
     if (!a->X || !a->y || !a->s || !a->gammas) return fail(ctx, NLS_ERR_ARG, "X, y, s and gammas must not be NULL");
     if (a->n < 1 || a->G < 1) return fail(ctx, NLS_ERR_ARG, "n and G must be >= 1 (n=%ld, G=%d)", (long)a->n, a->G);
     if (a->gamma_index_in >= a->G) return fail(ctx, NLS_ERR_ARG, "gamma_index_in out of range");
-    if (a->flags & ~(NLS_FIT_SWEEP_ONLY | NLS_FIT_FINISH_IF_BELOW)) return fail(ctx, NLS_ERR_ARG, "unknown flag bits 0x%x", (unsigned)a->flags);
+    if (a->flags & ~(NLS_FIT_SWEEP_ONLY | NLS_FIT_FINISH_IF_BELOW | NLS_FIT_RESIDUALS_FROM_SWEEP)) return fail(ctx, NLS_ERR_ARG, "unknown flag bits 0x%x", (unsigned)a->flags);
     return NLS_OK;
   }();
   HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -953,7 +962,6 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
     tm[NLS_T_ROW_CHUNK] = (double)st.rc;
   }));
   const int D1 = mp.D1, Kf = mp.Kf, Np = mp.Np;
-  (void)Kf;
 
   // ---- phase B: EVD of A / c (P4) --------------------------------------------------------------
   double2 *Acm = nullptr, *Qcm = nullptr, *db = nullptr;
@@ -1163,7 +1171,10 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
   if (rc == NLS_OK && !finish) {  // a non-winning sigma of a gamma x sigma grid: the error curve is all that is needed (no further exchange: every rank
     if (a->finished) *a->finished = 0;  // decides the same from the same numbers)
     NLSCHK(spans_collect(ctx, tm));
-    if (a->lam) HIPCHK(ctx, hipMemcpy(a->lam, lam, sizeof(double) * D1, hipMemcpyDeviceToHost));
+    if (a->lam) {
+      HIPCHK(ctx, hipMemcpyAsync(a->lam, lam, sizeof(double) * D1, hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
     if (a->loo_errors) std::memcpy(a->loo_errors, herrs.data(), sizeof(double) * G);
     if (a->objective) std::memcpy(a->objective, hobj.data(), sizeof(double) * G);
     if (a->gamma_index) *a->gamma_index = opt;
@@ -1224,6 +1235,10 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
   } side_join;
   bool side_copy = false, y_carried = false;
   double2* ysolve = nullptr;  // beta = cho_solve(L_, b): L y = b is carried through the factorisation, L^H beta = y follows the download
+  // residuals_ = Re(phi beta) - y is defined on the RETURNED beta (_neo_ls_svm.py:178-182).  When that is the Cholesky re-solve (the caller asked
+  // for L_; a sharded fit: rank 0's beta is everybody's) one more pass over the feature planes computes it from that beta, below; otherwise the
+  // returned beta IS the eigendecomposition's and the sweep's column (k_loo_column) is its residual vector already.
+  const bool res_from_beta = a->residuals && (a->L || multi_rank(ctx)) && !(a->flags & NLS_FIT_RESIDUALS_FROM_SWEEP);
   rc = [&]() -> int {
     HIPCHK(ctx, hipMemcpyAsync(hsum, csum, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     NLSCHK(ws_get_t(ctx, "chol.beta", (size_t)D1, &dbeta));
@@ -1274,8 +1289,7 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
       HIPCHK(ctx, hipGetLastError());
     }
 
-    // residuals_ = Re(phi beta) - y (P8) came out of k_loo_column: the sweep's table holds Re(phi beta(gamma)) on the whole grid (round 2 made another
-    // pass over the feature planes for it - 11 ms at c3, and a second feature map when the planes are not resident).
+    // (k_loo_column has left Re(phi beta_evd(gamma*)) - y in `res`: the sweep's table holds Re(phi beta(gamma)) on the whole grid)
 
     // ---- outputs -------------------------------------------------------------------------------
     {
@@ -1288,7 +1302,7 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
       NLSCHK(d2h(a->loo_residuals, loo_res, sizeof(double) * n));
       NLSCHK(d2h(a->loo_leverage, loo_lev, sizeof(double) * n));
       NLSCHK(d2h(a->loo_std, loo_std, sizeof(double) * n));
-      NLSCHK(d2h(a->residuals, res, sizeof(double) * n));
+      if (!res_from_beta) NLSCHK(d2h(a->residuals, res, sizeof(double) * n));
     }
     if (side_copy) {  // everything else is enqueued: the block columns of L_ now follow the factorisation (pageable memory: each copy blocks this thread)
       prefault.join();
@@ -1321,9 +1335,9 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
     if (side && multi_rank(ctx)) {
       // sharded: rank 0's factorisation is judged BEFORE its beta is broadcast - a non-positive pivot goes into the vote below and every rank
       // raises the same LinAlgError (one rank: the check after the outputs, as before, so that the side streams keep running beside them)
-      HIPCHK(ctx, hipStreamSynchronize(ctx->stream2));
       rocblas_int info2 = 0;
-      HIPCHK(ctx, hipMemcpy(&info2, dinfo2, sizeof(info2), hipMemcpyDeviceToHost));
+      HIPCHK(ctx, hipMemcpyAsync(&info2, dinfo2, sizeof(info2), hipMemcpyDeviceToHost, ctx->stream2));
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream2));
       if (info2 != 0) return fail(ctx, NLS_ERR_LINALG, "Cholesky factorisation of gamma* C + A: pivot %d is not positive (matrix not positive definite)", (int)info2);
     }
     return NLS_OK;
@@ -1336,11 +1350,33 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
     NLSCHK(rc);
   }
   if (a->beta) HIPCHK(ctx, hipMemcpyAsync(a->beta, dbeta, sizeof(double2) * D1, hipMemcpyDeviceToHost, ctx->stream));
+  if (res_from_beta) {  // (no exchange follows: a failure here simply returns)
+    SpanGuard g(ctx, NLS_T_RESIDUALS);
+    double *br = nullptr, *bi = nullptr;
+    NLSCHK(ws_get_t(ctx, "chol.br", (size_t)Kf, &br));
+    NLSCHK(ws_get_t(ctx, "chol.bi", (size_t)Kf, &bi));
+    hipLaunchKernelGGL(k_split_vec, dim3((unsigned)((Kf + 255) / 256)), dim3(256), 0, ctx->stream, dbeta, mp.D, Kf, br, bi);
+    HIPCHK(ctx, hipGetLastError());
+    // resident planes: one launch over all rows (the planes carry the row scale rs: undone by inv_rs); else the feature map again, chunk by chunk
+    for (long r0 = 0; r0 < n; r0 += st.resident ? n : st.rc) {
+      const long rows = st.resident ? n : std::min<long>(st.rc, n - r0);
+      if (!st.resident) {
+        SpanGuard gf(ctx, NLS_T_FEATUREMAP);
+        NLSCHK(launch_featuremap_planes(ctx, mp, st.dX + r0 * mp.d, rows, round_up(rows, BM), st.rs + r0, st.Fc, st.Fs));
+        tm[NLS_T_FEATUREMAP_LAUNCHES] += 1;
+        tm[NLS_T_FEATUREMAP_FLOPS] += 2.0 * rows * mp.d * mp.D;
+      }
+      hipLaunchKernelGGL(k_plane_gemv, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, planes_c(st, r0), planes_s(st, r0), Kf, br, bi, dbeta, mp.D,
+                         rows, st.dy + r0, is_clf, res + r0, st.inv_rs + r0);
+      HIPCHK(ctx, hipGetLastError());
+    }
+    HIPCHK(ctx, hipMemcpyAsync(a->residuals, res, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+  }
   if (side) {  // join the side streams; their stage times go into the cholesky / download slots
+    rocblas_int info2 = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&info2, dinfo2, sizeof(info2), hipMemcpyDeviceToHost, ctx->stream2));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream2));
     HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));
-    rocblas_int info2 = 0;
-    HIPCHK(ctx, hipMemcpy(&info2, dinfo2, sizeof(info2), hipMemcpyDeviceToHost));
     if (info2 != 0) return fail(ctx, NLS_ERR_LINALG, "Cholesky factorisation of gamma* C + A: pivot %d is not positive (matrix not positive definite)", (int)info2);
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, ctx->side_ev[0], ctx->side_ev[1]) == hipSuccess) tm[NLS_T_CHOLESKY] += ms * 1e-3;

@@ -304,7 +304,7 @@ def rank_codes(y, ctx: Context | None = None):
 
 
 def _primal_args(X, y, s, shift, scale, B, is_classifier, gammas, gamma_index, ctx, want_L, want_rows, sweep_only, finish_below,
-                 complexity_matrix):
+                 complexity_matrix, residuals_from_sweep=False):
     """Marshal one ``nls_primal_fit_args``: returns (args, out dict of the output arrays, keep-alive tuple)."""
     X = _f64(ctx.held(X), "X")
     if len(X.shape) != 2:
@@ -338,6 +338,7 @@ def _primal_args(X, y, s, shift, scale, B, is_classifier, gammas, gamma_index, c
     a.is_classifier = 1 if is_classifier else 0
     a.gamma_index_in = -1 if gamma_index is None else int(gamma_index)
     a.flags = (_lib.FIT_SWEEP_ONLY if sweep_only else 0) | (_lib.FIT_FINISH_IF_BELOW if finish_below is not None else 0)
+    a.flags |= _lib.FIT_RESIDUALS_FROM_SWEEP if residuals_from_sweep else 0
     a.finish_below = float(finish_below) if finish_below is not None else 0.0
     Cm = None
     if complexity_matrix is not None:
@@ -395,6 +396,7 @@ def primal_fit(
     sweep_only: bool = False,
     finish_below: float | None = None,
     complexity_matrix=None,
+    residuals_from_sweep: bool = False,
 ) -> dict:
     """Primal LS-SVM fit with the full gamma sweep (P1-P9).
 
@@ -411,10 +413,13 @@ def primal_fit(
     outputs only when the selected objective is below t (``out["finished"]`` says which) - how a gamma x sigma grid
     avoids finishing sigmas that cannot win.  ``complexity_matrix``: None = identity (the reference's only reachable
     case), else a (D+1) x (D+1) symmetric positive definite matrix -> generalised-EVD branch (``_neo_ls_svm.py:122-124``).
+    ``residuals`` is Re(phi beta) - y of the returned beta as the reference computes it (``_neo_ls_svm.py:178-182``: one more pass over
+    the feature planes when beta is the Cholesky re-solve); ``residuals_from_sweep=True`` takes the sweep table's column instead
+    (the eigendecomposition's beta at gamma*, equal to ~1e-9 relative, no extra pass).
     """
     ctx = ctx or default_context()
     a, out, keep = _primal_args(X, y, s, shift, scale, B, is_classifier, gammas, gamma_index, ctx, want_L, want_rows, sweep_only, finish_below,
-                                complexity_matrix)  # fmt: skip
+                                complexity_matrix, residuals_from_sweep)  # fmt: skip
     fn = ctx.lib.nls_group_primal_fit if isinstance(ctx, Group) else ctx.lib.nls_primal_fit
     ctx._check(fn(ctx.handle, C.byref(a)))
     return _primal_result(out, keep, want_rows)

@@ -4,11 +4,16 @@
 // path (ctx->comm != NULL: ncclAllReduce / ncclBroadcast / grouped broadcasts, csrc/nls_host.h, csrc/nls_evd.hip)
 // would otherwise run for the first time on an 8-GPU node.  This shim implements exactly the entry points
 // csrc/nls_comm.hip resolves, with RCCL's semantics as far as the library relies on them:
-//   * a collective is ASYNCHRONOUS, like RCCL's: the call returns at once, the caller's stream is held by a small kernel that spins on
-//     a host flag (RCCL's kernels spin on their peers the same way) and a worker thread of the communicator does the exchange - it waits
-//     for the stream to reach the call, stages the data through a POSIX shared-memory segment, every rank reduces all slots in rank
-//     order (identical bits on every rank), writes the result back and releases the stream.  So a rank whose peer never arrives sits in
-//     `hipStreamQuery == hipErrorNotReady`, exactly what the library's deadline (comm_wait) has to deal with;
+//   * collectives are ordered on the stream they are given; the data is staged through a POSIX shared-memory segment and every rank
+//     reduces all slots in rank order (identical bits on every rank).  Two modes:
+//       - default (synchronous): the call drains the stream and does the exchange before it returns.  Nothing of the shim is ever pending
+//         on the device, so the functional tests - N ranks on ONE GPU - cannot dead-lock on a device-wide synchronisation (a hipFree of a
+//         growing workspace, a hipDeviceSynchronize of the caller) that would wait for a peer's pending collective, which waits for us;
+//         RCCL itself never meets that: it refuses two ranks per device;
+//       - NLS_SHIM_ASYNC=1 (the failure-handling tests): ASYNCHRONOUS like RCCL - the call returns at once, the caller's stream is held by
+//         a small kernel that spins on a host flag (RCCL's kernels spin on their peers the same way) and a worker thread of the
+//         communicator does the exchange once the stream has reached the call, then releases the stream.  A rank whose peer never
+//         arrives then sits in `hipStreamQuery == hipErrorNotReady`, exactly what the library's deadline (comm_wait) has to deal with;
 //   * calls between ncclGroupStart / ncclGroupEnd are deferred to ncclGroupEnd;
 //   * in-place and out-of-place buffers, ncclDouble with ncclSum / ncclMax, arbitrary roots and unequal counts per call;
 //   * ncclCommAbort ends this rank's pending collectives (the stream is released) WITHOUT telling the peers - as with RCCL, they find out
@@ -95,6 +100,14 @@ struct Deferred {
 thread_local int g_group_depth = 0;
 thread_local std::vector<Deferred> g_deferred;
 
+bool async_mode() {
+#ifdef SHIM_HOST_ONLY
+  return false;
+#else
+  static const bool on = [] { const char* e = std::getenv("NLS_SHIM_ASYNC"); return e && e[0] == '1'; }();
+  return on;
+#endif
+}
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 double timeout_s() {
   const char* e = std::getenv("NLS_SHIM_TIMEOUT_S");
@@ -221,12 +234,16 @@ void stop_worker(Comm* c) {
 }
 #endif
 
-// One collective of communicator c on `stream`: inline in the host-only build, through the worker otherwise.
+// One collective of communicator c on `stream`: inline (synchronous mode, host-only build) or through the worker (NLS_SHIM_ASYNC=1).
 ncclResult_t launch(Comm* c, hipStream_t stream, std::function<ncclResult_t()> fn) {
 #ifdef SHIM_HOST_ONLY
   (void)stream;
   return fn();
 #else
+  if (!async_mode()) {
+    if (hipStreamSynchronize(stream) != hipSuccess) return ncclUnhandledCudaError;
+    return fn();
+  }
   if (c->aborted.load()) return ncclInvalidUsage;
   if (c->async_err.load() != 0) return (ncclResult_t)c->async_err.load();  // a communicator in error state takes no more work
   Job j;
@@ -330,7 +347,7 @@ ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId id, int
     return ncclUnhandledCudaError;
   }
   *c->flag = 0;
-  c->worker = std::thread(worker_main, c);
+  if (async_mode()) c->worker = std::thread(worker_main, c);
 #endif
   const ncclResult_t r = barrier(c);  // like RCCL: returns once every rank has joined
   if (r != ncclSuccess) {

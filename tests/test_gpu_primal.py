@@ -198,18 +198,30 @@ def test_gram_tile_orders_are_bit_identical(golden_loader, monkeypatch):
 
 
 def test_returned_residuals_are_those_of_the_returned_beta(golden_loader, hp):
-    """``residuals`` comes from the sweep's table (the eigendecomposition's beta at gamma*), ``beta`` from the Cholesky re-solve
-    (``_neo_ls_svm.py:176-179``): the returned pair must agree, Re(phi(X) beta) - y == residuals, to cond * eps (header note)."""
+    """``residuals`` is Re(phi beta) - y of the RETURNED beta - the Cholesky re-solve when ``L`` is requested - as the reference computes it
+    (``_neo_ls_svm.py:176-182``): equal to rounding to the decision function of that beta, and closer to the reference's fixture than the
+    sweep table's column (``residuals_from_sweep=True``: the eigendecomposition's beta at gamma*, cond * eps away).  Without ``L`` the
+    returned beta IS the eigendecomposition's, and the column is its residual vector."""
     for name in ("primal_reg_n3000_d20_D256", "primal_clf_n3000_d16_D256_wz"):
         g = golden_loader(name)
         y = signed_targets(g)
         clf = g["task"] == "clf"
+
+        def residuals_of(beta):
+            yhat, _ = hp.primal_predict(g["X"], g["shift"], g["scale"], g["B"], beta=beta)
+            e = yhat - y
+            return np.where(y * e > 0, 0.0, e) if clf else e  # residual clipping of the classifier (_neo_ls_svm.py:180-182)
+
+        scale = max(np.max(np.abs(g["residuals"])), 1e-300)
         r = hp.primal_fit(g["X"], y, g["s"], g["shift"], g["scale"], g["B"], clf)
-        yhat, _ = hp.primal_predict(g["X"], g["shift"], g["scale"], g["B"], beta=r["beta"])
-        e = yhat - y
-        if clf:  # residual clipping of the classifier (_neo_ls_svm.py:180-182)
-            e = np.where(y * e > 0, 0.0, e)
-        assert np.max(np.abs(e - r["residuals"])) <= 1e-9 * max(np.max(np.abs(r["residuals"])), 1e-300), name
+        assert np.max(np.abs(residuals_of(r["beta"]) - r["residuals"])) <= 2e-13 * scale, name
+        assert np.max(np.abs(r["residuals"] - g["residuals"])) <= 1e-11 * scale, name
+        rs = hp.primal_fit(g["X"], y, g["s"], g["shift"], g["scale"], g["B"], clf, residuals_from_sweep=True)
+        assert np.array_equal(rs["beta"], r["beta"])
+        assert np.max(np.abs(rs["residuals"] - r["residuals"])) <= 1e-9 * scale, name
+        re = hp.primal_fit(g["X"], y, g["s"], g["shift"], g["scale"], g["B"], clf, want_L=False)
+        assert np.max(np.abs(residuals_of(re["beta"]) - re["residuals"])) <= 1e-9 * scale, name
+        assert np.array_equal(re["residuals"], rs["residuals"])  # both are the sweep's column
 
 
 def test_sigma_grid_matches_reference(golden_loader, hp):

@@ -50,6 +50,7 @@ CONFIGS = {
 }
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X dense fp64 matrix peak; measured issue rate 78.0 (profiles/r01_probe_mfma.log)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E (MI355X_MICROARCH.md); a plain 16-byte copy reaches 4.6 TB/s (profiles/r01_probe_hw.log)
+K1_VALU_PER_FEATURE = 36.6  # vector instructions per feature in k_featuremap's epilogue (34.9 sincos + scale + stores' addresses, 1.7 range test): tools/k1_valu_count.py
 PRESTEP_PREFIX = 200_000  # for n = 1e6 the affine pre-step is fitted on a fixed 2e5-row prefix
 
 
@@ -710,6 +711,17 @@ def main():
                                   "traffic_over_algorithmic": None if k1_traffic is None else k1_traffic * fm_rows / fm_bytes},
                 "avg_launch_ms": 1e3 * stage["featuremap"] / fm_launches,
                 "algorithmic_bytes_per_launch": fm_bytes / fm_launches,
+                # The bound that actually binds K1: the fp64 matrix pipe and the fp64 vector ALU share one datapath (profiles/r02_probe_f64_coexec.log),
+                # so the K = d product and the sincos epilogue ADD: t >= 2 rows dk Kf / MFMA peak + (VALU instructions per feature) rows Kf / issue rate.
+                "datapath": (lambda dk, mat_s, valu_s: {
+                    "bound": "fp64 datapath (MFMA + VALU, serialised)",
+                    "matrix_ms_per_launch": 1e3 * mat_s / fm_launches,
+                    "valu_ms_per_launch": 1e3 * valu_s / fm_launches,
+                    "valu_instructions_per_feature": K1_VALU_PER_FEATURE,
+                    "valu_issue_rate_note": "256 CUs x 4 SIMDs x one wave64 fp64 instruction per 4 cycles at 2.4 GHz = 3.93e13 lane-operations/s; count from the ISA: tools/k1_valu_count.py",
+                    "bound_ms_per_launch": 1e3 * (mat_s + valu_s) / fm_launches,
+                    "frac": (mat_s + valu_s) / max(stage["featuremap"], 1e-12),
+                })(-(-d // 16) * 16, 2.0 * fm_rows * (-(-d // 16) * 16) * Kf / (FP64_MFMA_PEAK_TFLOPS * 1e12), K1_VALU_PER_FEATURE * fm_rows * Kf / 3.93e13),
             },
             "stage_ms_per_step": {
                 k: round(1e3 * stage.get(k, 0.0) / args.steps, 3)

@@ -1239,9 +1239,13 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
   // for L_; a sharded fit: rank 0's beta is everybody's) one more pass over the feature planes computes it from that beta, below; otherwise the
   // returned beta IS the eigendecomposition's and the sweep's column (k_loo_column) is its residual vector already.
   const bool res_from_beta = a->residuals && (a->L || multi_rank(ctx)) && !(a->flags & NLS_FIT_RESIDUALS_FROM_SWEEP);
+  auto mark = [&](const char* what) {  // NLS_COMM_TRACE=1: where the host is in the last stretch (rank 0 works while the others wait at the vote)
+    if (comm_trace() && multi_rank(ctx)) std::fprintf(stderr, "[nls mark] rank %d: %s\n", ctx->rank, what);
+  };
   rc = [&]() -> int {
     HIPCHK(ctx, hipMemcpyAsync(hsum, csum, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     NLSCHK(ws_get_t(ctx, "chol.beta", (size_t)D1, &dbeta));
+    mark("score sums requested");
     if (a->L) {
       NLSCHK(fault_point(ctx, "cholesky"));
       if (!ctx->stream2) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));  // (the dual path's look-ahead may have made it)
@@ -1249,6 +1253,7 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
         if (rocblas_create_handle(&ctx->blas2) != rocblas_status_success) return fail(ctx, NLS_ERR_HIP, "rocblas_create_handle (side stream) failed");
         BLASCHK(ctx, rocblas_set_stream(ctx->blas2, ctx->stream2));
       }
+      mark("side stream and rocBLAS handle exist");
       for (auto& e : ctx->side_ev)
         if (!e) HIPCHK(ctx, hipEventCreate(&e));
       NLSCHK(ws_get_t(ctx, "chol.info2", 4, &dinfo2));
@@ -1274,9 +1279,11 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
       NLSCHK(ensure_copy_stream(ctx, nblk));
       side_join.s2 = ctx->copy_stream;
       NLSCHK(ws_get_t(ctx, "chol.solve", (size_t)D1, &ysolve));
+      mark("copy streams exist");
       NLSCHK(zpotrf_lower(ctx, s2, ctx->blas2, Acm, D1, (long)D1, reinterpret_cast<int*>(dinfo2), NBK, db, ysolve, &y_carried));
       HIPCHK(ctx, hipEventRecord(ctx->side_ev[1], s2));
       side_copy = true;
+      mark("factorisation enqueued");
     }
     {
       SpanGuard g(ctx, NLS_T_RESIDUALS);
@@ -1304,10 +1311,12 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
       NLSCHK(d2h(a->loo_std, loo_std, sizeof(double) * n));
       if (!res_from_beta) NLSCHK(d2h(a->residuals, res, sizeof(double) * n));
     }
+    mark("row outputs requested");
     if (side_copy) {  // everything else is enqueued: the block columns of L_ now follow the factorisation (pageable memory: each copy blocks this thread)
       prefault.join();
       NLSCHK(download_block_columns(ctx, a->L, Acm, D1, (long)D1, sizeof(double2), 512, true));
       HIPCHK(ctx, hipEventRecord(ctx->side_ev[2], ctx->copy_stream));
+      mark("factor downloaded");
     }
     if (side_copy) {
       // beta = cho_solve(L_, b) (_neo_ls_svm.py:178).  The copy stream has conjugated the factor in place on its way out (Acm now holds
@@ -1339,6 +1348,7 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
       HIPCHK(ctx, hipMemcpyAsync(&info2, dinfo2, sizeof(info2), hipMemcpyDeviceToHost, ctx->stream2));
       HIPCHK(ctx, hipStreamSynchronize(ctx->stream2));
       if (info2 != 0) return fail(ctx, NLS_ERR_LINALG, "Cholesky factorisation of gamma* C + A: pivot %d is not positive (matrix not positive definite)", (int)info2);
+      mark("factorisation judged");
     }
     return NLS_OK;
   }();
@@ -1360,12 +1370,8 @@ extern "C" int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* a) {
     // resident planes: one launch over all rows (the planes carry the row scale rs: undone by inv_rs); else the feature map again, chunk by chunk
     for (long r0 = 0; r0 < n; r0 += st.resident ? n : st.rc) {
       const long rows = st.resident ? n : std::min<long>(st.rc, n - r0);
-      if (!st.resident) {
-        SpanGuard gf(ctx, NLS_T_FEATUREMAP);
+      if (!st.resident)  // (its time stays in the residuals stage: spans do not nest)
         NLSCHK(launch_featuremap_planes(ctx, mp, st.dX + r0 * mp.d, rows, round_up(rows, BM), st.rs + r0, st.Fc, st.Fs));
-        tm[NLS_T_FEATUREMAP_LAUNCHES] += 1;
-        tm[NLS_T_FEATUREMAP_FLOPS] += 2.0 * rows * mp.d * mp.D;
-      }
       hipLaunchKernelGGL(k_plane_gemv, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, planes_c(st, r0), planes_s(st, r0), Kf, br, bi, dbeta, mp.D,
                          rows, st.dy + r0, is_clf, res + r0, st.inv_rs + r0);
       HIPCHK(ctx, hipGetLastError());

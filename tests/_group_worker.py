@@ -281,7 +281,7 @@ def mode_fault(world):
         hp.primal_fit(X, y, s, shift, scale, B, False, ctx=grp)
     except (NlsError, npl.LinAlgError) as exc:
         waited, msg = time.monotonic() - t0, str(exc)
-        assert waited < 60.0, f"{waited:.1f} s: the deadline, not the vote, ended the call"
+        assert waited < 45.0, f"{waited:.1f} s: the deadline, not the vote, ended the call"
         assert isinstance(exc, npl.LinAlgError if linalg else NlsError), (type(exc), msg)
         # the group reports the member that failed of its own accord, with that member's message
         assert f"rank {bad} of {world}" in msg and "injected fault" in msg and f"'{site}'" in msg, msg
@@ -308,8 +308,8 @@ def mode_lost(world):
         hp.primal_fit(X, y, s, shift, scale, B, False, ctx=grp)
     except NlsError as exc:
         waited, msg = time.monotonic() - t0, str(exc)
-        # NLS_COMM_TIMEOUT_S is 240 s in this test: returning within seconds shows the abort flag, not the deadline, released the members
-        assert waited < 60.0, f"{waited:.1f} s"
+        # NLS_COMM_TIMEOUT_S is 90 s in this test: returning within seconds shows the abort flag, not the deadline, released the members
+        assert waited < 45.0, f"{waited:.1f} s"
         assert f"rank {bad} of {world}" in msg and "injected" in msg, msg
     else:
         raise AssertionError("the lost RCCL call did not surface")

@@ -13,7 +13,8 @@
 //       - NLS_SHIM_ASYNC=1 (the failure-handling tests): ASYNCHRONOUS like RCCL - the call returns at once, the caller's stream is held by
 //         a small kernel that spins on a host flag (RCCL's kernels spin on their peers the same way) and a worker thread of the
 //         communicator does the exchange once the stream has reached the call, then releases the stream.  A rank whose peer never
-//         arrives then sits in `hipStreamQuery == hipErrorNotReady`, exactly what the library's deadline (comm_wait) has to deal with;
+//         arrives then sits in `hipStreamQuery == hipErrorNotReady`, exactly what the library's deadline (comm_wait) has to deal with.
+//         Run it with GPU_MAX_HW_QUEUES=32: a held stream holds its hardware queue, and by default the streams of one process share 4;
 //   * calls between ncclGroupStart / ncclGroupEnd are deferred to ncclGroupEnd;
 //   * in-place and out-of-place buffers, ncclDouble with ncclSum / ncclMax, arbitrary roots and unequal counts per call;
 //   * ncclCommAbort ends this rank's pending collectives (the stream is released) WITHOUT telling the peers - as with RCCL, they find out
@@ -280,8 +281,12 @@ bool injected_rank_failure(Comm* c) {
 void release(Comm* c) {
 #ifndef SHIM_HOST_ONLY
   stop_worker(c);
-  if (c->flag) (void)hipHostFree(c->flag);
-  if (c->copy) (void)hipStreamDestroy(c->copy);
+  // An ABORTED communicator keeps its flag page and copy stream (a leak of test infrastructure): hipHostFree waits for the whole device, and on
+  // the one device the ranks share a peer's stream may be held by its spinning kernel - waiting for this very rank.
+  if (!c->aborted.load()) {
+    if (c->flag) (void)hipHostFree(c->flag);
+    if (c->copy) (void)hipStreamDestroy(c->copy);
+  }
 #endif
   if (c->base) munmap(c->base, c->map_bytes);
   delete c;

@@ -18,6 +18,7 @@ import pytest
 
 HERE = Path(__file__).resolve().parent
 pytestmark = pytest.mark.gpu
+ASYNC_STAND_IN = {"NLS_SHIM_ASYNC": "1", "GPU_MAX_HW_QUEUES": "32"}  # (see tests/test_rccl_shim.py: one process, many streams, one device)
 
 
 def _run(mode, world, extra_env=None, timeout=1200):
@@ -68,12 +69,12 @@ def test_one_member_fails_locally_the_group_call_returns(world, spec):
     """One member of the group fails on its own (``NLS_FAULT_INJECT=site:rank[:code]``) at each stretch of the sharded fit: no member is
     left in a collective and the one call returns the failing member's error (``LinAlgError`` for a factorisation failure) - at the next
     status vote, not at the deadline - and the next call on the same group, the same communicator, is right."""
-    _run("fault", world, {"NLS_FAULT_INJECT": spec, "NLS_COMM_TIMEOUT_S": "240", "NLS_SHIM_ASYNC": "1"}, timeout=900)
+    _run("fault", world, {"NLS_FAULT_INJECT": spec, "NLS_COMM_TIMEOUT_S": "90", **ASYNC_STAND_IN}, timeout=900)
 
 
 @pytest.mark.parametrize("world, bad, call", [(2, 1, 4), (8, 5, 8), (8, 0, 3)])
 def test_one_member_loses_an_rccl_call_the_abort_flag_releases_the_others(world, bad, call):
     """The ``call``-th collective of ONE member fails inside the communication library; that member's thread returns, the others are
     inside a collective it will never join.  The group's abort flag (polled by their bounded waits) releases them at once - with the
-    deadline at 240 s the call must still return within seconds - and the group joins a fresh communicator for the next call."""
-    _run("lost", world, {"NLS_SHIM_FAIL_RANK": str(bad), "NLS_SHIM_FAIL_CALL": str(call), "NLS_COMM_TIMEOUT_S": "240", "NLS_SHIM_ASYNC": "1"}, timeout=900)
+    deadline at 90 s the call must still return within seconds - and the group joins a fresh communicator for the next call."""
+    _run("lost", world, {"NLS_SHIM_FAIL_RANK": str(bad), "NLS_SHIM_FAIL_CALL": str(call), "NLS_COMM_TIMEOUT_S": "90", **ASYNC_STAND_IN}, timeout=900)

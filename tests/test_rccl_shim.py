@@ -21,6 +21,11 @@ HERE = Path(__file__).resolve().parent
 SHIM_SRC = HERE / "csrc" / "rccl_shim.cpp"
 SHIM_DIR = HERE / "csrc" / "_shim"
 HIPCC = "/opt/rocm/bin/hipcc"
+# The stand-in's asynchronous mode holds a rank's stream with a spinning kernel.  HIP maps the streams of ONE process onto 4 hardware queues by
+# default, and a stream that shares a queue with a held one does not run: with the ranks' main streams, the stand-in's copy streams and rank 0's
+# side streams all on one device (a group: one process) that dead-locks - measured: GPU_MAX_HW_QUEUES=4 hangs, 16 / 32 do not.  (On a real node
+# every rank has its own device and holds only its own queues.)
+ASYNC_STAND_IN = {"NLS_SHIM_ASYNC": "1", "GPU_MAX_HW_QUEUES": "32"}
 
 
 def build_shim(host_only: bool) -> Path:
@@ -107,7 +112,7 @@ def _launch_native(mode, world, extra_env=None, timeout=900):
 def test_native_communicator_world2_asynchronous_stand_in():
     """The same fits with the stand-in in its ASYNCHRONOUS mode (``NLS_SHIM_ASYNC=1``: the call returns, a kernel holds the stream, a worker
     thread exchanges - RCCL's shape): every collective wait of the library goes through its polling loop for real."""
-    _launch_native("gpu_rccl", 2, {"NLS_SHIM_ASYNC": "1"})
+    _launch_native("gpu_rccl", 2, {**ASYNC_STAND_IN})
 
 
 @pytest.mark.gpu
@@ -156,7 +161,7 @@ def test_one_rank_fails_locally_every_rank_returns_at_the_vote(world, spec):
     library) at each stretch of the sharded fit: the rank goes to the next status vote instead of leaving, every rank returns an error
     at once - its own on the failed rank, NLS_ERR_COMM naming rank and code on the others, ``LinAlgError`` everywhere for a factorisation
     failure on rank 0 - and the same communicator carries the next fit."""
-    _launch_native("gpu_rccl_fault", world, {"NLS_FAULT_INJECT": spec, "NLS_COMM_TIMEOUT_S": "240", "NLS_SHIM_ASYNC": "1"}, timeout=900)
+    _launch_native("gpu_rccl_fault", world, {"NLS_FAULT_INJECT": spec, "NLS_COMM_TIMEOUT_S": "90", **ASYNC_STAND_IN}, timeout=900)
 
 
 @pytest.mark.gpu
@@ -166,7 +171,7 @@ def test_one_rank_loses_an_rccl_call_the_others_meet_the_deadline(world, bad, ca
     rank returns at once; the others sit in a collective whose peer has left and are released by the library's own deadline
     (``NLS_COMM_TIMEOUT_S`` = 10 s here, far below the stand-in's safety net): NLS_ERR_COMM, communicator aborted, further
     collective calls refused, ``nls_comm_destroy`` makes the context a single rank again."""
-    env = {"NLS_SHIM_FAIL_RANK": str(bad), "NLS_SHIM_FAIL_CALL": str(call), "NLS_TEST_LOST_RANK": str(bad), "NLS_COMM_TIMEOUT_S": "10", "NLS_SHIM_ASYNC": "1"}
+    env = {"NLS_SHIM_FAIL_RANK": str(bad), "NLS_SHIM_FAIL_CALL": str(call), "NLS_TEST_LOST_RANK": str(bad), "NLS_COMM_TIMEOUT_S": "10", **ASYNC_STAND_IN}
     _launch_native("gpu_rccl_lost_call", world, env, timeout=900)
 
 
@@ -178,7 +183,7 @@ def test_one_rank_dies_the_others_meet_the_deadline(world, bad):
     lib = build_shim(host_only=False)
     with tempfile.TemporaryDirectory() as td:
         env = {"NLS_RCCL_LIB": str(lib), "NLS_RENDEZVOUS_DIR": td, "NLS_SHIM_SLOT_BYTES": str(1 << 20), "NLS_SHIM_TIMEOUT_S": "300",
-               "NLS_TEST_LOST_RANK": str(bad), "NLS_COMM_TIMEOUT_S": "10", "NLS_SHIM_ASYNC": "1"}  # fmt: skip
+               "NLS_TEST_LOST_RANK": str(bad), "NLS_COMM_TIMEOUT_S": "10", **ASYNC_STAND_IN}  # fmt: skip
         _run_ranks([str(HERE / "_sharded_worker.py"), "gpu_rccl_lost_dead"], world, env, 900, expect_exit={bad: 7})
 
 

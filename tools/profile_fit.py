@@ -15,5 +15,6 @@ t = time.time(); mk().fit(X[:20000], y[:20000]); print(f"warm-up fit (20k rows) 
 pr = cProfile.Profile(); t = time.time(); pr.enable(); m = mk().fit(X, y); pr.disable(); el = time.time() - t
 print(f"n={n} d={d} D={D} {'clf' if clf else 'reg'}: fit end to end {el:.2f} s, solver {m.fit_timings_['total']:.2f} s")
 print("  solver stages (s):", {k: round(v, 3) for k, v in m.fit_timings_.items() if v and not k.endswith(("flops", "launches"))})
-t = time.time(); m2 = mk().fit(X, y); print(f"  second full-size fit (workspace already allocated): {time.time() - t:.2f} s, solver {m2.fit_timings_['total']:.2f} s")
-pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
+pr2 = cProfile.Profile(); t = time.time(); pr2.enable(); m2 = mk().fit(X, y); pr2.disable()
+print(f"  second full-size fit (workspace already allocated): {time.time() - t:.3f} s, solver {m2.fit_timings_['total']:.3f} s, stages {({k: round(v, 4) for k, v in m2.fit_wall_.items()})}")
+pstats.Stats(pr2 if len(sys.argv) > 5 and sys.argv[5] == "second" else pr).sort_stats("cumulative").print_stats(40)

@@ -24,6 +24,9 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
+# rocBLAS's own process-wide switch (real GEMMs through hipBLASLt: 5.5 ms of a c4 fit): exported by this launcher for its own process and the
+# ranks it spawns - the library itself does not touch the environment; a caller's explicit choice stands
+os.environ.setdefault("ROCBLAS_USE_HIPBLASLT", "1")
 
 CONFIGS = {
     # BASELINE.json configs[2] - the configuration the metric is quoted on

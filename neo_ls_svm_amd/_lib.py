@@ -237,11 +237,9 @@ def load_library() -> C.CDLL:
             "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C neo_ls_svm_amd/csrc`). "
             "neo_ls_svm_amd has no CPU fallback."
         )
-    # rocBLAS's real GEMMs through hipBLASLt: the first back-transformation of the two-stage eigendecomposition (the W = V^T C products at real
-    # n = 1e4) runs at 37.5 instead of 43 ms; complex and small products measured unchanged.  The switch is rocBLAS's own and
-    # process-wide, read when rocBLAS initialises - so it is set here, before the library (and with it rocBLAS) is loaded, and only when the
-    # caller has not chosen (ROCBLAS_USE_HIPBLASLT=0 keeps the Tensile kernels).
-    os.environ.setdefault("ROCBLAS_USE_HIPBLASLT", "1")
+    # (ROCBLAS_USE_HIPBLASLT=1 - rocBLAS's own, process-wide switch: the real GEMMs of the two-stage eigendecomposition's first back-transformation
+    # run at 37.5 instead of 43 ms at n = 1e4 - is the LAUNCHER's to export: loading this library does not change the host process's environment,
+    # INTEGRATION.md section 5)
     lib = C.CDLL(str(LIB_PATH))
     for name, (restype, argtypes) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the export is missing

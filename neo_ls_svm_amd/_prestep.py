@@ -16,12 +16,50 @@ It is O(n d log n) sort/select work on the CPU - SURVEY.md 8(f) lists it as the 
 
 from __future__ import annotations
 
+import os
+
 import numpy as np
 from threadpoolctl import ThreadpoolController
 
 __all__ = ["target_bins", "weighted_median_columns", "fit_affine_normalizer", "fit_affine_separator", "blas_threads"]
 
 _controller = None
+
+
+_pool = None
+
+
+def host_pool():
+    """A process-wide pool of eight host threads for the pre-step's independent small pieces (the separator's bins, the ORF blocks' QRs).
+    Persistent: starting threads costs ~2 ms each - 6 of a 100 ms fit at n = 1e5 when a pool is made per call - and the workers spend
+    their time in NumPy / LAPACK calls that release the GIL."""
+    global _pool
+    if _pool is None:
+        from concurrent.futures import ThreadPoolExecutor
+
+        _pool = ThreadPoolExecutor(max_workers=8, thread_name_prefix="nls-prestep")
+    return _pool
+
+
+class _Inline:
+    """``submit`` that runs the call at once on the calling thread (the pre-step without its pipeline: NLS_PRESTEP_PIPELINE=0)."""
+
+    class _Done:
+        def __init__(self, value):
+            self.value = value
+
+        def result(self):
+            return self.value
+
+    def submit(self, fn, *args):
+        return self._Done(fn(*args))
+
+
+def _pipelined() -> bool:
+    """NLS_PRESTEP_PIPELINE=1: the element-wise halves of the separator's distance matrices on pool threads beside the calling thread's
+    products.  Same numbers either way.  Off unless asked for: with few host cores the pool threads and the BLAS's own (spinning) workers
+    take each other's cores - measured 46 -> 110 ms on 8 cores; see DESIGN.md section 9 for the GPU box's figure."""
+    return os.environ.get("NLS_PRESTEP_PIPELINE", "0") == "1"
 
 
 def blas_threads(limit: int):
@@ -252,17 +290,26 @@ def _sq_dists(P, Q):
     """||p_i - q_j||^2 by the expansion (|p|^2 - 2 p.q) + |q|^2, in the reference's order of operations (``_affine_separator.py:24-29``:
     the nearest-neighbour argmin over near-ties depends on the rounding) but in ONE buffer: the three n x m temporaries of the plain
     expression cost more than the product itself at these sizes (384 ... 1536 rows)."""
-    D = P @ Q.T
+    return _sq_dists_finish(P @ Q.T, P, Q)
+
+
+def _sq_dists_finish(D, P, Q):
+    """The element-wise half of ``_sq_dists`` on the product D = P Q^T (in place): no BLAS call in here, so it may run on a pool thread
+    beside the calling thread's products."""
     D *= 2.0  # exact
     np.subtract(np.sum(P * P, axis=1, keepdims=True), D, out=D)
     D += np.sum(Q * Q, axis=1, keepdims=True).T
     return D
 
 
+def _nearest_finish(D, P, Q):
+    idx = np.argmin(_sq_dists_finish(D, P, Q), axis=1, keepdims=True)
+    return np.take_along_axis(Q, idx, axis=0)
+
+
 def _nearest_rows(P, Q):
     """Rows of Q nearest to each row of P: ``_affine_separator.py:24-29``."""
-    idx = np.argmin(_sq_dists(P, Q), axis=1, keepdims=True)
-    return np.take_along_axis(Q, idx, axis=0)
+    return _nearest_finish(P @ Q.T, P, Q)
 
 
 def _right_singular_vectors(M):
@@ -305,8 +352,8 @@ def fit_affine_separator(
     X = np.asarray(X)
     y = np.ravel(np.asarray(y)).astype(X.dtype)
     shift, scale = (normalizer or fit_affine_normalizer)(X, y, sample_weight)
-    # The edge-sample products below are a few hundred rows wide: on a 64-thread BLAS they spend their time in thread
-    # hand-offs (13 ms per 1536 x 128 x 1536 product against 3 ms on 8 threads).
+    # (the edge-sample products are a few hundred rows wide: on a 64-thread BLAS they spend their time in thread hand-offs - 13 ms per
+    # 1536 x 128 x 1536 product against 3 ms on 8 threads; since round 6 the bins run side by side, one BLAS thread each)
     with blas_threads(8):
         return _separator_directions(X, y, sample_weight, shift, scale, rank_threshold, edge_sample_size, edge_search_multiplier, random_state, unique)
 
@@ -325,25 +372,54 @@ def _separator_directions(X, y, sample_weight, shift, scale, rank_threshold, edg
 
     m = int(edge_sample_size * 4 / 3) if len(ids) == 2 else edge_sample_size
     gen = random_state if isinstance(random_state, np.random.RandomState) else np.random.RandomState(random_state)
-    dirs, edge_in, edge_out = [], [], []
+    # The draws first, in the reference's order (one random stream: seeds, outside candidates, inside candidates per bin) ...
+    draws = []
     for i in range(len(ids)):
-        seeds = rows(ids[i][gen.choice(len(ids[i]), size=m, p=p_bins[i])])
+        seeds_ix = ids[i][gen.choice(len(ids[i]), size=m, p=p_bins[i])]
         rest = np.concatenate([ix for j, ix in enumerate(ids) if j != i])
         s_rest = sw[rest]
-        cand = rows(rest[gen.choice(len(rest), size=m * edge_search_multiplier, p=s_rest / np.sum(s_rest))])
-        outside = _nearest_rows(seeds, cand)
+        cand_ix = rest[gen.choice(len(rest), size=m * edge_search_multiplier, p=s_rest / np.sum(s_rest))]
+        cand_in_ix = ids[i][gen.choice(len(ids[i]), size=m * edge_search_multiplier, p=p_bins[i])]
+        draws.append((seeds_ix, cand_ix, cand_in_ix))
+
+    # ... then the bins pipelined over host threads.  Every BLAS / LAPACK call stays on THIS thread with the caller's thread count: the
+    # nearest-neighbour argmin sits on near-ties whose outcome follows the rounding of the distance product, and that follows how the product
+    # is split over BLAS threads (under a one-thread product half of the ames-shaped fixture's B changes) - and several multi-threaded BLAS calls
+    # at once fight over the cores (measured: 47 -> 650 ms).  What runs beside them on the pool is the element-wise half of each distance
+    # matrix (scale, two broadcast adds, argmin, gather: 0.8 of each 1 ms call at these sizes): the same operations on the same numbers.
+    pool = host_pool() if _pipelined() else _Inline()
+    nb_ = len(ids)
+    first = []
+    for seeds_ix, cand_ix, _ in draws:
+        P, Q = rows(seeds_ix), rows(cand_ix)
+        first.append(pool.submit(_nearest_finish, P @ Q.T, P, Q))
+    second, edge_out = [], []
+    for k, (_, _, cand_in_ix) in enumerate(draws):
+        outside = first[k].result()
         edge_out.append(outside)
-        cand_in = rows(ids[i][gen.choice(len(ids[i]), size=m * edge_search_multiplier, p=p_bins[i])])
-        inside = _nearest_rows(outside, cand_in)
+        Q = rows(cand_in_ix)
+        second.append(pool.submit(_nearest_finish, outside @ Q.T, outside, Q))
+    edge_in, dirs = [], []
+    for k in range(nb_):
+        inside = second[k].result()
         edge_in.append(inside)
-        sv, V = _right_singular_vectors(inside - outside)
+        sv, V = _right_singular_vectors(inside - edge_out[k])
         dirs.append(V[:, : int(np.sum(sv > rank_threshold * sv[0]))])
     A = np.hstack(dirs)
-    inter = intra = 0.0
     n_inter, n_intra = m * (m + 1) / 2, m * (m - 1) / 2
-    for ein, eout, nb in zip(edge_in, edge_out, n_bins):
-        inter += nb * np.sum(np.tril(_sq_dists(ein @ A, eout @ A), k=0)) / n_inter
-        intra += nb * np.sum(np.tril(_sq_dists(ein @ A, ein @ A), k=-1)) / n_intra
+
+    def spread(D, P, Q, k, norm):
+        return np.sum(np.tril(_sq_dists_finish(D, P, Q), k=k)) / norm
+
+    futs = []
+    for k in range(nb_):
+        ein, eout = edge_in[k] @ A, edge_out[k] @ A
+        futs.append((pool.submit(spread, ein @ eout.T, ein, eout, 0, n_inter), pool.submit(spread, ein @ ein.T, ein, ein, -1, n_intra)))
+    parts = [(fi.result(), fa.result()) for fi, fa in futs]
+    inter = intra = 0.0
+    for (pi, pa), nb in zip(parts, n_bins):  # (summed in bin order, as the reference's loop does)
+        inter += nb * pi
+        intra += nb * pa
     inter /= sum(n_bins)
     intra /= sum(n_bins)
     lam = np.sqrt(2 * np.log(inter / intra) / (inter - intra)) if intra > 0 else 1

@@ -173,12 +173,8 @@ extern "C" int nls_ctx_create(int device, nls_ctx** out) {
   if (const char* ek = std::getenv("NLS_ROT_KSTAGGER")) ctx->rot_kstagger = std::max(0, std::min(16, std::atoi(ek)));
   if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess)
     return bail("hipStreamCreate", hipGetErrorString(e));
-  // (rocBLAS's real GEMMs through hipBLASLt - Q1 of the two-stage eigendecomposition 43 -> 37.5 ms at n = 1e4; takes effect only if rocBLAS has
-  // not read its environment yet: a C host exports ROCBLAS_USE_HIPBLASLT=1 itself; never overrides the caller's choice)
-  {
-    static std::once_flag once;  // (contexts of a group are created on several host threads at once; setenv is not re-entrant)
-    std::call_once(once, [] { setenv("ROCBLAS_USE_HIPBLASLT", "1", 0); });
-  }
+  // (ROCBLAS_USE_HIPBLASLT - Q1 of the two-stage eigendecomposition 43 -> 37.5 ms at n = 1e4 - is rocBLAS's own process-wide switch and the
+  // launcher's to export: the library does not touch the host's environment)
   if (rocblas_create_handle(&ctx->blas) != rocblas_status_success) return bail("rocblas_create_handle", "status != success");
   rocblas_set_stream(ctx->blas, ctx->stream);
   {  // the feature map's sincos table (8 KB), computed on the host in long double

@@ -16,6 +16,7 @@ import numpy as np
 
 from . import _lib
 from ._hostpool import factor_output
+from . import _prestep
 from ._prestep import blas_threads
 from ._lib import Context, DeviceArray, DualFitArgs, Factor, Group, GroupFactor, PrimalFitArgs, SigmaGrid, default_context, default_group
 
@@ -65,10 +66,8 @@ def orf_frequencies(d: int, D: int, random_state=42) -> np.ndarray:
     # blocks run side by side on host threads instead (LAPACK releases the GIL).  The rounding pattern of a block does not depend on how many
     # run at once, only on the BLAS thread count of its own call - fixed at one here when there are several blocks.
     if len(starts) > 1:
-        from concurrent.futures import ThreadPoolExecutor
-
-        with blas_threads(1), ThreadPoolExecutor(max_workers=min(len(starts), 16)) as pool:
-            qs = list(pool.map(block_q, starts))
+        with blas_threads(1):  # (the pre-step's persistent pool: a pool per call costs ~6 ms of thread starts)
+            qs = list(_prestep.host_pool().map(block_q, starts))
     else:
         with blas_threads(8):
             qs = [block_q(0)]

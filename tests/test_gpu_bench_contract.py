@@ -39,8 +39,12 @@ def test_bench_line_contract():
     assert ro["bound"] == "mfma" and ro["unit"] == "TFLOP/s" and ro["peak"] == 78.6 and abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-12
     assert 0 < ro["frac"] < 1.0, "frac is the matrix-pipe utilisation: executed flops / time / peak"
     assert 1.0 < ro["algorithmic_gain"] < 1.5
+    # what the run cannot measure itself (counter passes under profiles/) is labelled as such, apart from the live fields
+    assert "NOT measured by this run" in ro["from_profiles"]["what"] and "mfma_busy" in ro["from_profiles"] and "mfma_busy" not in ro
     k1 = d["roofline_k1"]
     assert k1["bound"] == "hbm" and k1["unit"] == "GB/s" and k1["peak"] == 8000.0 and 0 < k1["frac"] < 1
+    dp = k1["datapath"]  # the bound that binds K1: matrix pipe + vector issue on the shared fp64 datapath
+    assert dp["valu_instructions_per_feature"] > 30 and abs(dp["bound_ms_per_launch"] - dp["matrix_ms_per_launch"] - dp["valu_ms_per_launch"]) < 1e-9 and 0 < dp["frac"] < 1
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "fits/s" and cb["cores"] >= 1 and cb["host_cpus"] >= cb["cores"] and "mode" in cb and "sample" in cb
     assert cb["value"] > 0 and "seconds_mode_R" in cb and "seconds_mode_S" in cb  # c0 fits host RAM: both schedules at full size
@@ -52,3 +56,17 @@ def test_bench_through_a_one_rank_rccl_communicator(tmp_path):
     assert d["n_gpus"] == 1 and d["cpu_baseline"] is None and d["value"] > 0
     assert d["stage_ms_per_step"]["allreduce"] > 0.0  # the collectives really ran (RCCL on the device buffers)
     assert not list(tmp_path.iterdir()), "rank 0 removes the rendezvous file"
+
+
+def test_bench_virtual_rank_line(tmp_path):
+    """``--as-rank r --of W``: one rank's share of a W-GPU sharded fit on one GPU (own rows, own eigenvector columns, every exchange through a
+    one-rank communicator on the real librccl); the peers' blocks are replayed from a captured complete fit, so the results must be that fit's."""
+    d = run_bench({"NLS_RENDEZVOUS_DIR": str(tmp_path)}, args=("--no-cpu-baseline", "--no-end-to-end", "--as-rank", "1", "--of", "4"))
+    v = d["virtual_rank"]
+    assert (v["rank"], v["of"], v["global_n"]) == (1, 4, 20_000) and d["n_gpus"] == 1 and d["config"]["rows_per_gpu"] == 5_000
+    assert "VIRTUAL rank 1 of 4" in d["config"]["parallelism"] and "not run" in d["config"]["parallelism"]
+    eq = v["equals_complete_fit"]
+    assert eq["argmin_equal"] and eq["beta_max_rel_diff"] < 1e-12 and eq["loo_errors_max_rel_diff"] < 1e-12
+    assert d["stage_ms_per_step"]["allreduce"] > 0.0 and d["cpu_baseline"] is None
+    d0 = run_bench({"NLS_RENDEZVOUS_DIR": str(tmp_path)}, args=("--no-cpu-baseline", "--no-end-to-end", "--as-rank", "0", "--of", "4"))
+    assert "run (rank 0)" in d0["config"]["parallelism"] and d0["virtual_rank"]["equals_complete_fit"]["beta_max_rel_diff"] < 1e-12

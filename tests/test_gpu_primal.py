@@ -234,6 +234,27 @@ def test_sigma_grid_matches_reference(golden_loader, hp):
         assert relerr(r["loo_errors_gammas"], sg["loo_errors"][k]) < TOL
 
 
+@pytest.mark.parametrize("G", [32, 64])
+def test_small_grid_sweep_equals_the_tile_sweep(G, golden_loader, hp, monkeypatch):
+    """Grids of <= 64 points take the streaming sweep ``k_sweep_small<2>`` / ``<4>`` (the gamma x sigma grid's 32 points); ``NLS_SWEEP_SMALL=0``
+    (read per call) sends the same fit through the 128-wide tile kernel it replaces: error curve, objective, selection and row outputs must
+    agree to rounding - and both with the reference's fixture curve on the sub-grid."""
+    for name in ("primal_reg_n3000_d20_D256", "primal_clf_n3000_d16_D256_wz"):
+        g = golden_loader(name)
+        y, clf = signed_targets(g), g["task"] == "clf"
+        step = 1024 // G
+        gam = hp.gamma_grid(1024)[::step][:G]
+        monkeypatch.setenv("NLS_SWEEP_SMALL", "1")
+        a = hp.primal_fit(g["X"], y, g["s"], g["shift"], g["scale"], g["B"], clf, gammas=gam)
+        monkeypatch.setenv("NLS_SWEEP_SMALL", "0")
+        b = hp.primal_fit(g["X"], y, g["s"], g["shift"], g["scale"], g["B"], clf, gammas=gam)
+        monkeypatch.delenv("NLS_SWEEP_SMALL")
+        assert a["opt"] == b["opt"]
+        for k in ("loo_errors_gammas", "objective", "loo_residuals", "loo_leverage", "loo_std", "beta"):
+            assert relerr(a[k], b[k]) < 1e-12, (name, k, relerr(a[k], b[k]))
+        assert relerr(a["loo_errors_gammas"], g["loo_errors_gammas"][::step][:G]) < TOL
+
+
 def test_sigma_grid_driver(golden_loader, hp):
     """The gamma x sigma driver reproduces the reference's per-sigma error tables and picks the joint minimum."""
     sg = golden_loader("sigma_grid_reg_n3000")

@@ -1,5 +1,7 @@
 import sys, time
 sys.path.insert(0, '/root/repo')
+import os
+os.environ.setdefault("ROCBLAS_USE_HIPBLASLT", "1")  # the launcher's export
 import numpy as np
 import neo_ls_svm_amd as hp
 n, d = 10000, 256

@@ -4,6 +4,8 @@ import sys, time
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 sys.path[:0] = [str(ROOT), str(ROOT / "oracle")]
+import os
+os.environ.setdefault("ROCBLAS_USE_HIPBLASLT", "1")  # the launcher's export
 import numpy as np
 import neo_ls_svm_amd as hp
 

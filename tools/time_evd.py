@@ -2,6 +2,8 @@
 import sys, time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import os
+os.environ.setdefault("ROCBLAS_USE_HIPBLASLT", "1")  # the launcher's export
 import numpy as np
 import neo_ls_svm_amd as hp
 

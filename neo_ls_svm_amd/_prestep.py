@@ -56,10 +56,12 @@ class _Inline:
 
 
 def _pipelined() -> bool:
-    """NLS_PRESTEP_PIPELINE=1: the element-wise halves of the separator's distance matrices on pool threads beside the calling thread's
-    products.  Same numbers either way.  Off unless asked for: with few host cores the pool threads and the BLAS's own (spinning) workers
-    take each other's cores - measured 46 -> 110 ms on 8 cores; see DESIGN.md section 9 for the GPU box's figure."""
-    return os.environ.get("NLS_PRESTEP_PIPELINE", "0") == "1"
+    """The BLAS-free halves of the separator's direction step - the sampling cdfs of its draws and the element-wise halves of its distance
+    matrices - on pool threads beside the calling thread's products.  Same numbers either way (NLS_PRESTEP_PIPELINE=0 / 1 forces).  On by
+    default only with at least 32 host cores: with few, the pool threads and the BLAS's own (spinning) workers take each other's cores -
+    measured at n = 1e5: 39 -> 25-31 ms per call on the GPU box's 256 cores (before the cdfs moved to the pool too), ~100 -> ~120 ms on 8."""
+    e = os.environ.get("NLS_PRESTEP_PIPELINE")
+    return e == "1" if e in ("0", "1") else (os.cpu_count() or 1) >= 32
 
 
 def blas_threads(limit: int):
@@ -372,14 +374,30 @@ def _separator_directions(X, y, sample_weight, shift, scale, rank_threshold, edg
 
     m = int(edge_sample_size * 4 / 3) if len(ids) == 2 else edge_sample_size
     gen = random_state if isinstance(random_state, np.random.RandomState) else np.random.RandomState(random_state)
-    # The draws first, in the reference's order (one random stream: seeds, outside candidates, inside candidates per bin) ...
-    draws = []
-    for i in range(len(ids)):
-        seeds_ix = ids[i][gen.choice(len(ids[i]), size=m, p=p_bins[i])]
+    # The draws first, in the reference's order (one random stream: seeds, outside candidates, inside candidates per bin).  The reference calls
+    # RandomState.choice(len, size, p), which is  cdf = p.cumsum(); cdf /= cdf[-1]; idx = cdf.searchsorted(random_sample(size), "right")
+    # (numpy/random/mtrand.pyx, legacy sampling with replacement): the cdf halves - a concatenation of n indices, three n-long element-wise
+    # passes and a cumsum per bin, half of this function's time at n = 1e5 - consume no random numbers, so they are prepared side by side on
+    # the pool and only the random_sample calls follow the stream's order.  Same draws, bit for bit (the fixtures pin B).
+    pool = host_pool() if _pipelined() else _Inline()
+
+    def cdf_of(p):
+        cdf = p.cumsum()
+        cdf /= cdf[-1]
+        return cdf
+
+    def prepare(i):  # (no BLAS in here)
         rest = np.concatenate([ix for j, ix in enumerate(ids) if j != i])
         s_rest = sw[rest]
-        cand_ix = rest[gen.choice(len(rest), size=m * edge_search_multiplier, p=s_rest / np.sum(s_rest))]
-        cand_in_ix = ids[i][gen.choice(len(ids[i]), size=m * edge_search_multiplier, p=p_bins[i])]
+        return rest, cdf_of(s_rest / np.sum(s_rest)), cdf_of(np.asarray(p_bins[i], dtype=np.float64))
+
+    prepared = [pool.submit(prepare, i) for i in range(len(ids))]
+    draws = []
+    for i in range(len(ids)):
+        rest, cdf_rest, cdf_in = prepared[i].result()
+        seeds_ix = ids[i][cdf_in.searchsorted(gen.random_sample(m), side="right")]
+        cand_ix = rest[cdf_rest.searchsorted(gen.random_sample(m * edge_search_multiplier), side="right")]
+        cand_in_ix = ids[i][cdf_in.searchsorted(gen.random_sample(m * edge_search_multiplier), side="right")]
         draws.append((seeds_ix, cand_ix, cand_in_ix))
 
     # ... then the bins pipelined over host threads.  Every BLAS / LAPACK call stays on THIS thread with the caller's thread count: the
@@ -387,7 +405,6 @@ def _separator_directions(X, y, sample_weight, shift, scale, rank_threshold, edg
     # is split over BLAS threads (under a one-thread product half of the ames-shaped fixture's B changes) - and several multi-threaded BLAS calls
     # at once fight over the cores (measured: 47 -> 650 ms).  What runs beside them on the pool is the element-wise half of each distance
     # matrix (scale, two broadcast adds, argmin, gather: 0.8 of each 1 ms call at these sizes): the same operations on the same numbers.
-    pool = host_pool() if _pipelined() else _Inline()
     nb_ = len(ids)
     first = []
     for seeds_ix, cand_ix, _ in draws:

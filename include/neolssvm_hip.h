@@ -291,7 +291,8 @@ int nls_primal_fit(nls_ctx* ctx, const nls_primal_fit_args* args);
  *      is the separator's own bandwidth, so the incumbent is good from the start;
  *   2. the first sigma is finished unconditionally (P8 / P9: Cholesky re-solve, row outputs, L); a later one only when its selected
  *      objective is STRICTLY below the incumbent's (NLS_FIT_FINISH_IF_BELOW) - its outputs then replace the incumbent's in args' buffers;
- *   3. with world > 1 and a merge context the Sg x G tables (each sigma owned by one rank, zeros elsewhere) are summed over the ranks;
+ *   3. with world > 1 and a merge context the Sg x G tables (each sigma owned by one rank, zeros elsewhere) are summed over the ranks -
+ *      after a status vote on the merge communicator: a rank whose own fits failed takes every rank out of the call (see nls_comm_*);
  *      without one the rows of the other ranks' sigmas are NaN;
  *   4. sigma_index = first minimum over the owned sigmas of min_g objective[k][g] (numpy.argmin: ties go to the SMALLEST index); unmerged,
  *      a tie that includes the finished incumbent goes to the incumbent (it carries the full result); gamma_index = argmin_g of that row.

@@ -415,9 +415,20 @@ extern "C" int nls_primal_fit_grid(nls_ctx* ctx, const nls_primal_fit_args* a, c
                                   "of the merge on a second context, grid->merge)");
   if (gr->merge == ctx) return fail(ctx, NLS_ERR_ARG, "grid->merge must be a context other than the fitting context");
   GridLocal loc;
-  NLSCHK(grid_local_pass(ctx, a, gr->sigmas, Sg, rank, world, &loc));
-  std::vector<char> owned((size_t)Sg, 0);
   const bool merged = world > 1 && gr->merge != nullptr;
+  {
+    // A rank whose own sigmas failed must not leave its peers in the merge's all-reduces: its status goes into a vote on the merge
+    // communicator first (comm_vote, nls_host.h), and every rank of the grid leaves together.  (Without a merge context no rank waits for another.)
+    const int rc_local = grid_local_pass(ctx, a, gr->sigmas, Sg, rank, world, &loc);
+    if (merged) {
+      gr->merge->voted_out = gr->merge->vote_victim = false;
+      const int rc = comm_vote(gr->merge, rc_local, "before the merge of the sigma grid's tables");
+      if (rc != NLS_OK) return rc_local != NLS_OK ? rc_local : fail(ctx, rc, "%s", nls_last_error(gr->merge));
+    } else {
+      NLSCHK(rc_local);
+    }
+  }
+  std::vector<char> owned((size_t)Sg, 0);
   if (merged) {  // step 3: every sigma is owned by one rank, the others hold zeros -> a sum all-reduce in pieces of NLS_COMM_UTIL_MAX
     auto sum_all = [&](std::vector<double>& v) -> int {
       for (size_t off = 0; off < v.size(); off += NLS_COMM_UTIL_MAX) {

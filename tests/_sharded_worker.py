@@ -315,6 +315,39 @@ def run_gpu_lost_rank(rank, world, how):
     ctx.close()
 
 
+def run_gpu_grid_fault(rank, world):
+    """The sigma-sharded grid (``nls_primal_fit_grid`` with a merge context): ONE rank's own fits fail (only that process sets NLS_FAULT_INJECT);
+    without a vote its peers would wait in the merge's all-reduces for the deadline.  Every rank must return at once, and the same merge
+    communicator must carry the next grid."""
+    import time
+
+    from neo_ls_svm_amd._lib import NlsError
+
+    bad = int(os.environ["NLS_TEST_LOST_RANK"])
+    hp, cctx = _native_ctx(rank, world)  # the communicator-only context of the merge
+    ctx = hp.Context(0)
+    X, y, s, shift, scale, B = problem(n=3000, d=8, D=64, clf=False)
+    sig, gam = np.logspace(-0.5, 0.5, 8), hp.gamma_grid(1024)[::33]
+    if rank == bad:
+        os.environ["NLS_FAULT_INJECT"] = "sweep"
+    t0 = time.monotonic()
+    try:
+        hp.primal_fit_sigma_grid(X, y, s, shift, scale, B, False, sig, gammas=gam, ctx=ctx, rank=rank, world=world, merge_ctx=cctx, want_L=False)
+    except NlsError as exc:
+        waited, msg = time.monotonic() - t0, str(exc)
+        assert waited < 45.0, f"rank {rank} waited {waited:.1f} s"
+        assert ("injected fault" in msg) if rank == bad else (f"rank {bad} of {world} failed with NLS_ERR_HIP" in msg and "merge" in msg), msg
+    else:
+        raise AssertionError(f"rank {rank}: the grid returned although rank {bad}'s fits failed")
+    os.environ.pop("NLS_FAULT_INJECT", None)
+    assert cctx.comm_state == "joined"
+    g = hp.primal_fit_sigma_grid(X, y, s, shift, scale, B, False, sig, gammas=gam, ctx=ctx, rank=rank, world=world, merge_ctx=cctx, want_L=False)
+    g1 = hp.primal_fit_sigma_grid(X, y, s, shift, scale, B, False, sig, gammas=gam, ctx=ctx, want_L=False)  # the whole grid on this rank alone
+    assert (g["sigma_index"], g["gamma_index"]) == (g1["sigma_index"], g1["gamma_index"])
+    ctx.close()
+    cctx.close()
+
+
 if __name__ == "__main__":
     mode = sys.argv[1]
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
@@ -324,6 +357,10 @@ if __name__ == "__main__":
         sys.exit(0)
     if mode == "gpu_rccl_fault":
         run_gpu_fault(rank, world)
+        print(f"OK {rank}", flush=True)
+        sys.exit(0)
+    if mode == "gpu_grid_fault":
+        run_gpu_grid_fault(rank, world)
         print(f"OK {rank}", flush=True)
         sys.exit(0)
     if mode in ("gpu_rccl_lost_call", "gpu_rccl_lost_dead"):

@@ -165,6 +165,15 @@ def test_one_rank_fails_locally_every_rank_returns_at_the_vote(world, spec):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world, bad", [(2, 1), (8, 4)])
+def test_one_rank_of_the_sigma_grid_fails_every_rank_returns_at_the_vote(world, bad):
+    """The gamma x sigma grid shards the SIGMAS; its only exchange is the merge of the small tables on a second, communicator-only
+    context.  ONE rank's own fits fail: the status vote on the merge communicator takes every rank out at once (its own error on the
+    failed rank, NLS_ERR_COMM naming it on the others), and the next grid on the same communicator names the single-rank winner."""
+    _launch_native("gpu_grid_fault", world, {"NLS_TEST_LOST_RANK": str(bad), "NLS_COMM_TIMEOUT_S": "90", **ASYNC_STAND_IN}, timeout=900)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("world, bad, call", [(2, 1, 5), (8, 3, 9)])
 def test_one_rank_loses_an_rccl_call_the_others_meet_the_deadline(world, bad, call):
     """The ``call``-th collective of rank ``bad`` ALONE fails inside the communication library (the stand-in's asymmetric injection): that

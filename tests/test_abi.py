@@ -258,6 +258,21 @@ def test_rendezvous_explicit_key_joins_ranks_of_different_parents(tmp_path, monk
     assert distributed._launch_nonce() != distributed._launch_nonce(explicit_key=True)
 
 
+def test_graft_entry_build_runs_and_agrees_on_the_abi_version():
+    """``__graft_entry__.build()`` - the driver's "does it build" check - compiles (or finds up to date) the library and asserts the ABI
+    version: header, library, Python mirror and that assertion must move together (round 6 bumped three of the four at first)."""
+    import re
+
+    import __graft_entry__ as g
+
+    from neo_ls_svm_amd import _lib
+
+    header = (ROOT / "include" / "neolssvm_hip.h").read_text()
+    version = int(re.search(r"#define\s+NLS_ABI_VERSION\s+(\d+)", header).group(1))
+    assert version == _lib.ABI_VERSION
+    g.build()  # raises on a mismatch (and when the sources do not compile)
+
+
 def test_no_cpu_fallback_without_gpu():
     """On a box without an MI355X the context must refuse loudly, not compute on the CPU."""
     # (torch is deliberately not imported here: loading torch's bundled ROCm after this library's

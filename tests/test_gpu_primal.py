@@ -453,6 +453,53 @@ def test_single_rank_rccl_communicator(golden_loader, hp):
         ctx.close()
 
 
+def test_failure_handling_entry_points_on_real_rccl(golden_loader, hp, monkeypatch):
+    """The failure contract's RCCL calls - ``ncclCommAbort``, ``ncclCommGetAsyncError``, the status vote's all-reduce, the polling wait - on the
+    REAL librccl (a one-rank communicator: the only kind one GPU allows): a local fault goes through the vote and leaves the communicator
+    joined; ``nls_comm_abort`` gives it up, the context then refuses sharded work until it joins a new one; results are unchanged throughout."""
+    from neo_ls_svm_amd._lib import NlsError
+
+    g = golden_loader("primal_reg_n3000_d20_D256")
+    y = signed_targets(g)
+
+    def fit(ctx):
+        return hp.primal_fit(g["X"], y, g["s"], g["shift"], g["scale"], g["B"], False, ctx=ctx)
+
+    ctx = hp.Context(0)
+    try:
+        assert ctx.comm_state == "none"
+        ctx.comm_init(ctx.comm_unique_id(), 0, 1)
+        ctx.comm_set_timeout(60.0)
+        assert ctx.comm_state == "joined"
+        r1 = fit(ctx)
+        for site in ("prepare", "gram", "evd", "backtransform", "sweep", "select", "cholesky"):
+            monkeypatch.setenv("NLS_FAULT_INJECT", f"{site}:0")
+            with pytest.raises(NlsError, match=f"injected fault at '{site}'"):
+                fit(ctx)
+            assert ctx.comm_state == "joined", site  # left through the vote: nothing pending, communicator intact
+        monkeypatch.setenv("NLS_FAULT_INJECT", "cholesky:0:3")
+        with pytest.raises(np.linalg.LinAlgError):
+            fit(ctx)
+        monkeypatch.delenv("NLS_FAULT_INJECT")
+        r2 = fit(ctx)
+        for k in ("beta", "loo_residuals", "loo_errors_gammas", "residuals", "L"):
+            assert np.array_equal(r1[k], r2[k]), k
+        ctx.comm_abort()
+        assert ctx.comm_state == "aborted"
+        with pytest.raises(NlsError, match="aborted"):
+            fit(ctx)
+        with pytest.raises(NlsError, match="aborted"):
+            ctx.comm_allreduce([1.0])
+        ctx.comm_init(ctx.comm_unique_id(), 0, 1)  # a new communicator
+        assert ctx.comm_state == "joined"
+        r3 = fit(ctx)
+        assert np.array_equal(r1["beta"], r3["beta"]) and np.array_equal(r1["L"], r3["L"])
+        ctx.comm_destroy()
+        assert ctx.comm_state == "none"
+    finally:
+        ctx.close()
+
+
 @pytest.mark.parametrize("name", ["primal_reg_n3000_d20_D256", "primal_clf_n3000_d16_D256_wz"])
 def test_compressed_sweep_equals_direct_products(name, golden_loader, hp, monkeypatch):
     """The 1024-point sweep through 128 Chebyshev nodes (default) against the direct n x (D+1) x G products."""

@@ -101,9 +101,9 @@ struct nls_ctx {
   // (launch_rotate in nls_lib.hip has the counters)
   int rot_pr = 0, rot_pc = 0;
   bool rot_patch_set = false;
-  // k_gram3 tile order: 1 = contiguous run of the (split, half tile) list per XCD, 0 = round-robin, -1 = unset (NLS_GRAM_ORDER=contiguous / plain):
-  // contiguous with a communicator (17 % less traffic past L2 for the ranks that share the fabric), plain on one GPU (the contiguous order costs
-  // 1.4 % of the kernel in the counter passes and 3 % - 22 ms - per c3 fit: profiles/r04_pmc_summary.md, profiles/r04_bench_c3.json)
+  // k_gram3 tile order: 0 = round-robin (plain: the default everywhere since round 6), 1 = contiguous run of the (split, half tile) list per XCD,
+  // 2 = XCD patches, -1 = unset (NLS_GRAM_ORDER=plain / contiguous / patch).  The other orders trade traffic past L2 (17 % / 40 % less) for
+  // 1.4-2.9 % of kernel time (profiles/r04_pmc_summary.md, profiles/r05_gram_orders.md, profiles/r06_evd_world8.md).
   int gram_order = -1;
   int k1_stagger_ticks = 0;  // NLS_K1_STAGGER_US: period over which the first-round workgroups of K1 are spread (k1_stagger)
   int rot_kstagger = 0;  // NLS_ROT_KSTAGGER=S: K-walk phase (tr + tc) % S slices per workgroup (see mainloop_3m)

@@ -558,7 +558,10 @@ static int primal_gram_local(nls_ctx* ctx, PrimalState& st, double* timings) {
       const long rps = round_up((rows_pad + nsplit - 1) / nsplit, BK);
       const long ns = (rows_pad + rps - 1) / rps;
       const long gblocks = half_tiles * ns;
-      const int order = ctx->gram_order >= 0 ? ctx->gram_order : (multi_rank(ctx) ? 1 : 0);  // 0 plain, 1 XCD-contiguous, 2 XCD patches (k_gram3)
+      // 0 plain (default), 1 XCD-contiguous, 2 XCD patches (k_gram3).  Rounds 4-5 took the contiguous order inside a communicator ("17 % less
+      // traffic past L2 for ranks that share the fabric"); but a rank's traffic past L2 stays inside ITS package (own HBM, own Infinity Cache) and the
+      // only thing ever measured is that the order costs 1.4 % of the kernel: 91.2 against 89.6-90.0 ms on rank 0's share of an 8-GPU c3 fit (round 6).
+      const int order = ctx->gram_order >= 0 ? ctx->gram_order : 0;
       long ggrid = order == 1 ? round_up(gblocks, 8) : gblocks;
       if (order == 2) {
         const long pa = (st.nt + 3) / 4, npatch = pa * (pa + 1) / 2;
